@@ -1,0 +1,117 @@
+/* mmgt_hip.h — C ABI of libmmgt_hip.so: the MI355X (gfx950) kernels behind MMGT's Stage-2 denoising path.
+ *
+ * This is the drop-in boundary.  The reference has no native layer at all: every call below replaces arithmetic that
+ * the reference reaches through PyTorch / diffusers modules, cited per entry point (paths relative to the reference
+ * checkout).  A maintainer binds these with ctypes; mmgt_amd/hip.py is exactly such a binding.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers unless stated; inputs are borrowed and never written; outputs are caller-owned.
+ *  - `dtype` selects the storage type of activations and weights: MMGT_BF16 (product) or MMGT_F32 (the fp32-I/O parity
+ *    mode of the same kernels).  Accumulation is always fp32.  Bias / norm affine / mask / scale vectors are fp32.
+ *  - Activations are channels-last: an image tensor is (N, H, W, C) == a token matrix (N*H*W, C), row stride given.
+ *  - `stream` is a hipStream_t (0 = default stream).  Calls only enqueue work; nothing synchronises, allocates or frees,
+ *    so sequences of calls may be captured into a hipGraph.
+ *  - Return 0 on success, non-zero on error with a message in mmgt_last_error() (thread-local).  Unsupported shapes are
+ *    errors; there is no fallback path.
+ */
+#ifndef MMGT_HIP_H
+#define MMGT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMGT_F32 0
+#define MMGT_BF16 1
+
+#define MMGT_ACT_NONE 0
+#define MMGT_ACT_GEGLU 1 /* weights packed per 64 rows as [32 h | 32 gate]; output has N/2 columns */
+#define MMGT_ACT_SILU 2
+
+int mmgt_abi_version(void);
+const char* mmgt_last_error(void);
+
+/* out[M,N] = epi(A[M,K] . W[N,K]^T):  v = acc + bias[n] + bias2[m / bias2_rows][n]; v = act(v);
+ * v *= row_scale[m] * alpha; v += residual[m][n].   Optional batch (grid.z) with element strides bs*.
+ * Replaces: nn.Linear / 1x1 nn.Conv2d / diffusers Attention.to_q,to_k,to_v,to_out / FeedForward(GEGLU) call sites
+ * src/models/transformer_3d.py:176,253; src/models/attention.py:323-349,361,465,568-626,730-769;
+ * src/models/motion_module.py:161,172,233,256; src/models/resnet.py:211-215,226,243; src/models/unet_3d.py:502. */
+int mmgt_gemm(const void* A, long lda, const void* W, const float* bias, const float* bias2, int bias2_rows,
+              const float* row_scale, float alpha, const void* residual, long ldr, void* out, long ldo, int M, int N,
+              int K, int act, int batch, long bsA, long bsW, long bsR, long bsO, int dtype, void* stream);
+
+/* 3x3 / pad 1 convolution on channels-last input as implicit GEMM.  x0 (NB,IH,IW,C0) and optional x1 (NB,IH,IW,C1) are
+ * read as one (C0+C1)-channel tensor (the UNet skip concat, unet_3d_blocks.py:894,1057); `upsample` = the conv sees the
+ * nearest-2x upsampled input (Upsample3D, resnet.py:70-88); stride 2 = Downsample3D (resnet.py:112-120).
+ * Wp: [Cout][3][3][C0+C1].  out (NB,OH,OW,Cout) = act(conv + bias + bias2[pixel / bias2_rows]) + residual.
+ * Replaces: InflatedConv3d (src/models/resnet.py:9-17) in ResnetBlock3D.conv1/conv2 (resnet.py:223,240), conv_in /
+ * conv_out (unet_3d.py:517,620), PoseGuider convs (pose_guider.py:47-57), AutoencoderKL decoder convs (diffusers). */
+int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1, int NB, int IH, int IW, int stride, int upsample,
+                      const void* Wp, const float* bias, const float* bias2, int bias2_rows, const void* residual,
+                      void* out, int Cout, int act, int dtype, void* stream);
+
+/* GroupNorm over channels-last images, one statistic per (image, group), optional fused SiLU.
+ * x,out (NB, HW, C) where C = C0 + C1 may be split over two sources (skip concat); workspace: NB*chunks*G*2 floats
+ * with chunks = mmgt_groupnorm_chunks(HW).
+ * Replaces: InflatedGroupNorm / nn.GroupNorm (+F.silu) at resnet.py:220-221,231,237; transformer_3d.py:174;
+ * motion_module.py:156; unet_3d.py:618-619. */
+int mmgt_groupnorm_chunks(int HW);
+int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta, void* out,
+                        float* workspace, int NB, int HW, int G, float eps, int silu, int dtype, void* stream);
+
+/* LayerNorm over the last dimension of a (rows, C) token matrix, optional additive table pe[(row / pe_div) % pe_mod][C]
+ * applied AFTER the affine transform (the temporal positional encoding enters q, k and v: motion_module.py:359-366).
+ * Replaces: nn.LayerNorm at attention.py:392-396,450-454,465,677-681,712-716,769; motion_module.py:244,256;
+ * mutual_self_attention.py:122,195-199,210; audio_proj.py:119. */
+int mmgt_layernorm(const void* x, long ldx, const float* gamma, const float* beta, float eps, const float* pe, int pe_div,
+                   int pe_mod, void* out, long ldo, int rows, int C, int dtype, void* stream);
+
+/* softmax(Q K^T * scale) V for `batch` x `heads` independent problems, flash style (scores never leave the chip).
+ *   Q element (b, i, h, d) at q[(b / q_bdiv) * q_bs0 + (b % q_bdiv) * q_bs1 + i * q_ts + h * hd + d]; K, V, O likewise.
+ *   Keys/values come from up to two segments: [K, V] with nk keys, then [K2, V2] with nk2 keys for batches
+ *   b >= seg2_first_batch (the ReferenceNet feature bank that only the conditional CFG half attends to); segment 2
+ *   uses batch index b / k2_bdiv2 with stride k2_bs.
+ *   v_transposed = 1: V (and V2) are stored [b][h*hd + d][key] (key contiguous, row stride v_ts).
+ * Replaces: diffusers Attention + AttnProcessor2_0 (F.scaled_dot_product_attention) at attention.py:323-349,568-626;
+ * motion_module.py:377-383; and the bank concat + uncond recompute of mutual_self_attention.py:149-188. */
+int mmgt_attention(const void* q, long q_bs0, long q_bs1, long q_ts, const void* k, long k_bs0, long k_bs1, long k_ts,
+                   const void* v, long v_bs0, long v_bs1, long v_ts, void* o, long o_bs0, long o_bs1, long o_ts,
+                   int bdiv, const void* k2, const void* v2, long k2_bs, long k2_ts, long v2_bs, long v2_ts, int k2_bdiv,
+                   int nk2, int seg2_first_batch, int batch, int heads, int hd, int nq, int nk, float scale,
+                   int v_transposed, int dtype, void* stream);
+
+/* Row softmax of a (rows, cols) matrix scaled by `scale` (materialised-score attention of the VAE mid block). */
+int mmgt_softmax_rows(const void* x, long ldx, void* out, long ldo, int rows, int cols, float scale, int dtype,
+                      void* stream);
+
+/* Layout / dtype plumbing between the reference's (b, c, f, h, w) fp32 tensors and channels-last T:
+ * out[(b*F + f), y, x, c] (c padded with zeros up to Cpad) <- in[b, c, f, y, x]; and the inverse (first C channels).
+ * Replaces: the einops rearranges at resnet.py:13-15; transformer_3d.py:158,178-180,248-252,264. */
+int mmgt_ncfhw_to_nhwc(const float* in, void* out, int B, int C, int F, int H, int W, int Cpad, int dtype, void* stream);
+int mmgt_nhwc_to_ncfhw(const void* in, float* out, int B, int C, int F, int H, int W, int Cpad, int dtype, void* stream);
+
+/* Sinusoidal timestep features: out[b][0:half] = cos(t_b * f_i), out[b][half:] = sin(t_b * f_i), f_i = 10000^(-i/half).
+ * Replaces: diffusers Timesteps(flip_sin_to_cos=True, shift 0) at unet_3d.py:496.  timesteps: fp32 [B] device. */
+int mmgt_timestep_features(const float* timesteps, void* out, int B, int dim, int dtype, void* stream);
+
+/* Elementwise x -> silu(x) (time embedding activation, resnet.py:226) over n elements. */
+int mmgt_silu(const void* x, void* out, long n, int dtype, void* stream);
+
+/* One CFG + DDIM update on fp32 latents (all (1,4,F,H,W) = n elements; pred_sum holds [uncond | cond] = 2n):
+ *   eps = pred_sum / counter (per frame);  v = eps_u + s (eps_c - eps_u);
+ *   x0 = sa_t x - sb_t v;  e = sa_t v + sb_t x;  x_prev = sa_p x0 + sb_p e          (v-prediction, eta = 0)
+ * counter: fp32 [F]; frame index of element i = (i / hw) % F.
+ * Replaces: src/pipelines/pipeline_pose2vid_long.py:622-635 + diffusers DDIMScheduler.step. */
+int mmgt_cfg_ddim_step(const float* pred_sum, const float* counter, const float* latents, float* latents_out, long n,
+                       int F, int hw, float guidance, float sa_t, float sb_t, float sa_p, float sb_p, void* stream);
+
+/* pred_sum[:, :, idx[j]] += pred[:, :, j]; counter[idx[j]] += 1 for a window of Fw frames (closed-loop indices).
+ * pred is channels-last T ((2*Fw), hw, Cpad) as produced by the UNet; pred_sum fp32 (2, C, F, hw).
+ * Replaces: src/pipelines/pipeline_pose2vid_long.py:622-624. */
+int mmgt_accumulate_window(const void* pred, float* pred_sum, float* counter, const int* idx, int Fw, int F, int C,
+                           int Cpad, int hw, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,313 @@
+// Flash-style attention for the MMGT Stage-2 path (gfx950): spatial self-attention with the ReferenceNet feature bank as
+// a second key/value segment, MM-HAA audio cross-attention (32 keys) and temporal self-attention (<= 32 frames), all
+// with head_dim in {40, 80, 160}.
+//
+// Structure per wave (32 queries): the score tile is computed TRANSPOSED, S^T[key][q] = K . Q^T, so a lane owns one
+// query column: the online-softmax max / sum are in-register reductions plus one exchange between the two lane halves,
+// and the exponentiated accumulator registers are directly the B operand of the second product
+// O^T[d][q] += V^T[d][key] . P^T[key][q] (guide section 3, "an accumulator tile as the next MFMA's operand").
+// K and V tiles (64 keys) are staged through LDS and shared by the workgroup's waves.
+#include "common.h"
+#include "mmgt_hip.h"
+
+namespace {
+
+struct AttnParams {
+  const char *q, *k, *v, *k2, *v2;
+  char* o;
+  long q_bs0, q_bs1, q_ts, k_bs0, k_bs1, k_ts, v_bs0, v_bs1, v_ts, o_bs0, o_bs1, o_ts;
+  long k2_bs, k2_ts, v2_bs, v2_ts;
+  int bdiv, k2_bdiv, nk2, seg2_first_batch;
+  int nq, nk;
+  float scale_log2e;
+};
+
+constexpr int KT = 64;  // keys per LDS tile
+
+template <typename T, int HD, int NW, bool VT>
+__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
+  constexpr int ESZ = sizeof(T);
+  constexpr int VEC = 16 / ESZ;                 // elements per 16-byte vector
+  constexpr int HDK = (HD + 15) / 16 * 16;      // QK^T reduction length (zero padded)
+  constexpr int KSQ = HDK / 16;
+  constexpr int DT = (HD + 31) / 32;            // 32-row tiles of O^T
+  constexpr int HDV = DT * 32;
+  constexpr int RSK = HDK * ESZ + 16;           // K tile row stride (bytes): odd multiple of 16 -> conflict-free b128
+  constexpr int RSV = VT ? (KT * ESZ + (ESZ == 2 ? 8 : 16)) : (HDV * ESZ + 16);
+  constexpr int VROWS = VT ? HDV : KT;
+  constexpr int NT = NW * 64;
+  __shared__ __attribute__((aligned(16))) char smem[KT * RSK + VROWS * RSV];
+  char* lK = smem;
+  char* lV = smem + KT * RSK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int bo = b / p.bdiv, bi = b - bo * p.bdiv;
+  const int q0 = (blockIdx.x * NW + wid) * 32;
+
+  const T* qb = reinterpret_cast<const T*>(p.q) + bo * p.q_bs0 + bi * p.q_bs1 + (long)head * HD;
+  T* ob = reinterpret_cast<T*>(p.o) + bo * p.o_bs0 + bi * p.o_bs1 + (long)head * HD;
+
+  // ---- Q^T fragments (B operand of S^T = K . Q^T): lane (q = lr, half lh) holds d = 16 ks + 8 lh + j ----
+  Frag<T> qf[KSQ];
+  {
+    int qi = q0 + lr;
+    if (qi >= p.nq) qi = p.nq - 1;
+    if (qi < 0) qi = 0;
+    const T* qrow = qb + (long)qi * p.q_ts;
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      const int d = 16 * ks + 8 * lh;
+      if (d < HD) frag_load(qf[ks], qrow + d);
+      else qf[ks].zero();
+    }
+  }
+
+  f32x16 o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) o[i] = (f32x16)(0.f);
+  float m_run = -1e30f, l_run = 0.f;
+  const float c = p.scale_log2e;
+
+  const int nseg = (p.k2 != nullptr && p.nk2 > 0 && b >= p.seg2_first_batch) ? 2 : 1;
+  for (int seg = 0; seg < nseg; ++seg) {
+    const T *kb, *vb;
+    long kts, vts;
+    int nks;
+    if (seg == 0) {
+      kb = reinterpret_cast<const T*>(p.k) + bo * p.k_bs0 + bi * p.k_bs1 + (long)head * HD;
+      vb = reinterpret_cast<const T*>(p.v) + bo * p.v_bs0 + bi * p.v_bs1;
+      kts = p.k_ts; vts = p.v_ts; nks = p.nk;
+    } else {
+      const int b2 = b / p.k2_bdiv;
+      kb = reinterpret_cast<const T*>(p.k2) + b2 * p.k2_bs + (long)head * HD;
+      vb = reinterpret_cast<const T*>(p.v2) + b2 * p.v2_bs;
+      kts = p.k2_ts; vts = p.v2_ts; nks = p.nk2;
+    }
+    // V addressing: row-major -> vb + key * vts + head*HD + d ; transposed -> vb + (head*HD + d) * vts + key
+    for (int kt = 0; kt < nks; kt += KT) {
+      __syncthreads();
+      // ---- stage K tile: KT rows x HDK columns ----
+      {
+        constexpr int NVK = HDK / VEC;
+        for (int idx = tid; idx < KT * NVK; idx += NT) {
+          const int row = idx / NVK, vc = idx - row * NVK;
+          const int key = kt + row, d = vc * VEC;
+          u32x4 val = (u32x4)(0u);
+          if (key < nks && d < HD) val = *reinterpret_cast<const u32x4*>(kb + (long)key * kts + d);
+          *reinterpret_cast<u32x4*>(lK + row * RSK + vc * 16) = val;
+        }
+      }
+      // ---- stage V tile ----
+      if (VT) {
+        constexpr int NVV = KT / VEC;
+        for (int idx = tid; idx < HDV * NVV; idx += NT) {
+          const int row = idx / NVV, vc = idx - row * NVV;
+          const int key0 = kt + vc * VEC;
+          union { u32x4 v; T e[VEC]; } val;
+          val.v = (u32x4)(0u);
+          if (row < HD) {
+            const T* src = vb + ((long)head * HD + row) * vts + key0;
+            if (key0 + VEC <= nks) {
+              val.v = *reinterpret_cast<const u32x4*>(src);
+            } else {
+#pragma unroll
+              for (int e = 0; e < VEC; ++e)
+                if (key0 + e < nks) val.e[e] = src[e];
+            }
+          }
+          if (ESZ == 2) {  // 136-byte rows: two 8-byte stores keep natural alignment
+            u32x2* dst = reinterpret_cast<u32x2*>(lV + row * RSV + vc * 16);
+            dst[0] = (u32x2){val.v[0], val.v[1]};
+            dst[1] = (u32x2){val.v[2], val.v[3]};
+          } else {
+            *reinterpret_cast<u32x4*>(lV + row * RSV + vc * 16) = val.v;
+          }
+        }
+      } else {
+        constexpr int NVV = HDV / VEC;
+        for (int idx = tid; idx < KT * NVV; idx += NT) {
+          const int row = idx / NVV, vc = idx - row * NVV;
+          const int key = kt + row, d = vc * VEC;
+          u32x4 val = (u32x4)(0u);
+          if (key < nks && d < HD) val = *reinterpret_cast<const u32x4*>(vb + (long)key * vts + (long)head * HD + d);
+          *reinterpret_cast<u32x4*>(lV + row * RSV + vc * 16) = val;
+        }
+      }
+      __syncthreads();
+
+      // ---- S^T = K . Q^T for the two 32-key sub-tiles ----
+      f32x16 s[2];
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        s[sub] = (f32x16)(0.f);
+        const char* kp = lK + (sub * 32 + lr) * RSK + lh * 8 * ESZ;
+#pragma unroll
+        for (int ks = 0; ks < KSQ; ++ks) {
+          Frag<T> kf;
+          frag_load(kf, reinterpret_cast<const T*>(kp + ks * 16 * ESZ));
+          mma32(s[sub], kf, qf[ks]);
+        }
+      }
+      // ---- online softmax over this tile's 64 keys (lane = query column) ----
+      float mt = -1e30f;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt + sub * 32 + acc_row(r, lane);
+          const float v = key < nks ? s[sub][r] : -1e30f;
+          s[sub][r] = v;
+          mt = fmaxf(mt, v);
+        }
+      mt = fmaxf(mt, __shfl_xor(mt, 32));
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = exp2f((m_run - m_new) * c);
+      const float mc = m_new * c;
+      float ls = 0.f;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = exp2f(s[sub][r] * c - mc);
+          s[sub][r] = pv;
+          ls += pv;
+        }
+      l_run = l_run * alpha + ls;
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) o[i] *= alpha;
+
+      // ---- O^T += V^T . P^T ----
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          Frag<T> pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf.set(j, s[sub][8 * s2 + j]);
+          // element j of this lane <-> key  sub*32 + 16*s2 + 8*(j>>2) + 4*lh + (j&3)
+          const int kbase = sub * 32 + 16 * s2 + 4 * lh;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            Frag<T> vf;
+            const int d = dt * 32 + lr;
+            if (VT) {
+              const T* vp = reinterpret_cast<const T*>(lV + d * RSV) + kbase;
+              if (ESZ == 2) {
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(vp);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + 8);
+                union { u32x4 u; Frag<T> f; } cv;
+                cv.u = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+                vf = cv.f;
+              } else {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(vp);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(vp + 8);
+                union { float f[8]; Frag<T> fr; } cv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { cv.f[j] = lo[j]; cv.f[4 + j] = hi[j]; }
+                vf = cv.fr;
+              }
+            } else {
+              union { T e[8]; Frag<T> f; } cv;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const int key = kbase + 8 * (j >> 2) + (j & 3);
+                cv.e[j] = *(reinterpret_cast<const T*>(lV + key * RSV) + d);
+              }
+              vf = cv.f;
+            }
+            mma32(o[dt], vf, pf);
+          }
+        }
+    }
+  }
+
+  // ---- normalise and store: lane (q, half) owns d = 32 dt + 8 g + 4 half + (0..3) ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_tot;
+  const int qi = q0 + lr;
+  if (qi < p.nq) {
+    T* orow = ob + (long)qi * p.o_ts;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * lh;
+        if (d < HD) {
+          if (ESZ == 2) {
+            union { bf16_t e[4]; u32x2 u; } pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk.e[e] = f32_to_bf16(o[dt][4 * g + e] * inv);
+            *reinterpret_cast<u32x2*>(orow + d) = pk.u;
+          } else {
+            f32x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = o[dt][4 * g + e] * inv;
+            *reinterpret_cast<f32x4*>(orow + d) = pk;
+          }
+        }
+      }
+  }
+}
+
+template <typename T, int HD>
+int launch_hd(const AttnParams& p, int batch, int heads, int vt, hipStream_t s) {
+  // Short sequences (temporal attention, <= 32 frames) use one wave per workgroup; spatial sequences four.
+  if (p.nq <= 32) {
+    dim3 grid(1, heads, batch);
+    if (vt) hipLaunchKernelGGL((attn_kernel<T, HD, 1, true>), grid, dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((attn_kernel<T, HD, 1, false>), grid, dim3(64), 0, s, p);
+  } else {
+    dim3 grid((p.nq + 127) / 128, heads, batch);
+    if (vt) hipLaunchKernelGGL((attn_kernel<T, HD, 4, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_kernel<T, HD, 4, false>), grid, dim3(256), 0, s, p);
+  }
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+int launch_t(const AttnParams& p, int batch, int heads, int hd, int vt, hipStream_t s) {
+  switch (hd) {
+    case 40: return launch_hd<T, 40>(p, batch, heads, vt, s);
+    case 80: return launch_hd<T, 80>(p, batch, heads, vt, s);
+    case 160: return launch_hd<T, 160>(p, batch, heads, vt, s);
+    default: mmgt_set_error("attention: head_dim %d unsupported (40, 80, 160)", hd); return 1;
+  }
+}
+
+}  // namespace
+
+extern "C" int mmgt_attention(const void* q, long q_bs0, long q_bs1, long q_ts, const void* k, long k_bs0, long k_bs1,
+                              long k_ts, const void* v, long v_bs0, long v_bs1, long v_ts, void* o, long o_bs0,
+                              long o_bs1, long o_ts, int bdiv, const void* k2, const void* v2, long k2_bs, long k2_ts,
+                              long v2_bs, long v2_ts, int k2_bdiv, int nk2, int seg2_first_batch, int batch, int heads,
+                              int hd, int nq, int nk, float scale, int v_transposed, int dtype, void* stream) {
+  MMGT_CHECK(q && k && v && o, "attention: null pointer");
+  MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "attention: bad dtype %d", dtype);
+  MMGT_CHECK(batch > 0 && heads > 0 && nq > 0 && nk > 0 && bdiv > 0, "attention: empty problem");
+  MMGT_CHECK(batch <= 65535 && heads <= 65535, "attention: batch %d / heads %d exceed the grid limits", batch, heads);
+  MMGT_CHECK((k2 == nullptr) == (v2 == nullptr), "attention: k2/v2 must come together");
+  MMGT_CHECK(!k2 || (k2_bdiv > 0 && nk2 >= 0), "attention: bad second segment");
+  const int esz = dtype == MMGT_BF16 ? 2 : 4;
+  const long vec = 16 / esz;
+  MMGT_CHECK(q_ts % vec == 0 && k_ts % vec == 0 && o_ts % vec == 0 && q_bs0 % vec == 0 && q_bs1 % vec == 0 &&
+                 k_bs0 % vec == 0 && k_bs1 % vec == 0 && v_bs0 % vec == 0 && v_bs1 % vec == 0 && v_ts % vec == 0,
+             "attention: strides must keep 16-byte alignment");
+  MMGT_CHECK(!k2 || (k2_ts % vec == 0 && k2_bs % vec == 0 && v2_ts % vec == 0 && v2_bs % vec == 0),
+             "attention: segment-2 strides must keep 16-byte alignment");
+  AttnParams p{};
+  p.q = (const char*)q; p.k = (const char*)k; p.v = (const char*)v; p.k2 = (const char*)k2; p.v2 = (const char*)v2;
+  p.o = (char*)o;
+  p.q_bs0 = q_bs0; p.q_bs1 = q_bs1; p.q_ts = q_ts; p.k_bs0 = k_bs0; p.k_bs1 = k_bs1; p.k_ts = k_ts;
+  p.v_bs0 = v_bs0; p.v_bs1 = v_bs1; p.v_ts = v_ts; p.o_bs0 = o_bs0; p.o_bs1 = o_bs1; p.o_ts = o_ts;
+  p.k2_bs = k2_bs; p.k2_ts = k2_ts; p.v2_bs = v2_bs; p.v2_ts = v2_ts;
+  p.bdiv = bdiv; p.k2_bdiv = k2 ? k2_bdiv : 1; p.nk2 = k2 ? nk2 : 0; p.seg2_first_batch = seg2_first_batch;
+  p.nq = nq; p.nk = nk;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  hipStream_t s = (hipStream_t)stream;
+  return dtype == MMGT_BF16 ? launch_t<bf16_t>(p, batch, heads, hd, v_transposed, s)
+                            : launch_t<float>(p, batch, heads, hd, v_transposed, s);
+}

@@ -1,0 +1,116 @@
+// Shared device helpers for the MMGT Stage-2 HIP kernels (gfx950 / CDNA4 only).
+//
+// Every matrix kernel is written once over a storage type T in {float, bf16}: the bf16 instantiation is the
+// product path (v_mfma_f32_32x32x16_bf16, fp32 accumulate); the float instantiation is the fp32-I/O parity mode of the
+// SAME kernel (v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fma chain) that the rtol 1e-3 / atol 1e-4 gate runs on.
+// Both use one fragment convention: lane (r = lane & 31, h = lane >> 5) holds 8 consecutive k values k = 8h .. 8h+7 of
+// row/column r for a K-step of 16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+typedef unsigned short bf16_t;  // raw storage
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((unsigned int)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+  __hip_bfloat16 b = __float2bfloat16(f);
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float cvt(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+  static __device__ __forceinline__ float cvt(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+};
+
+// ---- MFMA fragment: 8 consecutive-k elements of T per lane ---------------------------------------------------------
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+  s16x8 v;
+  __device__ __forceinline__ void zero() { v = (s16x8)(0); }
+  __device__ __forceinline__ void set(int j, float f) { v[j] = (short)f32_to_bf16(f); }
+};
+template <> struct Frag<float> {
+  float v[8];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  }
+  __device__ __forceinline__ void set(int j, float f) { v[j] = f; }
+};
+
+// acc(32x32) += A(32x16) * B(16x32); C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+__device__ __forceinline__ void mma32(f32x16& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32(f32x16& acc, const Frag<float>& a, const Frag<float>& b) {
+  // K=2 per instruction: lanes 0-31 supply k = j, lanes 32-63 k = 8 + j; eight of them cover the 16-wide K-step.
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+// Load a fragment (8 consecutive elements) from LDS / global at a 16-byte (bf16) or 32-byte (f32) aligned address.
+__device__ __forceinline__ void frag_load(Frag<bf16_t>& f, const bf16_t* p) { f.v = *reinterpret_cast<const s16x8*>(p); }
+__device__ __forceinline__ void frag_load(Frag<float>& f, const float* p) {
+  f32x4 lo = *reinterpret_cast<const f32x4*>(p);
+  f32x4 hi = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.v[j] = lo[j]; f.v[4 + j] = hi[j]; }
+}
+
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ---- host side error plumbing (no exceptions cross the C ABI) ------------------------------------------------------
+#ifdef __cplusplus
+extern "C" {
+#endif
+void mmgt_set_error(const char* fmt, ...);
+#ifdef __cplusplus
+}
+#endif
+
+#define MMGT_CHECK(cond, ...)      \
+  do {                             \
+    if (!(cond)) {                 \
+      mmgt_set_error(__VA_ARGS__); \
+      return 1;                    \
+    }                              \
+  } while (0)
+
+#define MMGT_LAUNCH_CHECK()                                              \
+  do {                                                                   \
+    hipError_t e_ = hipGetLastError();                                   \
+    if (e_ != hipSuccess) {                                              \
+      mmgt_set_error("%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return 2;                                                          \
+    }                                                                    \
+  } while (0)

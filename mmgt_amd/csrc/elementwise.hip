@@ -1,0 +1,225 @@
+// Layout conversion, timestep features, CFG + DDIM update, window accumulation, row softmax (gfx950).  All HBM-bound
+// grid-stride kernels.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+#include "mmgt_hip.h"
+
+// ---------------------------------------------------------------------------------------------- error plumbing
+static thread_local char g_err[512] = "";
+extern "C" void mmgt_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* mmgt_last_error(void) { return g_err; }
+extern "C" int mmgt_abi_version(void) { return 1; }
+
+namespace {
+
+inline int grid_for(long n, int block = 256) {
+  long g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 2048 * 4 ? 2048 * 4 : g));
+}
+
+template <typename T>
+__global__ void ncfhw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int C, int F, int HW,
+                                     int Cpad) {
+  const long total = (long)B * F * HW * Cpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % Cpad;
+    long t = i / Cpad;
+    const int p = t % HW;
+    t /= HW;
+    const int f = t % F;
+    const int b = t / F;
+    float v = 0.f;
+    if (c < C) v = in[(((long)b * C + c) * F + f) * HW + p];
+    Elem<T>::st(out + i, v);
+  }
+}
+
+template <typename T>
+__global__ void nhwc_to_ncfhw_kernel(const T* __restrict__ in, float* __restrict__ out, int B, int C, int F, int HW,
+                                     int Cpad) {
+  const long total = (long)B * C * F * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int p = i % HW;
+    long t = i / HW;
+    const int f = t % F;
+    t /= F;
+    const int c = t % C;
+    const int b = t / C;
+    out[i] = Elem<T>::ld(in + (((long)b * F + f) * HW + p) * Cpad + c);
+  }
+}
+
+template <typename T>
+__global__ void timestep_kernel(const float* __restrict__ ts, T* __restrict__ out, int B, int dim) {
+  const int half = dim / 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * dim; i += gridDim.x * blockDim.x) {
+    const int b = i / dim, j = i % dim;
+    const int k = j < half ? j : j - half;
+    const float freq = expf(-9.210340371976184f * (float)k / (float)half);  // ln(10000)
+    const float a = ts[b] * freq;
+    Elem<T>::st(out + i, j < half ? cosf(a) : sinf(a));
+  }
+}
+
+template <typename T>
+__global__ void silu_kernel(const T* __restrict__ x, T* __restrict__ out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    Elem<T>::st(out + i, silu_f(Elem<T>::ld(x + i)));
+}
+
+__global__ void cfg_ddim_kernel(const float* __restrict__ ps, const float* __restrict__ counter,
+                                const float* __restrict__ x, float* __restrict__ xo, long n, int F, int hw, float g,
+                                float sa_t, float sb_t, float sa_p, float sb_p) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int f = (int)((i / hw) % F);
+    const float cnt = counter[f];
+    const float eu = ps[i] / cnt, ec = ps[n + i] / cnt;
+    const float v = eu + g * (ec - eu);
+    const float xi = x[i];
+    const float x0 = sa_t * xi - sb_t * v;
+    const float e = sa_t * v + sb_t * xi;
+    xo[i] = sa_p * x0 + sb_p * e;
+  }
+}
+
+template <typename T>
+__global__ void accumulate_window_kernel(const T* __restrict__ pred, float* __restrict__ ps, float* __restrict__ counter,
+                                         const int* __restrict__ idx, int Fw, int F, int C, int Cpad, int hw) {
+  const long total = 2l * C * Fw * hw;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int p = i % hw;
+    long t = i / hw;
+    const int j = t % Fw;
+    t /= Fw;
+    const int c = t % C;
+    const int b = t / C;
+    const float v = Elem<T>::ld(pred + (((long)b * Fw + j) * hw + p) * Cpad + c);
+    ps[(((long)b * C + c) * F + idx[j]) * hw + p] += v;  // window indices are distinct: no two threads share a target
+  }
+  if (blockIdx.x == 0 && threadIdx.x < Fw) counter[idx[threadIdx.x]] += 1.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ x, long ldx, T* __restrict__ out,
+                                                           long ldo, int rows, int cols, float scale) {
+  // one wave per row; three passes over a row that stays in L2 (VAE mid-block attention only)
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wid;
+  if (row >= rows) return;
+  const T* xr = x + row * ldx;
+  float m = -1e30f;
+  for (int c = lane; c < cols; c += 64) m = fmaxf(m, Elem<T>::ld(xr + c) * scale);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += __expf(Elem<T>::ld(xr + c) * scale - m);
+  s = wave_sum(s);
+  const float inv = 1.f / s;
+  for (int c = lane; c < cols; c += 64) Elem<T>::st(out + row * ldo + c, __expf(Elem<T>::ld(xr + c) * scale - m) * inv);
+}
+
+}  // namespace
+
+
+extern "C" int mmgt_ncfhw_to_nhwc(const float* in, void* out, int B, int C, int F, int H, int W, int Cpad, int dtype,
+                                  void* stream) {
+  MMGT_CHECK(in && out && Cpad >= C && C > 0, "ncfhw_to_nhwc: bad arguments");
+  MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "ncfhw_to_nhwc: bad dtype");
+  const long total = (long)B * F * H * W * Cpad;
+  if (dtype == MMGT_BF16)
+    hipLaunchKernelGGL(ncfhw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                       (bf16_t*)out, B, C, F, H * W, Cpad);
+  else
+    hipLaunchKernelGGL(ncfhw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                       (float*)out, B, C, F, H * W, Cpad);
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmgt_nhwc_to_ncfhw(const void* in, float* out, int B, int C, int F, int H, int W, int Cpad, int dtype,
+                                  void* stream) {
+  MMGT_CHECK(in && out && Cpad >= C && C > 0, "nhwc_to_ncfhw: bad arguments");
+  MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "nhwc_to_ncfhw: bad dtype");
+  const long total = (long)B * C * F * H * W;
+  if (dtype == MMGT_BF16)
+    hipLaunchKernelGGL(nhwc_to_ncfhw_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, out, B, C, F, H * W, Cpad);
+  else
+    hipLaunchKernelGGL(nhwc_to_ncfhw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)in, out, B, C, F, H * W, Cpad);
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmgt_timestep_features(const float* timesteps, void* out, int B, int dim, int dtype, void* stream) {
+  MMGT_CHECK(timesteps && out && B > 0 && dim > 0 && dim % 2 == 0, "timestep_features: bad arguments");
+  MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "timestep_features: bad dtype");
+  if (dtype == MMGT_BF16)
+    hipLaunchKernelGGL(timestep_kernel<bf16_t>, dim3(grid_for((long)B * dim)), dim3(256), 0, (hipStream_t)stream,
+                       timesteps, (bf16_t*)out, B, dim);
+  else
+    hipLaunchKernelGGL(timestep_kernel<float>, dim3(grid_for((long)B * dim)), dim3(256), 0, (hipStream_t)stream,
+                       timesteps, (float*)out, B, dim);
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmgt_silu(const void* x, void* out, long n, int dtype, void* stream) {
+  MMGT_CHECK(x && out && n > 0, "silu: bad arguments");
+  MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "silu: bad dtype");
+  if (dtype == MMGT_BF16)
+    hipLaunchKernelGGL(silu_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (bf16_t*)out, n);
+  else
+    hipLaunchKernelGGL(silu_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (float*)out, n);
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmgt_cfg_ddim_step(const float* pred_sum, const float* counter, const float* latents, float* latents_out,
+                                  long n, int F, int hw, float guidance, float sa_t, float sb_t, float sa_p, float sb_p,
+                                  void* stream) {
+  MMGT_CHECK(pred_sum && counter && latents && latents_out && n > 0 && F > 0 && hw > 0, "cfg_ddim_step: bad arguments");
+  hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, pred_sum, counter, latents,
+                     latents_out, n, F, hw, guidance, sa_t, sb_t, sa_p, sb_p);
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmgt_accumulate_window(const void* pred, float* pred_sum, float* counter, const int* idx, int Fw, int F,
+                                      int C, int Cpad, int hw, int dtype, void* stream) {
+  MMGT_CHECK(pred && pred_sum && counter && idx, "accumulate_window: null pointer");
+  MMGT_CHECK(Fw > 0 && Fw <= 256 && F >= Fw && C > 0 && Cpad >= C && hw > 0, "accumulate_window: bad sizes");
+  MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "accumulate_window: bad dtype");
+  const long total = 2l * C * Fw * hw;
+  if (dtype == MMGT_BF16)
+    hipLaunchKernelGGL(accumulate_window_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)pred, pred_sum, counter, idx, Fw, F, C, Cpad, hw);
+  else
+    hipLaunchKernelGGL(accumulate_window_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)pred, pred_sum, counter, idx, Fw, F, C, Cpad, hw);
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmgt_softmax_rows(const void* x, long ldx, void* out, long ldo, int rows, int cols, float scale, int dtype,
+                                 void* stream) {
+  MMGT_CHECK(x && out && rows > 0 && cols > 0, "softmax_rows: bad arguments");
+  MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "softmax_rows: bad dtype");
+  dim3 grid((rows + 3) / 4);
+  if (dtype == MMGT_BF16)
+    hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (bf16_t*)out, ldo, rows, cols, scale);
+  else
+    hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx,
+                       (float*)out, ldo, rows, cols, scale);
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,251 @@
+// GroupNorm (channels-last, per image) and LayerNorm for the MMGT Stage-2 path (gfx950).  Both are HBM-bound: 16-byte
+// vector loads, one wave per row so that a lane always owns the same channels (register accumulators, no atomics:
+// results are bitwise reproducible run to run).
+#include "common.h"
+#include "mmgt_hip.h"
+
+namespace {
+
+constexpr int GN_MAXC = 2560;
+
+__host__ __device__ inline int gn_chunks(int HW) {
+  int c = (HW + 127) / 128;
+  return c < 1 ? 1 : (c > 256 ? 256 : c);
+}
+
+template <typename T>
+struct VecIO {
+  static constexpr int VEC = 16 / sizeof(T);
+  static __device__ __forceinline__ void load(const T* p, float* f) {
+    union { u32x4 u; T e[VEC]; } v;
+    v.u = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) f[i] = Elem<T>::ld(&v.e[i]);
+  }
+  static __device__ __forceinline__ void store(T* p, const float* f) {
+    union { u32x4 u; T e[VEC]; } v;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) Elem<T>::st(&v.e[i], f[i]);
+    *reinterpret_cast<u32x4*>(p) = v.u;
+  }
+};
+
+// ---- GroupNorm pass 1: per (image, row chunk) partial sum / sum of squares per group ----
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1,
+                                                       float* __restrict__ partial, int HW, int G, int chunks) {
+  constexpr int VEC = VecIO<T>::VEC;
+  constexpr int MAXS = GN_MAXC / (VEC * 64);
+  __shared__ float ssum[GN_MAXC], ssq[GN_MAXC];
+  const int C = C0 + C1, nvec = C / VEC;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int rows_per = (HW + chunks - 1) / chunks;
+  const int r0 = chunk * rows_per, r1 = min(HW, r0 + rows_per);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+
+  float s[MAXS][VEC], q[MAXS][VEC];
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) s[i][e] = q[i][e] = 0.f;
+
+  for (int r = r0 + wid; r < r1; r += 4) {
+    const long pix = (long)n * HW + r;
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+      const int vc = lane + 64 * i;
+      if (vc < nvec) {
+        const int c = vc * VEC;
+        const T* src = c < C0 ? x0 + pix * C0 + c : x1 + pix * C1 + (c - C0);
+        float f[VEC];
+        VecIO<T>::load(src, f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s[i][e] += f[e]; q[i][e] += f[e] * f[e]; }
+      }
+    }
+  }
+  // combine the four waves in a fixed order
+  for (int w = 0; w < 4; ++w) {
+    if (wid == w) {
+#pragma unroll
+      for (int i = 0; i < MAXS; ++i) {
+        const int vc = lane + 64 * i;
+        if (vc < nvec)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const int c = vc * VEC + e;
+            if (w == 0) { ssum[c] = s[i][e]; ssq[c] = q[i][e]; }
+            else { ssum[c] += s[i][e]; ssq[c] += q[i][e]; }
+          }
+      }
+    }
+    __syncthreads();
+  }
+  const int cg = C / G;
+  if (threadIdx.x < G) {
+    float a = 0.f, b = 0.f;
+    for (int c = threadIdx.x * cg; c < (threadIdx.x + 1) * cg; ++c) { a += ssum[c]; b += ssq[c]; }
+    float* dst = partial + (((long)n * chunks + chunk) * G + threadIdx.x) * 2;
+    dst[0] = a;
+    dst[1] = b;
+  }
+}
+
+// ---- GroupNorm pass 2: normalise (+ SiLU) ----
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ partial, T* __restrict__ out, int HW,
+                                                       int G, int chunks, float eps, int silu) {
+  constexpr int VEC = VecIO<T>::VEC;
+  constexpr int MAXS = GN_MAXC / (VEC * 64);
+  __shared__ float sscale[GN_MAXC], sshift[GN_MAXC];
+  __shared__ float smean[64], srstd[64];
+  const int C = C0 + C1, nvec = C / VEC, cg = C / G;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int rows_per = (HW + chunks - 1) / chunks;
+  const int r0 = chunk * rows_per, r1 = min(HW, r0 + rows_per);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (threadIdx.x < G) {
+    float a = 0.f, b = 0.f;
+    for (int ch = 0; ch < chunks; ++ch) {
+      const float* src = partial + (((long)n * chunks + ch) * G + threadIdx.x) * 2;
+      a += src[0];
+      b += src[1];
+    }
+    const float cnt = (float)HW * (float)cg;
+    const float mean = a / cnt;
+    float var = b / cnt - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    smean[threadIdx.x] = mean;
+    srstd[threadIdx.x] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cg;
+    const float sc = srstd[g] * gamma[c];
+    sscale[c] = sc;
+    sshift[c] = beta[c] - smean[g] * sc;
+  }
+  __syncthreads();
+  for (int r = r0 + wid; r < r1; r += 4) {
+    const long pix = (long)n * HW + r;
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+      const int vc = lane + 64 * i;
+      if (vc < nvec) {
+        const int c = vc * VEC;
+        const T* src = c < C0 ? x0 + pix * C0 + c : x1 + pix * C1 + (c - C0);
+        float f[VEC];
+        VecIO<T>::load(src, f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float v = f[e] * sscale[c + e] + sshift[c + e];
+          f[e] = silu ? silu_f(v) : v;
+        }
+        VecIO<T>::store(out + pix * C + c, f);
+      }
+    }
+  }
+}
+
+// ---- LayerNorm: one wave per row, row held in registers, exact two-pass statistics ----
+template <typename T>
+__global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float eps, const float* __restrict__ pe,
+                                                 int pe_div, int pe_mod, T* __restrict__ out, long ldo, int rows, int C) {
+  constexpr int VEC = VecIO<T>::VEC;
+  constexpr int MAXS = 1280 / (VEC * 64) + 1;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wid;
+  if (row >= rows) return;
+  const int nvec = C / VEC;
+  float f[MAXS][VEC];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    const int vc = lane + 64 * i;
+    if (vc < nvec) {
+      VecIO<T>::load(x + row * ldx + vc * VEC, f[i]);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) sum += f[i][e];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    const int vc = lane + 64 * i;
+    if (vc < nvec)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { const float d = f[i][e] - mean; sq += d * d; }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  const float* perow = pe ? pe + (long)((row / pe_div) % pe_mod) * C : nullptr;
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    const int vc = lane + 64 * i;
+    if (vc < nvec) {
+      const int c = vc * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float v = (f[i][e] - mean) * rstd * gamma[c + e] + beta[c + e];
+        if (perow) v += perow[c + e];
+        f[i][e] = v;
+      }
+      VecIO<T>::store(out + row * ldo + c, f[i]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int mmgt_groupnorm_chunks(int HW) { return gn_chunks(HW); }
+
+extern "C" int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta,
+                                   void* out, float* workspace, int NB, int HW, int G, float eps, int silu, int dtype,
+                                   void* stream) {
+  MMGT_CHECK(x0 && gamma && beta && out && workspace, "groupnorm: null pointer");
+  MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "groupnorm: bad dtype %d", dtype);
+  MMGT_CHECK((x1 != nullptr) == (C1 > 0), "groupnorm: x1/C1 mismatch");
+  const int C = C0 + C1, vec = dtype == MMGT_BF16 ? 8 : 4;
+  MMGT_CHECK(C <= GN_MAXC && C % G == 0 && G <= 64 && C0 % vec == 0 && C1 % vec == 0,
+             "groupnorm: unsupported channels C0=%d C1=%d G=%d", C0, C1, G);
+  MMGT_CHECK(NB > 0 && HW > 0 && NB <= 65535, "groupnorm: bad NB=%d HW=%d", NB, HW);
+  const int chunks = gn_chunks(HW);
+  dim3 grid(chunks, NB);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MMGT_BF16) {
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x0, C0, (const bf16_t*)x1, C1,
+                       workspace, HW, G, chunks);
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x0, C0, (const bf16_t*)x1, C1, gamma,
+                       beta, workspace, (bf16_t*)out, HW, G, chunks, eps, silu);
+  } else {
+    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x0, C0, (const float*)x1, C1,
+                       workspace, HW, G, chunks);
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x0, C0, (const float*)x1, C1, gamma,
+                       beta, workspace, (float*)out, HW, G, chunks, eps, silu);
+  }
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmgt_layernorm(const void* x, long ldx, const float* gamma, const float* beta, float eps, const float* pe,
+                              int pe_div, int pe_mod, void* out, long ldo, int rows, int C, int dtype, void* stream) {
+  MMGT_CHECK(x && gamma && beta && out, "layernorm: null pointer");
+  MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "layernorm: bad dtype %d", dtype);
+  const int vec = dtype == MMGT_BF16 ? 8 : 4;
+  MMGT_CHECK(C > 0 && C <= 1280 && C % vec == 0 && ldx % vec == 0 && ldo % vec == 0, "layernorm: unsupported C=%d", C);
+  MMGT_CHECK(rows > 0, "layernorm: no rows");
+  MMGT_CHECK(!pe || (pe_div > 0 && pe_mod > 0), "layernorm: bad pe_div/pe_mod");
+  dim3 grid((rows + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MMGT_BF16)
+    hipLaunchKernelGGL(ln_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, gamma, beta, eps, pe, pe_div,
+                       pe_mod, (bf16_t*)out, ldo, rows, C);
+  else
+    hipLaunchKernelGGL(ln_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, gamma, beta, eps, pe, pe_div, pe_mod,
+                       (float*)out, ldo, rows, C);
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,277 @@
+"""ctypes binding of libmmgt_hip.so (include/mmgt_hip.h): the ONLY compute entry points of the product.
+
+There is no fallback: if the library is missing or a call fails, a RuntimeError is raised.  torch is used for device
+memory (the caching allocator) and the current HIP stream only.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_long, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmgt_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GEGLU, ACT_SILU = 0, 1, 2
+
+_lib = None
+
+_SIGS = {
+    "mmgt_abi_version": (c_int, []),
+    "mmgt_last_error": (ctypes.c_char_p, []),
+    "mmgt_gemm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_long,
+                          c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_int,
+                          c_void_p]),
+    "mmgt_conv3x3_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                  c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mmgt_groupnorm_chunks": (c_int, [c_int]),
+    "mmgt_groupnorm_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "mmgt_layernorm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_void_p, c_long,
+                               c_int, c_int, c_int, c_void_p]),
+    "mmgt_attention": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_long,
+                               c_long, c_long, c_void_p, c_long, c_long, c_long, c_int, c_void_p, c_void_p, c_long,
+                               c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                               c_int, c_int, c_void_p]),
+    "mmgt_softmax_rows": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_float, c_int, c_void_p]),
+    "mmgt_ncfhw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_nhwc_to_ncfhw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_timestep_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mmgt_silu": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "mmgt_cfg_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_float,
+                                   c_float, c_float, c_float, c_void_p]),
+    "mmgt_accumulate_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_void_p]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """Load libmmgt_hip.so once; raise loudly if it has not been built (python __graft_entry__.py / make -C mmgt_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C mmgt_amd/csrc` (hipcc, gfx950). "
+                               "mmgt_amd has no non-HIP compute path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {lib().mmgt_last_error().decode()}")
+
+
+def dtype_code(dt):
+    if dt == torch.bfloat16:
+        return BF16
+    if dt == torch.float32:
+        return F32
+    raise RuntimeError(f"mmgt_amd supports float32 and bfloat16 storage, got {dt}")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mmgt_amd.hip: tensors must live on the GPU (no CPU fallback exists)")
+
+
+def _f32(t, name):
+    if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+        raise RuntimeError(f"{name} must be contiguous float32")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------------------ GEMM
+
+def gemm(a, w, bias=None, *, out=None, residual=None, bias2=None, bias2_rows=0, row_scale=None, alpha=1.0,
+         act=ACT_NONE, out_cols=None):
+    """out[M, Nout] = epilogue(a[M, K] @ w[N, K]^T).  a may be a strided 2-D view (row stride, unit column stride)."""
+    _dev(a, w, bias, out, residual, bias2, row_scale)
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.is_contiguous() and a.dtype == w.dtype
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K, (a.shape, w.shape)
+    n_out = N // 2 if act == ACT_GEGLU else N
+    if out is None:
+        out = torch.empty((M, n_out), device=a.device, dtype=a.dtype)
+    assert out.shape == (M, n_out) and out.stride(1) == 1 and out.dtype == a.dtype
+    if residual is not None:
+        assert residual.shape == (M, n_out) and residual.stride(1) == 1 and residual.dtype == a.dtype
+    _check(lib().mmgt_gemm(_ptr(a), a.stride(0), _ptr(w), _ptr(_f32(bias, "bias")), _ptr(_f32(bias2, "bias2")),
+                           bias2_rows, _ptr(_f32(row_scale, "row_scale")), alpha, _ptr(residual),
+                           residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), M, N, K, act, 1,
+                           0, 0, 0, 0, dtype_code(a.dtype), _stream()), "mmgt_gemm")
+    return out
+
+
+def gemm_batched_wx(w, x, bias_unused=None, *, out):
+    """out[b] (R, ldo>=Ntok) = w[R, K] @ x[b][Ntok, K]^T for every batch b: the V^T projection (keys contiguous)."""
+    _dev(w, x, out)
+    B, ntok, K = x.shape
+    R = w.shape[0]
+    assert x.is_contiguous() and w.is_contiguous() and out.dim() == 3 and out.shape[0] == B and out.shape[1] == R
+    assert out.stride(2) == 1
+    _check(lib().mmgt_gemm(_ptr(w), K, _ptr(x), None, None, 0, None, 1.0, None, 0, _ptr(out), out.stride(1), R, ntok, K,
+                           ACT_NONE, B, 0, x.stride(0), 0, out.stride(0), dtype_code(x.dtype), _stream()),
+           "mmgt_gemm(batched)")
+    return out
+
+
+def conv3x3(x, wp, bias=None, *, stride=1, upsample=False, bias2=None, bias2_rows=0, residual=None, act=ACT_NONE,
+            x1=None, out=None):
+    """x (NB, H, W, C0) channels-last [+ x1 (NB, H, W, C1)], wp [Cout][3][3][C0+C1] -> (NB, OH, OW, Cout)."""
+    _dev(x, wp, bias, bias2, residual, x1)
+    assert x.dim() == 4 and x.is_contiguous() and wp.is_contiguous() and wp.dtype == x.dtype
+    NB, IH, IW, C0 = x.shape
+    C1 = 0 if x1 is None else x1.shape[3]
+    cout = wp.shape[0]
+    assert wp.numel() == cout * 9 * (C0 + C1)
+    vh, vw = (IH * 2, IW * 2) if upsample else (IH, IW)
+    oh, ow = (vh - 1) // stride + 1, (vw - 1) // stride + 1
+    if out is None:
+        out = torch.empty((NB, oh, ow, cout), device=x.device, dtype=x.dtype)
+    assert out.shape == (NB, oh, ow, cout) and out.is_contiguous()
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous()
+    _check(lib().mmgt_conv3x3_nhwc(_ptr(x), C0, _ptr(x1), C1, NB, IH, IW, stride, int(upsample), _ptr(wp),
+                                   _ptr(_f32(bias, "bias")), _ptr(_f32(bias2, "bias2")), bias2_rows, _ptr(residual),
+                                   _ptr(out), cout, act, dtype_code(x.dtype), _stream()), "mmgt_conv3x3_nhwc")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------ norms
+
+def groupnorm(x, gamma, beta, groups, eps, silu=False, x1=None, out=None):
+    """x (NB, HW, C0) [+ x1 (NB, HW, C1)] -> (NB, HW, C0+C1), per-image GroupNorm (+ SiLU)."""
+    _dev(x, gamma, beta, x1)
+    assert x.dim() == 3 and x.is_contiguous()
+    NB, HW, C0 = x.shape
+    C1 = 0 if x1 is None else x1.shape[2]
+    if x1 is not None:
+        assert x1.is_contiguous() and x1.shape[:2] == x.shape[:2] and x1.dtype == x.dtype
+    if out is None:
+        out = torch.empty((NB, HW, C0 + C1), device=x.device, dtype=x.dtype)
+    chunks = lib().mmgt_groupnorm_chunks(HW)
+    ws = torch.empty((NB * chunks * groups * 2,), device=x.device, dtype=torch.float32)
+    _check(lib().mmgt_groupnorm_nhwc(_ptr(x), C0, _ptr(x1), C1, _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")),
+                                     _ptr(out), _ptr(ws), NB, HW, groups, eps, int(silu), dtype_code(x.dtype),
+                                     _stream()), "mmgt_groupnorm_nhwc")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, pe=None, pe_div=1, pe_mod=1, out=None):
+    """x (rows, C) -> LayerNorm over C (+ pe[(row // pe_div) % pe_mod] added after the affine)."""
+    _dev(x, gamma, beta, pe)
+    assert x.dim() == 2 and x.stride(1) == 1
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty((rows, C), device=x.device, dtype=x.dtype)
+    _check(lib().mmgt_layernorm(_ptr(x), x.stride(0), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), eps,
+                                _ptr(_f32(pe, "pe")), pe_div, pe_mod, _ptr(out), out.stride(0), rows, C,
+                                dtype_code(x.dtype), _stream()), "mmgt_layernorm")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------ attention
+
+def attention(q, k, v, out, *, batch, heads, hd, nq, nk, scale, q_str, k_str, v_str, o_str, bdiv=1, v_transposed=False,
+              k2=None, v2=None, k2_str=(0, 0), v2_str=(0, 0), k2_bdiv=1, nk2=0, seg2_first_batch=0):
+    """Raw strided attention (see include/mmgt_hip.h).  *_str = (batch stride 0, batch stride 1, token stride)."""
+    _dev(q, k, v, out, k2, v2)
+    _check(lib().mmgt_attention(_ptr(q), q_str[0], q_str[1], q_str[2], _ptr(k), k_str[0], k_str[1], k_str[2], _ptr(v),
+                                v_str[0], v_str[1], v_str[2], _ptr(out), o_str[0], o_str[1], o_str[2], bdiv, _ptr(k2),
+                                _ptr(v2), k2_str[0], k2_str[1], v2_str[0], v2_str[1], k2_bdiv, nk2, seg2_first_batch,
+                                batch, heads, hd, nq, nk, scale, int(v_transposed), dtype_code(q.dtype), _stream()),
+           "mmgt_attention")
+    return out
+
+
+def softmax_rows(x, scale=1.0, out=None):
+    _dev(x)
+    assert x.dim() == 2 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().mmgt_softmax_rows(_ptr(x), x.stride(0), _ptr(out), out.stride(0), x.shape[0], x.shape[1], scale,
+                                   dtype_code(x.dtype), _stream()), "mmgt_softmax_rows")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------ plumbing
+
+def ncfhw_to_nhwc(x, cpad, dtype):
+    """(B, C, F, H, W) fp32 -> (B*F, H, W, cpad) channels-last `dtype`, zero padded channels."""
+    _dev(x)
+    assert x.dim() == 5 and x.dtype == torch.float32 and x.is_contiguous()
+    B, C, F, H, W = x.shape
+    out = torch.empty((B * F, H, W, cpad), device=x.device, dtype=dtype)
+    _check(lib().mmgt_ncfhw_to_nhwc(_ptr(x), _ptr(out), B, C, F, H, W, cpad, dtype_code(dtype), _stream()),
+           "mmgt_ncfhw_to_nhwc")
+    return out
+
+
+def nhwc_to_ncfhw(x, B, C):
+    """(B*F, H, W, cpad) -> (B, C, F, H, W) fp32 (first C channels)."""
+    _dev(x)
+    assert x.dim() == 4 and x.is_contiguous()
+    BF, H, W, cpad = x.shape
+    F = BF // B
+    out = torch.empty((B, C, F, H, W), device=x.device, dtype=torch.float32)
+    _check(lib().mmgt_nhwc_to_ncfhw(_ptr(x), _ptr(out), B, C, F, H, W, cpad, dtype_code(x.dtype), _stream()),
+           "mmgt_nhwc_to_ncfhw")
+    return out
+
+
+def timestep_features(timesteps, dim, dtype):
+    _dev(timesteps)
+    assert timesteps.dtype == torch.float32 and timesteps.dim() == 1
+    out = torch.empty((timesteps.shape[0], dim), device=timesteps.device, dtype=dtype)
+    _check(lib().mmgt_timestep_features(_ptr(timesteps), _ptr(out), timesteps.shape[0], dim, dtype_code(dtype),
+                                        _stream()), "mmgt_timestep_features")
+    return out
+
+
+def silu(x):
+    _dev(x)
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    _check(lib().mmgt_silu(_ptr(x), _ptr(out), x.numel(), dtype_code(x.dtype), _stream()), "mmgt_silu")
+    return out
+
+
+def cfg_ddim_step(pred_sum, counter, latents, guidance, sa_t, sb_t, sa_p, sb_p):
+    """latents (1, C, F, H, W) fp32; pred_sum (2, C, F, H, W) fp32; counter (F,) fp32 -> new latents."""
+    _dev(pred_sum, counter, latents)
+    assert latents.dtype == torch.float32 and latents.is_contiguous() and pred_sum.is_contiguous()
+    _, C, F, H, W = latents.shape
+    out = torch.empty_like(latents)
+    _check(lib().mmgt_cfg_ddim_step(_ptr(pred_sum), _ptr(_f32(counter, "counter")), _ptr(latents), _ptr(out),
+                                    latents.numel(), F, H * W, guidance, sa_t, sb_t, sa_p, sb_p, _stream()),
+           "mmgt_cfg_ddim_step")
+    return out
+
+
+def accumulate_window(pred, pred_sum, counter, idx, C):
+    """pred ((2*Fw), H, W, cpad) channels-last; pred_sum (2, C, F, H, W) fp32 += pred at frames idx (int32 device)."""
+    _dev(pred, pred_sum, counter, idx)
+    assert idx.dtype == torch.int32 and pred.is_contiguous() and pred_sum.is_contiguous()
+    Fw = idx.numel()
+    F = pred_sum.shape[2]
+    hw = pred.shape[1] * pred.shape[2]
+    _check(lib().mmgt_accumulate_window(_ptr(pred), _ptr(pred_sum), _ptr(counter), _ptr(idx), Fw, F, C, pred.shape[3], hw,
+                                        dtype_code(pred.dtype), _stream()), "mmgt_accumulate_window")

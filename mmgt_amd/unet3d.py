@@ -1,0 +1,592 @@
+"""UNet3DConditionModel on MI355X: the denoise-step operator of MMGT's Stage-2 pipeline.
+
+Host-side mirror of the reference class (src/models/unet_3d.py:33-718): same constructor config, same
+`forward(sample, timestep, encoder_hidden_states, audio_embedding, ..., pose_cond_fea, full_mask, face_mask, body_mask,
+motion_scale, return_dict)` signature and semantics, same state-dict key names.  All arithmetic runs in the HIP kernels
+of libmmgt_hip.so (mmgt_amd/hip.py); this file only wires them: activations stay channels-last ((b f), h, w, c) from
+conv_in to conv_out, so none of the reference's rearrange/contiguous round trips exist here.
+
+Work the reference does and this implementation does not (results identical):
+  * bank K/V are projected once per clip (set_banks), not per frame and step (mutual_self_attention.py:150-165);
+  * the unconditional CFG half never attends to the bank (the reference computes it and overwrites it, :160-188);
+  * cross-attention to the single CLIP token is softmax over one key == 1, so it collapses to a per-CFG-row vector
+    to_out(to_v(e)) added in the attn1 output epilogue (attention.py:455-462).
+"""
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Union
+
+import torch
+
+from . import hip
+from .packing import pack_conv3x3, pack_geglu, pad_cols, pad_rows, round_up
+from .unet3d_spec import unet3d_spec
+
+SD15_CONFIG = dict(  # SD-1.5 unet/config.json + unet_3d.py:649-662 + config/prompts/animation.yaml:47-75
+    in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2, attention_head_dim=8,
+    cross_attention_dim=768, audio_attention_dim=768, norm_num_groups=32, norm_eps=1e-5, center_input_sample=False,
+    use_motion_module=True, use_audio_module=True, use_inflated_groupnorm=True,
+    motion_module_kwargs=dict(num_attention_heads=8, temporal_position_encoding_max_len=32),
+)
+
+
+@dataclass
+class UNet3DConditionOutput:
+    sample: torch.Tensor
+
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+
+class _Config(dict):
+    __getattr__ = dict.__getitem__
+
+
+class UNet3DConditionModel:
+    _supports_gradient_checkpointing = True
+
+    def __init__(self, device="cuda", dtype=torch.bfloat16, **config):
+        cfg = dict(SD15_CONFIG)
+        unknown = set(config) - set(cfg) - {"sample_size", "motion_module_type", "motion_module_resolutions",
+                                            "motion_module_mid_block", "motion_module_decoder_only",
+                                            "unet_use_cross_frame_attention", "unet_use_temporal_attention",
+                                            "stack_enable_blocks_name", "stack_enable_blocks_depth", "flip_sin_to_cos",
+                                            "freq_shift", "down_block_types", "up_block_types", "mid_block_type",
+                                            "act_fn", "downsample_padding", "mid_block_scale_factor", "_class_name",
+                                            "only_cross_attention", "dual_cross_attention", "use_linear_projection",
+                                            "class_embed_type", "num_class_embeds", "upcast_attention",
+                                            "resnet_time_scale_shift", "task_type", "mode", "_diffusers_version"}
+        if unknown:
+            raise ValueError(f"UNet3DConditionModel: unsupported config keys {sorted(unknown)}")
+        cfg.update(config)
+        self.config = _Config(cfg)
+        boc = tuple(cfg["block_out_channels"])
+        if len(boc) != 4 or any(c % 64 for c in boc) or any((c // 8) not in (40, 80, 160) for c in boc):
+            raise ValueError(f"block_out_channels {boc}: the HIP kernels cover head dims 40/80/160 (SD-1.5 widths)")
+        self.boc = boc
+        self.heads = 8
+        self.in_channels = cfg["in_channels"]
+        self.out_channels = cfg["out_channels"]
+        self._device = torch.device(device)
+        self._dtype = dtype
+        hip.dtype_code(dtype)
+        self.training = True                 # from_config leaves the module in train() mode
+        self.gradient_checkpointing = False
+        self.spec = unet3d_spec(boc, cfg["cross_attention_dim"], cfg["audio_attention_dim"], self.in_channels,
+                                self.out_channels, cfg["layers_per_block"],
+                                cfg["motion_module_kwargs"].get("temporal_position_encoding_max_len", 32))
+        self.w: Dict[str, torch.Tensor] = {}
+        self._banks: Dict[str, tuple] = {}
+        self.bank_fp16_roundtrip = dtype == torch.float32   # reference stores banks as fp16 (mutual_self_attention.py:340)
+        self._loaded = False
+
+    # ------------------------------------------------------------------------------------------ reference-style API
+    @classmethod
+    def from_config(cls, config, **kwargs):
+        config = dict(config)
+        config.update(kwargs)
+        dev = config.pop("device", "cuda")
+        dt = config.pop("dtype", torch.bfloat16)
+        return cls(device=dev, dtype=dt, **config)
+
+    @classmethod
+    def from_pretrained_2d(cls, pretrained_model_path, motion_module_path, subfolder=None, unet_additional_kwargs=None,
+                           mm_zero_proj_out=False, device="cuda", dtype=torch.bfloat16):
+        """unet_3d.py:627-718: SD-1.5 `unet/` weights merged with the motion-module checkpoint, strict=False."""
+        import json
+        from pathlib import Path
+        path = Path(pretrained_model_path)
+        if subfolder is not None:
+            path = path / subfolder
+        cfg_file = path / "config.json"
+        if not cfg_file.is_file():
+            raise RuntimeError(f"{cfg_file} does not exist or is not a file")
+        cfg = json.load(open(cfg_file))
+        keep = {k: v for k, v in cfg.items() if k in SD15_CONFIG}
+        model = cls(device=device, dtype=dtype, **keep, **{k: v for k, v in (unet_additional_kwargs or {}).items()})
+        if (path / "diffusion_pytorch_model.safetensors").exists():
+            from safetensors.torch import load_file
+            sd = load_file(str(path / "diffusion_pytorch_model.safetensors"), device="cpu")
+        elif (path / "diffusion_pytorch_model.bin").exists():
+            sd = torch.load(path / "diffusion_pytorch_model.bin", map_location="cpu", weights_only=True)
+        else:
+            raise FileNotFoundError(f"no weights file found in {path}")
+        mpath = Path(motion_module_path)
+        if mpath.exists() and mpath.is_file():
+            if mpath.suffix.lower() in (".pth", ".pt", ".ckpt"):
+                msd = torch.load(mpath, map_location="cpu", weights_only=True)
+            elif mpath.suffix.lower() == ".safetensors":
+                from safetensors.torch import load_file
+                msd = load_file(str(mpath), device="cpu")
+            else:
+                raise RuntimeError(f"unknown file format for motion module weights: {mpath.suffix}")
+            if mm_zero_proj_out:
+                msd = {k: v for k, v in msd.items() if "proj_out" not in k}
+            sd.update(msd)
+        model.load_state_dict(sd, strict=False)
+        return model
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def device(self):
+        return self._device
+
+    def to(self, device=None, dtype=None):
+        if (device is not None and torch.device(device) != self._device) or (dtype is not None and dtype != self._dtype):
+            raise RuntimeError("construct UNet3DConditionModel with the target device/dtype: packed weights are not re-cast")
+        return self
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def enable_gradient_checkpointing(self):
+        """Only observable effect at inference: with train() mode it selects the motion_scale-weighted MM-HAA sum
+        (unet_3d_blocks.py:539-572 vs :591-600)."""
+        self.gradient_checkpointing = True
+
+    def disable_gradient_checkpointing(self):
+        self.gradient_checkpointing = False
+
+    def state_dict_spec(self):
+        return dict(self.spec)
+
+    # ------------------------------------------------------------------------------------------ weights
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self.spec if k not in sd]
+        unexpected = [k for k in sd if k not in self.spec]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:5]}... ({len(missing)}), unexpected "
+                               f"{unexpected[:5]}... ({len(unexpected)})")
+        for k in self.spec:
+            if k in sd and tuple(sd[k].shape) != tuple(self.spec[k]):
+                raise RuntimeError(f"load_state_dict: shape mismatch for {k}: {tuple(sd[k].shape)} vs {self.spec[k]}")
+        if missing:
+            if not self._loaded:
+                raise RuntimeError(f"load_state_dict(strict=False) on an empty model still needs every key; missing "
+                                   f"{len(missing)} e.g. {missing[:3]}")
+        self._pack(sd)
+        self._loaded = True
+        self._banks = {}
+        return missing, unexpected
+
+    def _t(self, x):      # model-dtype device copy
+        return x.to(device=self._device, dtype=self._dtype).contiguous()
+
+    def _f(self, x):      # fp32 device copy (bias / norm affine)
+        return x.to(device=self._device, dtype=torch.float32).contiguous()
+
+    def _pack(self, sd):
+        w = self.w
+        has = lambda k: k in sd
+
+        def norm(p):
+            if has(p + ".weight"):
+                w[p + ".g"], w[p + ".b"] = self._f(sd[p + ".weight"]), self._f(sd[p + ".bias"])
+
+        def lin(p, key=None):
+            key = key or p
+            if has(p + ".weight"):
+                w[key + ".w"] = self._t(sd[p + ".weight"].reshape(sd[p + ".weight"].shape[0], -1))
+            if has(p + ".bias"):
+                w[key + ".bias"] = self._f(sd[p + ".bias"])
+
+        def ff(p):
+            if has(p + ".net.0.proj.weight"):
+                wp, bp = pack_geglu(sd[p + ".net.0.proj.weight"], sd[p + ".net.0.proj.bias"])
+                w[p + ".ff1.w"], w[p + ".ff1.bias"] = self._t(wp), self._f(bp)
+            lin(p + ".net.2", p + ".ff2")
+
+        def self_attn(p):
+            if has(p + ".to_q.weight"):
+                w[p + ".qk.w"] = self._t(torch.cat([sd[p + ".to_q.weight"], sd[p + ".to_k.weight"]], 0))
+                w[p + ".k.w"] = self._t(sd[p + ".to_k.weight"])
+                w[p + ".v.w"] = self._t(sd[p + ".to_v.weight"])
+            lin(p + ".to_out.0", p + ".o")
+
+        def conv(p, cin_pad=None, cout_pad=None):
+            if has(p + ".weight"):
+                w[p + ".w"] = self._t(pack_conv3x3(sd[p + ".weight"], cin_pad, cout_pad))
+            if has(p + ".bias"):
+                w[p + ".bias"] = self._f(pad_rows(sd[p + ".bias"], cout_pad or sd[p + ".bias"].shape[0]))
+
+        conv("conv_in", cin_pad=64)
+        conv("conv_out", cout_pad=64)
+        norm("conv_norm_out")
+        lin("time_embedding.linear_1")
+        lin("time_embedding.linear_2")
+
+        self._resnets = [k[: -len(".conv1.weight")] for k in self.spec if k.endswith(".conv1.weight")]
+        temb_w, temb_b, off = [], [], 0
+        self._temb_slices = {}
+        for p in self._resnets:
+            norm(p + ".norm1")
+            norm(p + ".norm2")
+            conv(p + ".conv1")
+            conv(p + ".conv2")
+            cout = self.spec[p + ".conv1.weight"][0]
+            self._temb_slices[p] = (off, cout)
+            off += cout
+            if has(p + ".time_emb_proj.weight"):
+                temb_w.append(sd[p + ".time_emb_proj.weight"])
+                temb_b.append(sd[p + ".time_emb_proj.bias"])
+            if (p + ".conv_shortcut.weight") in self.spec and has(p + ".conv_shortcut.weight"):
+                ws = sd[p + ".conv_shortcut.weight"].reshape(cout, -1)
+                w[p + ".sc.w"] = self._t(ws)
+                w[p + ".sc.bias"] = self._f(sd[p + ".conv_shortcut.bias"])
+        if temb_w:
+            assert len(temb_w) == len(self._resnets), "time_emb_proj weights must be loaded together"
+            w["temb_all.w"] = self._t(torch.cat(temb_w, 0))
+            w["temb_all.bias"] = self._f(torch.cat(temb_b, 0))
+
+        for k in self.spec:
+            if k.endswith("samplers.0.conv.weight"):
+                conv(k[: -len(".weight")])
+
+        self._spatial = [k[: -len(".transformer_blocks.0.attn2.to_q.weight")] for k in self.spec
+                         if k.endswith(".transformer_blocks.0.attn2.to_q.weight")]
+        for p in self._spatial:
+            t = p + ".transformer_blocks.0"
+            norm(p + ".norm")
+            lin(p + ".proj_in")
+            lin(p + ".proj_out")
+            for n in ("norm1", "norm2", "norm3"):
+                norm(f"{t}.{n}")
+            self_attn(t + ".attn1")
+            lin(t + ".attn2.to_q", t + ".attn2.q")
+            if has(t + ".attn2.to_k.weight"):
+                w[t + ".attn2.kv.w"] = self._t(torch.cat([sd[t + ".attn2.to_k.weight"], sd[t + ".attn2.to_v.weight"]], 0))
+                w[t + ".attn2.v.w"] = self._t(sd[t + ".attn2.to_v.weight"])
+            lin(t + ".attn2.to_out.0", t + ".attn2.o")
+            ff(t + ".ff")
+
+        self._audio = [k[: -len(".transformer_blocks.0.attn2_0.to_q.weight")] for k in self.spec
+                       if k.endswith(".transformer_blocks.0.attn2_0.to_q.weight")]
+        for p in self._audio:
+            t = p + ".transformer_blocks.0"
+            norm(p + ".norm")
+            lin(p + ".proj_in")
+            lin(p + ".proj_out")
+            for n in ("norm1", "norm2", "norm3"):
+                norm(f"{t}.{n}")
+            self_attn(t + ".attn1")
+            if has(f"{t}.attn2_0.to_q.weight"):
+                w[t + ".q3.w"] = self._t(torch.cat([sd[f"{t}.attn2_{i}.to_q.weight"] for i in range(3)], 0))
+                w[t + ".kv3.w"] = self._t(torch.cat([sd[f"{t}.attn2_{i}.to_k.weight"] for i in range(3)] +
+                                                    [sd[f"{t}.attn2_{i}.to_v.weight"] for i in range(3)], 0))
+            for i, z in enumerate(("zero_conv_full", "zero_conv_face", "zero_conv_lip")):
+                lin(f"{t}.attn2_{i}.to_out.0", f"{t}.o{i}")
+                lin(f"{t}.{z}", f"{t}.z{i}")
+            ff(t + ".ff")
+
+        self._motion = [k[: -len(".temporal_transformer.norm.weight")] for k in self.spec
+                        if k.endswith(".temporal_transformer.norm.weight")]
+        for p in self._motion:
+            q = p + ".temporal_transformer"
+            t = q + ".transformer_blocks.0"
+            norm(q + ".norm")
+            lin(q + ".proj_in")
+            lin(q + ".proj_out")
+            for i in range(2):
+                a = f"{t}.attention_blocks.{i}"
+                if has(a + ".to_q.weight"):
+                    w[a + ".qkv.w"] = self._t(torch.cat([sd[a + ".to_q.weight"], sd[a + ".to_k.weight"],
+                                                         sd[a + ".to_v.weight"]], 0))
+                lin(a + ".to_out.0", a + ".o")
+                if has(a + ".pos_encoder.pe"):
+                    w[a + ".pe"] = self._f(sd[a + ".pos_encoder.pe"][0])
+                norm(f"{t}.norms.{i}")
+            norm(t + ".ff_norm")
+            ff(t + ".ff")
+
+    # ------------------------------------------------------------------------------------------ reference banks
+    def bank_keys(self) -> List[str]:
+        """The 16 reference-attention readers in the reference's module order down -> up -> mid."""
+        down = [p for p in self._spatial if p.startswith("down_blocks")]
+        up = [p for p in self._spatial if p.startswith("up_blocks")]
+        mid = [p for p in self._spatial if p.startswith("mid_block")]
+        return down + up + mid
+
+    def set_banks(self, banks: Optional[Dict[str, torch.Tensor]]):
+        """banks: {prefix: (2, N, C)} LayerNorm'd ReferenceNet features (what `ReferenceAttentionControl.update`
+        hands over).  Projects K and V^T of every bank ONCE (they are step- and frame-invariant)."""
+        self._banks = {}
+        if not banks:
+            return
+        for p, bank in banks.items():
+            if p not in self._spatial:
+                raise KeyError(f"set_banks: {p} is not a reference-attention reader")
+            t = p + ".transformer_blocks.0.attn1"
+            bk = bank.to(self._device)
+            if self.bank_fp16_roundtrip:
+                bk = bk.to(torch.float16)
+            bk = bk.to(self._dtype).contiguous()
+            two, n, c = bk.shape
+            kb = hip.gemm(bk.view(two * n, c), self.w[t + ".k.w"]).view(two, n, -1)
+            vbt = torch.empty((two, kb.shape[2], round_up(n, 8)), device=self._device, dtype=self._dtype)
+            hip.gemm_batched_wx(self.w[t + ".v.w"], bk, out=vbt)
+            self._banks[p] = (kb, vbt, n)
+
+    def clear_banks(self):
+        self._banks = {}
+
+    # ------------------------------------------------------------------------------------------ building blocks
+    def _gn(self, p, x, eps, silu=False, x1=None):
+        nb, h, ww, c = x.shape
+        y = hip.groupnorm(x.view(nb, h * ww, c), self.w[p + ".g"], self.w[p + ".b"], 32, eps, silu=silu,
+                          x1=None if x1 is None else x1.view(nb, h * ww, -1))
+        return y.view(nb, h, ww, -1)
+
+    def _ln(self, p, x, **kw):
+        return hip.layernorm(x, self.w[p + ".g"], self.w[p + ".b"], 1e-5, **kw)
+
+    def _lin(self, p, x, **kw):
+        return hip.gemm(x, self.w[p + ".w"], self.w.get(p + ".bias"), **kw)
+
+    def _ff(self, p, x, residual):
+        g = hip.gemm(x, self.w[p + ".ff1.w"], self.w[p + ".ff1.bias"], act=hip.ACT_GEGLU)
+        return hip.gemm(g, self.w[p + ".ff2.w"], self.w[p + ".ff2.bias"], residual=residual)
+
+    def _resnet(self, p, x, temb, skip=None):
+        """ResnetBlock3D (resnet.py:217-247); `skip` = the UNet skip tensor that the reference concatenates first."""
+        nb, h, ww, c0 = x.shape
+        hw = h * ww
+        cout = self.spec[p + ".conv1.weight"][0]
+        hdn = self._gn(p + ".norm1", x, self.config.norm_eps, silu=True, x1=skip)
+        hdn = hip.conv3x3(hdn, self.w[p + ".conv1.w"], self.w[p + ".conv1.bias"], bias2=temb[p],
+                          bias2_rows=(nb // temb[p].shape[0]) * hw)
+        hdn = self._gn(p + ".norm2", hdn, self.config.norm_eps, silu=True)
+        if (p + ".sc.w") in self.w:
+            wsc = self.w[p + ".sc.w"]
+            if skip is None:
+                res = hip.gemm(x.view(nb * hw, c0), wsc, self.w[p + ".sc.bias"])
+            else:
+                c1 = skip.shape[3]
+                res = hip.gemm(x.view(nb * hw, c0), self._sc_split(p, c0, 0), self.w[p + ".sc.bias"])
+                res = hip.gemm(skip.view(nb * hw, c1), self._sc_split(p, c0, 1), None, residual=res)
+            res = res.view(nb, h, ww, cout)
+        else:
+            assert skip is None
+            res = x
+        return hip.conv3x3(hdn, self.w[p + ".conv2.w"], self.w[p + ".conv2.bias"], residual=res)
+
+    def _sc_split(self, p, c0, which):
+        key = f"{p}.sc.w.{which}"
+        if key not in self.w:
+            wsc = self.w[p + ".sc.w"]
+            self.w[f"{p}.sc.w.0"] = wsc[:, :c0].contiguous()
+            self.w[f"{p}.sc.w.1"] = wsc[:, c0:].contiguous()
+        return self.w[key]
+
+    def _self_attention(self, t, n1, nb, n, inner, bank=None, frames=1):
+        """attn1: q,k from one GEMM, V^T from a batched W.X^T GEMM, flash attention, returns (nb*n, inner)."""
+        hd = inner // self.heads
+        qk = hip.gemm(n1, self.w[t + ".qk.w"])
+        npad = round_up(n, 8)
+        vt = torch.empty((nb, inner, npad), device=self._device, dtype=self._dtype)
+        hip.gemm_batched_wx(self.w[t + ".v.w"], n1.view(nb, n, inner), out=vt)
+        o = torch.empty((nb * n, inner), device=self._device, dtype=self._dtype)
+        kw = {}
+        if bank is not None:
+            kb, vbt, nkb = bank
+            kw = dict(k2=kb, v2=vbt, k2_str=(kb.stride(0), kb.stride(1)), v2_str=(vbt.stride(0), vbt.stride(1)),
+                      k2_bdiv=frames, nk2=nkb, seg2_first_batch=nb // 2)
+        hip.attention(qk, qk[:, inner:], vt, o, batch=nb, heads=self.heads, hd=hd, nq=n, nk=n, scale=hd ** -0.5,
+                      q_str=(n * 2 * inner, 0, 2 * inner), k_str=(n * 2 * inner, 0, 2 * inner),
+                      v_str=(inner * npad, 0, npad), o_str=(n * inner, 0, inner), v_transposed=True, **kw)
+        return o
+
+    def _spatial_transformer(self, p, x, ehs, frames):
+        """Transformer3DModel + TemporalBasicTransformerBlock in bank-read mode (transformer_3d.py:139-268,
+        mutual_self_attention.py:149-230)."""
+        nb, h, ww, c = x.shape
+        n = h * ww
+        m = nb * n
+        t = p + ".transformer_blocks.0"
+        xn = self._gn(p + ".norm", x, 1e-6)
+        hid = self._lin(p + ".proj_in", xn.view(m, c))
+        inner = hid.shape[1]
+        n1 = self._ln(t + ".norm1", hid)
+        o = self._self_attention(t + ".attn1", n1, nb, n, inner, bank=self._banks.get(p), frames=frames)
+        if ehs.shape[1] == 1:
+            # one key: softmax == 1, attn2 output is the per-CFG-row constant to_out(to_v(e))
+            e = ehs.reshape(ehs.shape[0], -1).to(self._dtype).contiguous()
+            cvec = hip.gemm(hip.gemm(e, self.w[t + ".attn2.v.w"]), self.w[t + ".attn2.o.w"], self.w[t + ".attn2.o.bias"])
+            rows = nb // ehs.shape[0] * n if ehs.shape[0] != nb else n
+            hid = hip.gemm(o, self.w[t + ".attn1.o.w"], self.w[t + ".attn1.o.bias"], residual=hid,
+                           bias2=cvec.float(), bias2_rows=rows)
+        else:
+            hid = hip.gemm(o, self.w[t + ".attn1.o.w"], self.w[t + ".attn1.o.bias"], residual=hid)
+            hid = self._cross_attention(t, hid, ehs, nb, n, inner)
+        hid = self._ff(t + ".ff", self._ln(t + ".norm3", hid), hid)
+        out = hip.gemm(hid, self.w[p + ".proj_out.w"], self.w[p + ".proj_out.bias"], residual=x.view(m, c))
+        return out.view(nb, h, ww, c)
+
+    def _cross_attention(self, t, hid, ehs, nb, n, inner):
+        """General attn2 (more than one context token): attention.py:448-462."""
+        hd = inner // self.heads
+        n2 = self._ln(t + ".norm2", hid)
+        q = hip.gemm(n2, self.w[t + ".attn2.q.w"])
+        e = ehs.to(self._dtype)
+        if e.shape[0] != nb:
+            e = e.repeat_interleave(nb // e.shape[0], dim=0)
+        e = e.contiguous()
+        l = e.shape[1]
+        kv = hip.gemm(e.view(nb * l, -1), self.w[t + ".attn2.kv.w"])
+        o = torch.empty_like(q)
+        hip.attention(q, kv, kv[:, inner:], o, batch=nb, heads=self.heads, hd=hd, nq=n, nk=l, scale=hd ** -0.5,
+                      q_str=(n * inner, 0, inner), k_str=(l * 2 * inner, 0, 2 * inner), v_str=(l * 2 * inner, 0, 2 * inner),
+                      o_str=(n * inner, 0, inner))
+        return hip.gemm(o, self.w[t + ".attn2.o.w"], self.w[t + ".attn2.o.bias"], residual=hid)
+
+    def _audio_transformer(self, p, x, audio, masks, depth, motion_scale):
+        """MM-HAA (attention.py:649-771): self-attention, three masked audio cross-attentions through zero-convs."""
+        nb, h, ww, c = x.shape
+        n = h * ww
+        m = nb * n
+        t = p + ".transformer_blocks.0"
+        xn = self._gn(p + ".norm", x, 1e-6)
+        hid = self._lin(p + ".proj_in", xn.view(m, c))
+        inner = hid.shape[1]
+        hd = inner // self.heads
+        n1 = self._ln(t + ".norm1", hid)
+        o = self._self_attention(t + ".attn1", n1, nb, n, inner)
+        hid = hip.gemm(o, self.w[t + ".attn1.o.w"], self.w[t + ".attn1.o.bias"], residual=hid)
+        n2 = self._ln(t + ".norm2", hid)
+        q3 = hip.gemm(n2, self.w[t + ".q3.w"])
+        la = audio.shape[1]
+        kv3 = hip.gemm(audio.view(nb * la, -1), self.w[t + ".kv3.w"])
+        a3 = torch.empty_like(q3)
+        hip.attention(q3, kv3, kv3[:, 3 * inner:], a3, batch=nb, heads=3 * self.heads, hd=hd, nq=n, nk=la,
+                      scale=hd ** -0.5, q_str=(n * 3 * inner, 0, 3 * inner), k_str=(la * 6 * inner, 0, 6 * inner),
+                      v_str=(la * 6 * inner, 0, 6 * inner), o_str=(n * 3 * inner, 0, 3 * inner))
+        for i in range(3):
+            mask = masks[i][depth].reshape(-1).to(device=self._device, dtype=torch.float32).contiguous()
+            if mask.numel() != m:
+                raise RuntimeError(f"mask level {depth} has {mask.numel()} entries, block has {m} tokens")
+            br = hip.gemm(a3[:, i * inner:(i + 1) * inner], self.w[f"{t}.o{i}.w"], self.w[f"{t}.o{i}.bias"],
+                          row_scale=mask)
+            s = 1.0 if motion_scale is None else float(motion_scale[i])
+            hid = hip.gemm(br, self.w[f"{t}.z{i}.w"], self.w[f"{t}.z{i}.bias"], alpha=s, residual=hid)
+        hid = self._ff(t + ".ff", self._ln(t + ".norm3", hid), hid)
+        out = hip.gemm(hid, self.w[p + ".proj_out.w"], self.w[p + ".proj_out.bias"], residual=x.view(m, c))
+        return out.view(nb, h, ww, c)
+
+    def _motion_module(self, p, x, frames):
+        """VanillaTemporalModule (motion_module.py:146-182,236-259,351-388): attention runs over the frame axis in
+        place on the ((b f), hw, c) layout (batch = (b, pixel), token stride hw*c)."""
+        nb, h, ww, c = x.shape
+        n = h * ww
+        m = nb * n
+        b = nb // frames
+        hd = c // self.heads
+        if frames > 32:
+            raise RuntimeError("temporal attention window is limited to 32 frames (positional encoding max_len)")
+        q = p + ".temporal_transformer"
+        t = q + ".transformer_blocks.0"
+        xn = self._gn(q + ".norm", x, 1e-6)
+        hid = self._lin(q + ".proj_in", xn.view(m, c))
+        for i in range(2):
+            a = f"{t}.attention_blocks.{i}"
+            nrm = self._ln(f"{t}.norms.{i}", hid, pe=self.w[a + ".pe"], pe_div=n, pe_mod=frames)
+            qkv = hip.gemm(nrm, self.w[a + ".qkv.w"])
+            o = torch.empty((m, c), device=self._device, dtype=self._dtype)
+            st = (frames * n * 3 * c, 3 * c, n * 3 * c)
+            hip.attention(qkv, qkv[:, c:], qkv[:, 2 * c:], o, batch=b * n, heads=self.heads, hd=hd, nq=frames, nk=frames,
+                          scale=hd ** -0.5, q_str=st, k_str=st, v_str=st, o_str=(frames * n * c, c, n * c), bdiv=n)
+            hid = hip.gemm(o, self.w[a + ".o.w"], self.w[a + ".o.bias"], residual=hid)
+        hid = self._ff(t + ".ff", self._ln(t + ".ff_norm", hid), hid)
+        out = hip.gemm(hid, self.w[q + ".proj_out.w"], self.w[q + ".proj_out.bias"], residual=x.view(m, c))
+        return out.view(nb, h, ww, c)
+
+    # ------------------------------------------------------------------------------------------ forward
+    def _time_embedding(self, timestep, batch):
+        if not torch.is_tensor(timestep):
+            ts = torch.tensor([float(timestep)], dtype=torch.float32, device=self._device)
+        else:
+            ts = timestep.to(device=self._device, dtype=torch.float32).reshape(-1)
+        ts = ts.expand(batch).contiguous()
+        feat = hip.timestep_features(ts, self.boc[0], self._dtype)
+        e = self._lin("time_embedding.linear_1", feat, act=hip.ACT_SILU)
+        e = self._lin("time_embedding.linear_2", e)
+        # every ResnetBlock3D's time_emb_proj(silu(emb)) in one GEMM (resnet.py:225-226)
+        all_t = hip.gemm(hip.silu(e), self.w["temb_all.w"], self.w["temb_all.bias"]).float()
+        return {p: all_t[:, off:off + n].contiguous() for p, (off, n) in self._temb_slices.items()}
+
+    def forward(self, sample, timestep, encoder_hidden_states, audio_embedding=None, class_labels=None,
+                mask_cond_fea=None, pose_cond_fea=None, attention_mask=None, full_mask=None, face_mask=None,
+                body_mask=None, motion_scale=None, down_block_additional_residuals=None,
+                mid_block_additional_residual=None, return_dict: bool = True):
+        if not self._loaded:
+            raise RuntimeError("UNet3DConditionModel.forward before load_state_dict")
+        if attention_mask is not None or class_labels is not None or down_block_additional_residuals is not None \
+                or mid_block_additional_residual is not None:
+            raise NotImplementedError("attention_mask / class_labels / additional residuals are not used on this path")
+        if not sample.is_cuda:
+            raise RuntimeError("mmgt_amd.UNet3DConditionModel runs on the GPU only (no CPU path exists)")
+        b, cin, f, hh, ww = sample.shape
+        if hh % 8 or ww % 8:
+            raise RuntimeError("latent height/width must be multiples of 8 (unet_3d.py:461-469)")
+        lpb = self.config.layers_per_block
+        # scripts leave the module in train() + gradient checkpointing => motion_scale applied
+        ms = motion_scale if (self.training and self.gradient_checkpointing) else None
+        x_in = sample.to(torch.float32).contiguous()
+        if self.config.center_input_sample:
+            x_in = 2 * x_in - 1.0
+        temb = self._time_embedding(timestep, b)
+        x = hip.ncfhw_to_nhwc(x_in, 64, self._dtype)
+        pose = None
+        if pose_cond_fea is not None:
+            pose = hip.ncfhw_to_nhwc(pose_cond_fea.to(torch.float32).contiguous(), self.boc[0], self._dtype)
+        x = hip.conv3x3(x, self.w["conv_in.w"], self.w["conv_in.bias"], residual=pose)
+        audio = None
+        if audio_embedding is not None:
+            audio = audio_embedding.to(device=self._device, dtype=self._dtype).reshape(b * f, *audio_embedding.shape[2:])
+            audio = audio.contiguous()
+        masks = (full_mask, face_mask, body_mask)
+        ehs = encoder_hidden_states.to(self._device)
+
+        skips = [x]
+        for i in range(4):
+            p = f"down_blocks.{i}"
+            for j in range(lpb):
+                x = self._resnet(f"{p}.resnets.{j}", x, temb)
+                if i < 3:
+                    x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs, f)
+                    if f"{p}.audio_modules.{j}" in self._audio:
+                        x = self._audio_transformer(f"{p}.audio_modules.{j}", x, audio, masks, i, ms)
+                x = self._motion_module(f"{p}.motion_modules.{j}", x, f)
+                skips.append(x)
+            if i != 3:
+                x = hip.conv3x3(x, self.w[f"{p}.downsamplers.0.conv.w"], self.w[f"{p}.downsamplers.0.conv.bias"], stride=2)
+                skips.append(x)
+
+        x = self._resnet("mid_block.resnets.0", x, temb)
+        x = self._spatial_transformer("mid_block.attentions.0", x, ehs, f)
+        x = self._motion_module("mid_block.motion_modules.0", x, f)
+        x = self._resnet("mid_block.resnets.1", x, temb)
+
+        for i in range(4):
+            p = f"up_blocks.{i}"
+            for j in range(lpb + 1):
+                x = self._resnet(f"{p}.resnets.{j}", x, temb, skip=skips.pop())
+                if i > 0:
+                    x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs, f)
+                x = self._motion_module(f"{p}.motion_modules.{j}", x, f)
+            if i != 3:
+                x = hip.conv3x3(x, self.w[f"{p}.upsamplers.0.conv.w"], self.w[f"{p}.upsamplers.0.conv.bias"], upsample=True)
+
+        x = self._gn("conv_norm_out", x, self.config.norm_eps, silu=True)
+        x = hip.conv3x3(x, self.w["conv_out.w"], self.w["conv_out.bias"])
+        out = hip.nhwc_to_ncfhw(x, b, self.out_channels).to(sample.dtype)
+        if not return_dict:
+            return (out,)
+        return UNet3DConditionOutput(sample=out)
+
+    __call__ = forward

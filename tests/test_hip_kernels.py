@@ -1,0 +1,310 @@
+"""Per-kernel parity of libmmgt_hip.so (through the C ABI, via mmgt_amd.hip) against plain fp32 torch math on the same
+inputs.  fp32-I/O mode is held to rtol 1e-3 / atol 1e-4 (the north-star tolerance); bf16 mode is compared with the fp32
+result of the bf16-rounded inputs at a bf16-output tolerance."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from mmgt_amd.synthetic import hash_uniform  # noqa: E402
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return dict(rtol=1e-3, atol=1e-4) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(name, shape, scale=1.0, dt=torch.float32):
+    return hash_uniform(name, shape, scale).to(dev()).to(dt)
+
+
+def ref_gemm(a, w):
+    return a.double() @ w.double().t()
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(16, 320, 320), (200, 320, 640), (128, 128, 64), (333, 960, 320), (2, 1280, 320),
+                                   (1536, 640, 768), (4096, 1280, 5120)])
+def test_gemm_plain_and_epilogue(dt, M, N, K):
+    from mmgt_amd import hip
+    a = rnd("a", (M, K), 1.0, dt)
+    w = rnd("w", (N, K), 1.0 / math.sqrt(K), dt)
+    bias = rnd("b", (N,), 0.5)
+    res = rnd("r", (M, N), 1.0, dt)
+    rs = rnd("rs", (M,), 1.0) + 1.0
+    rows = 7 if M > 7 else 1
+    b2 = rnd("b2", ((M + rows - 1) // rows, N), 0.5)
+    out = hip.gemm(a, w)
+    torch.testing.assert_close(out.double(), ref_gemm(a, w), **tol(dt))
+    out = hip.gemm(a, w, bias, residual=res, row_scale=rs, alpha=0.75, bias2=b2, bias2_rows=rows)
+    ref = (ref_gemm(a, w) + bias.double() + b2.double().repeat_interleave(rows, 0)[:M]) * rs.double()[:, None] * 0.75 \
+        + res.double()
+    torch.testing.assert_close(out.double(), ref, **tol(dt))
+    out = hip.gemm(a, w, bias, act=hip.ACT_SILU)
+    torch.testing.assert_close(out.double(), F.silu(ref_gemm(a, w) + bias.double()), **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_strided_views(dt):
+    from mmgt_amd import hip
+    big = rnd("big", (100, 960), 1.0, dt)
+    a = big[:, 320:640]
+    w = rnd("w", (320, 320), 0.05, dt)
+    outbig = torch.zeros((100, 640), device=dev(), dtype=dt)
+    hip.gemm(a, w, out=outbig[:, 320:])
+    torch.testing.assert_close(outbig[:, 320:].double(), ref_gemm(a, w), **tol(dt))
+    assert outbig[:, :320].abs().max() == 0
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_geglu(dt):
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_geglu
+    M, C = 150, 320
+    a = rnd("a", (M, C), 1.0, dt)
+    w = rnd("w", (8 * C, C), 1.0 / math.sqrt(C), dt)
+    b = rnd("b", (8 * C,), 0.5)
+    wp, bp = pack_geglu(w, b)
+    res = rnd("res", (M, 4 * C), 1.0, dt)
+    out = hip.gemm(a, wp, bp, act=hip.ACT_GEGLU)
+    h, g = (ref_gemm(a, w) + b.double()).chunk(2, dim=-1)
+    torch.testing.assert_close(out.double(), h * F.gelu(g), **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_gemm_batched_vt(dt):
+    from mmgt_amd import hip
+    B, ntok, C, inner = 3, 100, 320, 320
+    x = rnd("x", (B, ntok, C), 1.0, dt)
+    w = rnd("w", (inner, C), 0.05, dt)
+    ld = 104
+    out = torch.zeros((B, inner, ld), device=dev(), dtype=dt)
+    hip.gemm_batched_wx(w, x, out=out)
+    ref = torch.einsum("rc,bnc->brn", w.double(), x.double())
+    torch.testing.assert_close(out[:, :, :ntok].double(), ref, **tol(dt))
+    assert out[:, :, ntok:].abs().max() == 0
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("cin,cout,hw,stride,up", [(64, 320, 8, 1, False), (320, 320, 8, 2, False),
+                                                   (640, 640, 4, 1, True), (320, 64, 5, 1, False),
+                                                   (1280, 1280, 2, 1, False), (64, 128, 1, 1, False)])
+def test_conv3x3(dt, cin, cout, hw, stride, up):
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_conv3x3
+    nb = 6
+    x = rnd("x", (nb, cin, hw, hw), 1.0, dt)
+    w = rnd("w", (cout, cin, 3, 3), 1.0 / math.sqrt(9 * cin), dt)
+    b = rnd("b", (cout,), 0.5)
+    xin = F.interpolate(x.double(), scale_factor=2.0, mode="nearest") if up else x.double()
+    ref = F.conv2d(xin, w.double(), b.double(), stride=stride, padding=1)
+    out = hip.conv3x3(_nhwc(x), pack_conv3x3(w), b, stride=stride, upsample=up)
+    torch.testing.assert_close(out.double(), _nhwc(ref), **tol(dt))
+    # time-embedding add (one row per 3 images) + residual
+    b2 = rnd("b2", (2, cout), 0.5)
+    res = rnd("res", tuple(ref.shape), 1.0, dt)
+    out = hip.conv3x3(_nhwc(x), pack_conv3x3(w), b, stride=stride, upsample=up, bias2=b2,
+                      bias2_rows=3 * ref.shape[2] * ref.shape[3], residual=_nhwc(res))
+    ref2 = ref + b2.double().repeat_interleave(3, 0)[:, :, None, None] + res.double()
+    torch.testing.assert_close(out.double(), _nhwc(ref2), **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_conv3x3_two_sources(dt):
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_conv3x3
+    x0 = rnd("x0", (4, 320, 6, 6), 1.0, dt)
+    x1 = rnd("x1", (4, 640, 6, 6), 1.0, dt)
+    w = rnd("w", (320, 960, 3, 3), 0.01, dt)
+    ref = F.conv2d(torch.cat([x0, x1], 1).double(), w.double(), None, padding=1)
+    out = hip.conv3x3(_nhwc(x0), pack_conv3x3(w), None, x1=_nhwc(x1))
+    torch.testing.assert_close(out.double(), _nhwc(ref), **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("c0,c1,hw,silu", [(320, 0, 64, True), (640, 320, 16, True), (1280, 1280, 4, False),
+                                           (1280, 0, 1, True), (128, 0, 4096, True), (320, 0, 300, False)])
+def test_groupnorm(dt, c0, c1, hw, silu):
+    from mmgt_amd import hip
+    nb = 3
+    x0 = rnd("x0", (nb, hw, c0), 1.5, dt) + 0.3
+    x1 = rnd("x1", (nb, hw, c1), 0.7, dt) if c1 else None
+    g = rnd("g", (c0 + c1,), 0.2) + 1.0
+    b = rnd("b", (c0 + c1,), 0.2)
+    xx = torch.cat([x0, x1], 2) if c1 else x0
+    ref = F.group_norm(xx.double().permute(0, 2, 1), 32, g.double(), b.double(), 1e-5).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    out = hip.groupnorm(x0, g, b, 32, 1e-5, silu=silu, x1=x1)
+    torch.testing.assert_close(out.double(), ref, **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("C", [320, 640, 768, 1280])
+def test_layernorm(dt, C):
+    from mmgt_amd import hip
+    rows = 4 * 6 * 5 + 3
+    x = rnd("x", (rows, C), 2.0, dt) + 0.5
+    g = rnd("g", (C,), 0.2) + 1.0
+    b = rnd("b", (C,), 0.2)
+    ref = F.layer_norm(x.double(), (C,), g.double(), b.double(), 1e-5)
+    torch.testing.assert_close(hip.layernorm(x, g, b).double(), ref, **tol(dt))
+    pe = rnd("pe", (6, C), 1.0)
+    idx = (torch.arange(rows, device=dev()) // 5) % 6
+    torch.testing.assert_close(hip.layernorm(x, g, b, pe=pe, pe_div=5, pe_mod=6).double(), ref + pe.double()[idx],
+                               **tol(dt))
+
+
+def _ref_attn(q, k, v, scale):
+    # q (B, H, Nq, d), k/v (B, H, Nk, d) doubles
+    s = torch.einsum("bhqd,bhkd->bhqk", q, k) * scale
+    return torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, -1), v)
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("hd,nq,nk2", [(40, 64, 64), (40, 200, 200), (80, 16, 16), (160, 4, 4), (160, 1, 1),
+                                       (80, 300, 0), (40, 1024, 1024)])
+@pytest.mark.parametrize("vt", [False, True])
+def test_attention_spatial_with_bank(dt, hd, nq, nk2, vt):
+    """Self-attention over nq tokens; the second half of the batch also attends to a per-CFG-row bank of nk2 keys."""
+    from mmgt_amd import hip
+    heads, frames = 8, 3
+    B = 2 * frames
+    inner = heads * hd
+    q = rnd("q", (B, nq, inner), 1.0, dt)
+    k = rnd("k", (B, nq, inner), 1.0, dt)
+    v = rnd("v", (B, nq, inner), 1.0, dt)
+    kb = rnd("kb", (2, max(nk2, 1), inner), 1.0, dt)
+    vb = rnd("vb", (2, max(nk2, 1), inner), 1.0, dt)
+    scale = hd ** -0.5
+    split = lambda t: t.double().reshape(t.shape[0], t.shape[1], heads, hd).permute(0, 2, 1, 3)
+    refs = []
+    for b in range(B):
+        kk, vv = k[b:b + 1], v[b:b + 1]
+        if nk2 and b >= frames:
+            kk = torch.cat([kk, kb[b // frames][None]], 1)
+            vv = torch.cat([vv, vb[b // frames][None]], 1)
+        refs.append(_ref_attn(split(q[b:b + 1]), split(kk), split(vv), scale))
+    ref = torch.cat(refs).permute(0, 2, 1, 3).reshape(B, nq, inner)
+    out = torch.empty_like(q)
+    kw = {}
+    if vt:
+        pad = lambda n: (n + 7) // 8 * 8
+        vT = torch.full((B, inner, pad(nq)), float("nan"), device=dev(), dtype=dt)
+        vT[:, :, :nq] = v.transpose(1, 2)
+        vbT = torch.full((2, inner, pad(max(nk2, 1))), float("nan"), device=dev(), dtype=dt)
+        vbT[:, :, :max(nk2, 1)] = vb.transpose(1, 2)
+        vv, v_str = vT, (vT.stride(0), 0, vT.stride(1))
+        v2, v2_str = vbT, (vbT.stride(0), vbT.stride(1))
+    else:
+        vv, v_str = v, (nq * inner, 0, inner)
+        v2, v2_str = vb, (vb.stride(0), inner)
+    if nk2:
+        kw = dict(k2=kb, v2=v2, k2_str=(kb.stride(0), inner), v2_str=v2_str, k2_bdiv=frames, nk2=nk2,
+                  seg2_first_batch=frames)
+    hip.attention(q, k, vv, out, batch=B, heads=heads, hd=hd, nq=nq, nk=nq, scale=scale, q_str=(nq * inner, 0, inner),
+                  k_str=(nq * inner, 0, inner), v_str=v_str, o_str=(nq * inner, 0, inner), v_transposed=vt, **kw)
+    torch.testing.assert_close(out.double(), ref, **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("hd,frames,hw", [(40, 24, 16), (80, 8, 9), (160, 24, 4), (40, 32, 1)])
+def test_attention_temporal_layout(dt, hd, frames, hw):
+    """Sequences run over the frame axis of a ((b f), hw, C) token tensor: batch = (b, pixel), token stride hw*C."""
+    from mmgt_amd import hip
+    heads, b = 8, 2
+    C = heads * hd
+    qkv = rnd("qkv", (b * frames, hw, 3 * C), 1.0, dt)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    seq = lambda t: t.double().reshape(b, frames, hw, heads, hd).permute(0, 2, 3, 1, 4).reshape(b * hw, heads, frames, hd)
+    ref = _ref_attn(seq(q), seq(k), seq(v), hd ** -0.5)
+    ref = ref.reshape(b, hw, heads, frames, hd).permute(0, 3, 1, 2, 4).reshape(b * frames, hw, C)
+    out = torch.empty((b * frames, hw, C), device=dev(), dtype=dt)
+    st = (frames * hw * 3 * C, 3 * C, hw * 3 * C)
+    hip.attention(q, k, v, out, batch=b * hw, heads=heads, hd=hd, nq=frames, nk=frames, scale=hd ** -0.5, q_str=st,
+                  k_str=st, v_str=st, o_str=(frames * hw * C, C, hw * C), bdiv=hw)
+    torch.testing.assert_close(out.double(), ref, **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DT)
+def test_attention_cross_audio_24_heads(dt):
+    """MM-HAA: three cross-attention branches to 32 audio tokens run as one 24-head problem over fused projections."""
+    from mmgt_amd import hip
+    hd, nq, bf = 40, 64, 4
+    inner = 8 * hd
+    q3 = rnd("q3", (bf, nq, 3 * inner), 1.0, dt)
+    kv = rnd("kv", (bf, 32, 6 * inner), 1.0, dt)
+    out = torch.empty_like(q3)
+    hip.attention(q3, kv, kv[..., 3 * inner:], out, batch=bf, heads=24, hd=hd, nq=nq, nk=32, scale=hd ** -0.5,
+                  q_str=(nq * 3 * inner, 0, 3 * inner), k_str=(32 * 6 * inner, 0, 6 * inner),
+                  v_str=(32 * 6 * inner, 0, 6 * inner), o_str=(nq * 3 * inner, 0, 3 * inner))
+    sp = lambda t, n: t.double().reshape(bf, n, 24, hd).permute(0, 2, 1, 3)
+    ref = _ref_attn(sp(q3, nq), sp(kv[..., :3 * inner], 32), sp(kv[..., 3 * inner:], 32), hd ** -0.5)
+    torch.testing.assert_close(out.double(), ref.permute(0, 2, 1, 3).reshape(bf, nq, 3 * inner), **tol(dt))
+
+
+def test_softmax_rows_and_plumbing():
+    from mmgt_amd import hip
+    for dt in DT:
+        x = rnd("sm", (37, 1000), 3.0, dt)
+        torch.testing.assert_close(hip.softmax_rows(x, 0.3).double(), torch.softmax(x.double() * 0.3, -1), **tol(dt))
+        lat = rnd("lat", (2, 4, 3, 5, 5), 1.0)
+        nhwc = hip.ncfhw_to_nhwc(lat, 64, dt)
+        assert nhwc.shape == (6, 5, 5, 64) and nhwc[..., 4:].abs().max() == 0
+        torch.testing.assert_close(nhwc[..., :4].float(), lat.permute(0, 2, 3, 4, 1).reshape(6, 5, 5, 4).to(dt).float())
+        back = hip.nhwc_to_ncfhw(nhwc, 2, 4)
+        torch.testing.assert_close(back, lat.to(dt).float())
+        ts = torch.tensor([999.0, 3.0], device=dev())
+        tf = hip.timestep_features(ts, 320, dt)
+        fr = torch.exp(-math.log(10000.0) * torch.arange(160, device=dev()) / 160)
+        ref = torch.cat([torch.cos(ts[:, None] * fr), torch.sin(ts[:, None] * fr)], -1)
+        torch.testing.assert_close(tf.float(), ref, rtol=1e-3, atol=2e-3 if dt == torch.float32 else 1e-2)
+        torch.testing.assert_close(hip.silu(x).double(), F.silu(x.double()), **tol(dt))
+
+
+def test_cfg_ddim_and_window_accumulate():
+    from mmgt_amd import hip
+    Fr, C, hw = 6, 4, 3
+    lat = rnd("lat", (1, C, Fr, hw, hw), 1.0)
+    ps = torch.zeros((2, C, Fr, hw, hw), device=dev())
+    cnt = torch.zeros((Fr,), device=dev())
+    ref_ps = ps.clone()
+    ref_cnt = cnt.clone()
+    for wi, win in enumerate([[0, 1, 2, 3], [2, 3, 4, 5], [4, 5, 0, 1]]):
+        pred = rnd(f"pred{wi}", (2 * len(win), hw, hw, 64), 1.0, torch.bfloat16)
+        idx = torch.tensor(win, device=dev(), dtype=torch.int32)
+        hip.accumulate_window(pred, ps, cnt, idx, C)
+        p5 = pred[..., :C].float().reshape(2, len(win), hw, hw, C).permute(0, 4, 1, 2, 3)
+        ref_ps[:, :, win] += p5
+        ref_cnt[win] += 1
+    torch.testing.assert_close(ps, ref_ps)
+    torch.testing.assert_close(cnt, ref_cnt)
+    g, sa_t, sb_t, sa_p, sb_p = 3.5, 0.6, 0.8, 0.9, math.sqrt(1 - 0.81)
+    out = hip.cfg_ddim_step(ps, cnt, lat, g, sa_t, sb_t, sa_p, sb_p)
+    eps = ps / cnt[None, None, :, None, None]
+    v = eps[0:1] + g * (eps[1:2] - eps[0:1])
+    x0 = sa_t * lat - sb_t * v
+    e = sa_t * v + sb_t * lat
+    torch.testing.assert_close(out, sa_p * x0 + sb_p * e, rtol=1e-5, atol=1e-6)
+
+
+def test_errors_are_loud():
+    from mmgt_amd import hip
+    a = rnd("a", (8, 100), 1.0)
+    w = rnd("w", (8, 100), 1.0)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        hip.gemm(a, w)
+    with pytest.raises(RuntimeError):
+        hip.gemm(a.cpu(), w.cpu())
