@@ -1,0 +1,213 @@
+"""Pose2VideoPipeline on MI355X: windowed DDIM sampling around the HIP denoise-step operator.
+
+Host-side mirror of src/pipelines/pipeline_pose2vid_long.py:35-660 (used by scripts/pose2vid.py and scripts/audio2vid.py)
+and of the single-window src/pipelines/pipeline_pose2vid.py:284-506 (= context_frames >= video_length).  Same constructor
+and __call__ signature; the per-step tensor arithmetic (window accumulate, overlap average, CFG combine, DDIM update) runs
+in two HIP kernels on fp32 latents that never leave the GPU.
+
+Extensions through **kwargs (allowed by the reference signature, :365): `latents=` (inject initial noise, parity tests),
+`clip_image_embeds=` / `reference_banks=` / `pose_features=` (hand over prologue results when the corresponding module
+is None: the CLIP / ReferenceNet / VAE-encode prologue is a "next" row of SURVEY.md section 8f), `decode=False`.
+"""
+import math
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import hip
+from .context import get_context_scheduler
+
+
+@dataclass
+class Pose2VideoPipelineOutput:
+    videos: Union[torch.Tensor, np.ndarray]
+
+
+def _pil_to_tensor(img, width, height, normalize):
+    """VaeImageProcessor.preprocess for one PIL image: RGB, lanczos resize, /255, CHW, optional 2x-1 (App. B-6)."""
+    from PIL import Image
+    img = img.convert("RGB").resize((width, height), resample=Image.LANCZOS)
+    arr = torch.from_numpy(np.asarray(img).astype(np.float32) / 255.0).permute(2, 0, 1)
+    return arr * 2.0 - 1.0 if normalize else arr
+
+
+class Pose2VideoPipeline:
+    def __init__(self, vae, image_encoder, reference_unet, denoising_unet, pose_guider, scheduler,
+                 image_proj_model=None, tokenizer=None, text_encoder=None):
+        self.vae = vae
+        self.image_encoder = image_encoder
+        self.reference_unet = reference_unet
+        self.denoising_unet = denoising_unet
+        self.pose_guider = pose_guider
+        self.scheduler = scheduler
+        self.image_proj_model = image_proj_model
+        self.tokenizer = tokenizer
+        self.text_encoder = text_encoder
+        self.vae_scale_factor = 8          # 2 ** (len(vae.config.block_out_channels) - 1) for sd-vae-ft-mse
+
+    def to(self, device=None, dtype=None):
+        return self
+
+    @property
+    def device(self):
+        return self.denoising_unet.device
+
+    # --------------------------------------------------------------------------------------------- helpers
+    def prepare_latents(self, batch_size, num_channels_latents, width, height, video_length, dtype, device, generator,
+                        latents=None):
+        """pipeline_pose2vid_long.py:148-182; noise is drawn on the generator's device then moved (App. B-7)."""
+        shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor,
+                 width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(
+                f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            gdev = generator.device if isinstance(generator, torch.Generator) else torch.device("cpu")
+            latents = torch.randn(shape, generator=generator if isinstance(generator, torch.Generator) else None,
+                                  device=gdev, dtype=torch.float32)
+        latents = latents.to(device=device, dtype=torch.float32)
+        return (latents * self.scheduler.init_noise_sigma).contiguous()
+
+    def decode_latents(self, latents):
+        """pipeline_pose2vid_long.py:112-125: frame-by-frame VAE decode of z / 0.18215, (x/2+0.5).clamp(0,1), fp32 CPU."""
+        if self.vae is None:
+            raise RuntimeError("decode_latents needs a VAE (pass decode=False to get latents)")
+        video = self.vae.decode_video(latents)               # (b, 3, f, H, W) fp32 in [0, 1] on the GPU
+        return video.cpu().float().numpy()
+
+    def interpolate_latents(self, latents, interpolation_factor, device=None):
+        """pipeline_pose2vid_long.py:292-335 (no-op below factor 2)."""
+        if interpolation_factor < 2:
+            return latents
+        from .interp import get_tensor_interpolation_method
+        f = latents.shape[2]
+        new = torch.zeros((latents.shape[0], latents.shape[1], (f - 1) * interpolation_factor + 1, *latents.shape[3:]),
+                          device=latents.device, dtype=latents.dtype)
+        rate = [i / interpolation_factor for i in range(interpolation_factor)][1:]
+        idx = 0
+        v1 = None
+        for i0 in range(f - 1):
+            v0, v1 = latents[:, :, i0], latents[:, :, i0 + 1]
+            new[:, :, idx] = v0
+            idx += 1
+            for r in rate:
+                new[:, :, idx] = get_tensor_interpolation_method()(v0, v1, r)
+                idx += 1
+        new[:, :, idx] = v1
+        return new
+
+    # --------------------------------------------------------------------------------------------- the hot loop
+    def denoise(self, latents, timesteps, encoder_hidden_states, pose_fea, audio_tensor_pre, full_masks, face_masks,
+                lip_masks, guidance_scale, motion_scale, context_frames, context_stride, context_overlap,
+                context_schedule="uniform", num_inference_steps=None, callback=None, callback_steps=1):
+        """pipeline_pose2vid_long.py:494-643.  latents (1, C, L, h, w) fp32 on the GPU; returns the final latents."""
+        video_length = latents.shape[2]
+        dev = latents.device
+        sched = get_context_scheduler(context_schedule)
+        nsteps = num_inference_steps or len(timesteps)
+        # the reference passes step = 0 at every iteration, so the windows never move (:534-543)
+        windows = list(sched(0, nsteps, video_length, context_frames, context_stride, context_overlap))
+        win_idx = [torch.tensor(c, device=dev, dtype=torch.int32) for c in windows]
+        win_long = [torch.tensor(c, device=dev, dtype=torch.long) for c in windows]
+        # per-window conditioning is step-invariant: gather it once
+        cond = []
+        for c in win_long:
+            cond.append(dict(
+                pose=pose_fea[:, :, c].repeat(2, 1, 1, 1, 1).contiguous() if pose_fea is not None else None,
+                audio=audio_tensor_pre[:, c].contiguous(),
+                full=[t.view(2, video_length, -1)[:, c].reshape(-1, t.shape[-1]).contiguous() for t in full_masks],
+                face=[t.view(2, video_length, -1)[:, c].reshape(-1, t.shape[-1]).contiguous() for t in face_masks],
+                lips=[t.view(2, video_length, -1)[:, c].reshape(-1, t.shape[-1]).contiguous() for t in lip_masks]))
+        C = latents.shape[1]
+        for i, t in enumerate(timesteps):
+            pred_sum = torch.zeros((2,) + tuple(latents.shape[1:]), device=dev, dtype=torch.float32)
+            counter = torch.zeros((video_length,), device=dev, dtype=torch.float32)
+            for c_long, c_idx, cd in zip(win_long, win_idx, cond):
+                latent_in = self.scheduler.scale_model_input(latents[:, :, c_long].repeat(2, 1, 1, 1, 1), t)
+                pred = self.denoising_unet.denoise_window(
+                    latent_in, t, encoder_hidden_states=encoder_hidden_states, audio_embedding=cd["audio"],
+                    pose_cond_fea=cd["pose"], full_mask=cd["full"], face_mask=cd["face"], body_mask=cd["lips"],
+                    motion_scale=motion_scale)
+                hip.accumulate_window(pred, pred_sum, counter, c_idx, C)
+            sa_t, sb_t, sa_p, sb_p = self.scheduler.step_coefficients(t)
+            latents = hip.cfg_ddim_step(pred_sum, counter, latents, float(guidance_scale), sa_t, sb_t, sa_p, sb_p)
+            if callback is not None and i % callback_steps == 0:
+                callback(i, t, latents)
+        return latents
+
+    # --------------------------------------------------------------------------------------------- __call__
+    @torch.no_grad()
+    def __call__(self, ref_image, pose_images, audio_tensor, pixel_values_full_mask, pixel_values_face_mask,
+                 pixel_values_lip_mask, width, height, video_length, num_inference_steps, guidance_scale,
+                 num_images_per_prompt=1, eta: float = 0.0, motion_scale: Optional[List[float]] = None,
+                 generator=None, output_type: Optional[str] = "tensor", return_dict: bool = True,
+                 callback: Optional[Callable] = None, callback_steps: Optional[int] = 1, context_schedule="uniform",
+                 context_frames=12, context_stride=1, context_overlap=4, context_batch_size=1, interpolation_factor=1,
+                 **kwargs):
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0 is not used by the reference scripts")
+        if context_batch_size != 1:
+            raise NotImplementedError("the reference's window loop is only consistent for context_batch_size=1 (App. C-7)")
+        if not guidance_scale > 1.0:
+            raise NotImplementedError("classifier-free guidance is mandatory in the reference loop (App. C-7)")
+        unet = self.denoising_unet
+        dev = unet.device
+        self.scheduler.set_timesteps(num_inference_steps, device=None)
+        timesteps = self.scheduler.timesteps
+
+        # ---- prologue (once per clip) -------------------------------------------------------------------
+        clip_embeds = kwargs.get("clip_image_embeds")
+        if clip_embeds is None:
+            if self.image_encoder is None:
+                raise RuntimeError("no image_encoder: pass clip_image_embeds=(1, 768)")
+            from transformers import CLIPImageProcessor
+            clip_image = CLIPImageProcessor().preprocess(ref_image.resize((224, 224)), return_tensors="pt").pixel_values
+            clip_embeds = self.image_encoder(clip_image.to(dev, dtype=self.image_encoder.dtype)).image_embeds
+        ehs = clip_embeds.to(dev).float().reshape(1, 1, -1)
+        encoder_hidden_states = torch.cat([torch.zeros_like(ehs), ehs], dim=0)          # :388-394
+
+        banks = kwargs.get("reference_banks")
+        if banks is None:
+            if self.reference_unet is None:
+                raise RuntimeError("no reference_unet: pass reference_banks={prefix: (2, N, C)}")
+            ref_t = _pil_to_tensor(ref_image, width, height, True)[None].to(dev)
+            ref_latents = self.vae.encode_mean(ref_t) * 0.18215                          # :427-434
+            banks = self.reference_unet.write_banks(ref_latents.repeat(2, 1, 1, 1), 0, encoder_hidden_states)  # :510-520
+        unet.set_banks(banks)
+
+        latents = self.prepare_latents(num_images_per_prompt, unet.in_channels, width, height, video_length,
+                                       torch.float32, dev, generator, latents=kwargs.get("latents"))
+
+        pose_fea = kwargs.get("pose_features")
+        if pose_fea is None:
+            if torch.is_tensor(pose_images):
+                pose_t = pose_images.to(dev).float()
+            else:
+                pose_t = torch.stack([_pil_to_tensor(p, width, height, False) for p in pose_images], dim=1)[None].to(dev)
+            pose_fea = self.pose_guider(pose_t)                                           # :437-448
+        pose_fea = pose_fea.to(dev)
+
+        dup = lambda ms: [torch.cat([m.to(dev).float()] * 2) for m in ms]                 # :451-482
+        full_masks, face_masks, lip_masks = dup(pixel_values_full_mask), dup(pixel_values_face_mask), dup(pixel_values_lip_mask)
+        audio = audio_tensor.to(dev).float()
+        audio_pre = torch.cat([torch.zeros_like(audio), audio], dim=0)                    # :484-486
+
+        # ---- denoising loop ---------------------------------------------------------------------------------
+        latents = self.denoise(latents, timesteps, encoder_hidden_states, pose_fea, audio_pre, full_masks, face_masks,
+                               lip_masks, guidance_scale, motion_scale, context_frames, context_stride, context_overlap,
+                               context_schedule, num_inference_steps, callback, callback_steps)
+        unet.clear_banks()                                                                # :645-646
+
+        if interpolation_factor > 0:
+            latents = self.interpolate_latents(latents, interpolation_factor, dev)
+        if not kwargs.get("decode", True):
+            return Pose2VideoPipelineOutput(videos=latents) if return_dict else latents
+        images = self.decode_latents(latents)
+        if output_type == "tensor":
+            images = torch.from_numpy(images)
+        if not return_dict:
+            return images
+        return Pose2VideoPipelineOutput(videos=images)

@@ -523,11 +523,25 @@ class UNet3DConditionModel:
                 mask_cond_fea=None, pose_cond_fea=None, attention_mask=None, full_mask=None, face_mask=None,
                 body_mask=None, motion_scale=None, down_block_additional_residuals=None,
                 mid_block_additional_residual=None, return_dict: bool = True):
-        if not self._loaded:
-            raise RuntimeError("UNet3DConditionModel.forward before load_state_dict")
+        """UNet3DConditionModel.forward (unet_3d.py:425-625): (b, 4, f, h, w) in, (b, 4, f, h, w) out."""
         if attention_mask is not None or class_labels is not None or down_block_additional_residuals is not None \
                 or mid_block_additional_residual is not None:
             raise NotImplementedError("attention_mask / class_labels / additional residuals are not used on this path")
+        x = self.denoise_window(sample, timestep, encoder_hidden_states, audio_embedding, pose_cond_fea, full_mask,
+                                face_mask, body_mask, motion_scale)
+        out = hip.nhwc_to_ncfhw(x, sample.shape[0], self.out_channels).to(sample.dtype)
+        if not return_dict:
+            return (out,)
+        return UNet3DConditionOutput(sample=out)
+
+    __call__ = forward
+
+    def denoise_window(self, sample, timestep, encoder_hidden_states, audio_embedding=None, pose_cond_fea=None,
+                       full_mask=None, face_mask=None, body_mask=None, motion_scale=None):
+        """The operator body; returns the prediction channels-last ((b f), h, w, 64) with the first 4 channels valid
+        (what mmgt_accumulate_window consumes, so the sampler never converts layouts)."""
+        if not self._loaded:
+            raise RuntimeError("UNet3DConditionModel.forward before load_state_dict")
         if not sample.is_cuda:
             raise RuntimeError("mmgt_amd.UNet3DConditionModel runs on the GPU only (no CPU path exists)")
         b, cin, f, hh, ww = sample.shape
@@ -584,9 +598,4 @@ class UNet3DConditionModel:
 
         x = self._gn("conv_norm_out", x, self.config.norm_eps, silu=True)
         x = hip.conv3x3(x, self.w["conv_out.w"], self.w["conv_out.bias"])
-        out = hip.nhwc_to_ncfhw(x, b, self.out_channels).to(sample.dtype)
-        if not return_dict:
-            return (out,)
-        return UNet3DConditionOutput(sample=out)
-
-    __call__ = forward
+        return x
