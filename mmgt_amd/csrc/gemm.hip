@@ -7,23 +7,33 @@
 // the input, optional second source tensor = fused channel concat of the UNet skip connection).  K ordering of the conv
 // view is (ky, kx, cin) with cin fastest, matching weights pre-packed as [Cout][3][3][Cin].
 //
-// Tile: 128 x 128 per 256-thread workgroup (4 waves as 2 x 2, 64 x 64 per wave = 2 x 2 MFMA 32x32 tiles), K chunk of
-// 128 bytes per row (64 bf16 / 32 fp32), register-staged global -> LDS double buffering with one barrier per chunk,
-// LDS rows padded to 144 B so the ds_read_b128 fragment reads are bank-conflict free.
+// Structure (one template over storage type, A view and tile shape):
+//  * BM x BN tile per 256-thread workgroup (4 waves), K chunks of 128 bytes per row (64 bf16 / 32 fp32).
+//  * Both operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging registers): LDS rows are exactly
+//    128 B and lane-linear per wave instruction, so bank conflicts are removed by an XOR swizzle of the 16-byte chunk
+//    index applied on the per-lane SOURCE address and again on the fragment read (chunk ^ ((row >> 1) & 7): the sixteen
+//    lanes of every ds_read_b128 group hit sixteen distinct 16-byte slots).  Conv zero padding = the lane's source is a
+//    zero page.
+//  * NSTAGE-deep LDS ring, one raw s_barrier per chunk, counted s_waitcnt vmcnt so NSTAGE-2 chunks stay in flight
+//    across the barrier.
+//  * Epilogue through LDS: accumulators are transposed to row-major so that every lane loads/stores 8 consecutive
+//    columns (16 B bf16): bias, per-batch bias, SiLU / GEGLU, row scale, alpha, residual, store.
+//  * XCD-aware tile order (n fastest inside an XCD's contiguous run) so the tiles sharing an A row panel hit one L2.
+#include <string.h>
+
 #include "common.h"
 #include "mmgt_hip.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128;
-constexpr int ROWB = 128;          // bytes of K per tile row
-constexpr int LSTR = ROWB + 16;    // LDS row stride in bytes
-constexpr int TILE_BYTES = BM * LSTR;
+constexpr int ROWB = 128;  // bytes of K per tile row per chunk
+
+__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
 
 struct ADesc {
   const char* src0;
   const char* src1;
-  long ld0, ld1;      // dense: row stride (elements); conv: channels per pixel of each source
+  long ld0;           // dense: row stride (elements)
   long bs0, bs1;      // batch (grid.z) stride in elements
   int C0, C1;         // conv: channels of the two sources (Cin = C0 + C1)
   int IH, IW, OH, OW; // conv: stored input dims and output dims
@@ -40,20 +50,32 @@ struct Epi {
   int bias2_rows;
   float alpha;
   int act;                 // 0 none, 1 GEGLU (packed weights, out has N/2 columns), 2 SiLU
+  int fast;                // 1: N % 8 == 0 and every row / pointer 16-byte aligned -> vectorised epilogue
 };
 
-template <typename T, int MODE>  // MODE 0 dense, 1 conv3x3
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// MODE 0 dense, 1 conv3x3.  WM x WN waves (WM * WN == 4).
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(256) void gemm_kernel(ADesc ad, const char* __restrict__ W, long bsw, Epi ep, int M, int N,
                                                    int K, int tiles_m, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr int ESZ = sizeof(T);
-  constexpr int BK = ROWB / ESZ;        // elements per chunk
-  constexpr int KS = BK / 16;           // MFMA K-steps per chunk
-  auto lA = [&](int buf) -> char* { return smem + buf * 2 * TILE_BYTES; };
-  auto lB = [&](int buf) -> char* { return smem + buf * 2 * TILE_BYTES + TILE_BYTES; };
+  constexpr int BK = ROWB / ESZ;                 // elements per chunk
+  constexpr int KS = BK / 16;                    // MFMA K-steps per chunk
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int GA = BM / 8 / 4, GB = BN / 8 / 4;   // 8-row LDS-DMA groups per wave for A and B
+  static_assert(WM * WN == 4 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile");
 
-  // XCD-aware tile order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs; give each XCD a
-  // contiguous run of logical tiles (n fastest) so the tiles sharing an A row panel hit one L2.
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
   {
@@ -63,48 +85,54 @@ __global__ __launch_bounds__(256) void gemm_kernel(ADesc ad, const char* __restr
   const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int bz = blockIdx.z;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
   const int lr = lane & 31, lh = lane >> 5;
 
-  // ---- per-thread staging assignment: 4 rows (tid/8 + 32 i), one 16-byte column (tid % 8) ----
-  const int vcol = tid & 7;
-  const int srow = tid >> 3;
+  // ---- LDS-DMA source addressing: wave `wid` fills 8-row groups g = wid * GA + i; lane -> (row l>>3, slot l&7) ----
+  const int srow = lane >> 3, spos = lane & 7;
   const T* a0 = reinterpret_cast<const T*>(ad.src0) + (long)bz * ad.bs0;
   const T* a1 = ad.src1 ? reinterpret_cast<const T*>(ad.src1) + (long)bz * ad.bs1 : nullptr;
   const T* wbase = reinterpret_cast<const T*>(W) + (long)bz * bsw;
 
-  long arow_off[4];   // dense: element offset of the row; conv: unused
-  int cn[4], coy[4], cox[4];
-  bool arow_ok[4];
-  const T* wrow[4];
+  const char* aptr[GA];      // dense: pointer to (row, swizzled chunk) at k = 0
+  int cn[GA], coy[GA], cox[GA], achunk[GA];
+  const char* wptr[GB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = tm * BM + srow + 32 * i;
-    arow_ok[i] = m < M;
+  for (int i = 0; i < GA; ++i) {
+    const int row = (wid * GA + i) * 8 + srow;
+    const int chunk = spos ^ ((row >> 1) & 7);
+    int m = tm * BM + row;
     if (m >= M) m = M - 1;
     if (MODE == 0) {
-      arow_off[i] = (long)m * ad.ld0;
+      aptr[i] = reinterpret_cast<const char*>(a0 + (long)m * ad.ld0) + chunk * 16;
     } else {
       const int hw = ad.OH * ad.OW;
       cn[i] = m / hw;
       const int rem = m - cn[i] * hw;
       coy[i] = rem / ad.OW;
       cox[i] = rem - coy[i] * ad.OW;
+      achunk[i] = chunk * 16;
     }
-    int n = tn * BN + srow + 32 * i;
+  }
+#pragma unroll
+  for (int i = 0; i < GB; ++i) {
+    const int row = (wid * GB + i) * 8 + srow;
+    const int chunk = spos ^ ((row >> 1) & 7);
+    int n = tn * BN + row;
     if (n >= N) n = N - 1;
-    wrow[i] = wbase + (long)n * K;
+    wptr[i] = reinterpret_cast<const char*>(wbase + (long)n * K) + chunk * 16;
   }
 
-  u32x4 ra[4], rb[4];
-  auto load_chunk = [&](int kc) {  // kc: element offset into K
+  auto issue = [&](int ch) {  // chunk index -> LDS stage ch % NSTAGE
+    char* st = smem + (ch % NSTAGE) * STAGE_BYTES;
+    const long kb = (long)ch * ROWB;   // byte offset along K
     if (MODE == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        ra[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(a0 + arow_off[i] + kc) + vcol * 16);
+      for (int i = 0; i < GA; ++i) glds16(aptr[i] + kb, st + (wid * GA + i) * 1024);
     } else {
       const int cin = ad.C0 + ad.C1;
+      const int kc = ch * BK;
       const int tap = kc / cin;
       const int c = kc - tap * cin;
       const int ky = tap / 3, kx = tap - ky * 3;
@@ -114,119 +142,239 @@ __global__ __launch_bounds__(256) void gemm_kernel(ADesc ad, const char* __restr
       const long cpp = second ? ad.C1 : ad.C0;
       const int cc = second ? c - ad.C0 : c;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < GA; ++i) {
         const int iy = coy[i] * ad.stride + ky - 1, ix = cox[i] * ad.stride + kx - 1;
         const bool ok = iy >= 0 && iy < vh && ix >= 0 && ix < vw;
         const int sy = ad.up ? iy >> 1 : iy, sx = ad.up ? ix >> 1 : ix;
-        u32x4 v = (u32x4)(0u);
-        if (ok) {
-          const T* p = base + (((long)cn[i] * ad.IH + sy) * ad.IW + sx) * cpp + cc;
-          v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p) + vcol * 16);
-        }
-        ra[i] = v;
+        const char* p = reinterpret_cast<const char*>(base + (((long)cn[i] * ad.IH + sy) * ad.IW + sx) * cpp + cc) +
+                        achunk[i];
+        if (!ok) p = reinterpret_cast<const char*>(g_zero_page) + spos * 16;
+        glds16(p, st + (wid * GA + i) * 1024);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      rb[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(wrow[i] + kc) + vcol * 16);
-  };
-  auto store_chunk = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int off = (srow + 32 * i) * LSTR + vcol * 16;
-      *reinterpret_cast<u32x4*>(lA(buf) + off) = ra[i];
-      *reinterpret_cast<u32x4*>(lB(buf) + off) = rb[i];
-    }
+    for (int i = 0; i < GB; ++i) glds16(wptr[i] + kb, st + A_BYTES + (wid * GB + i) * 1024);
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16)(0.f);
+
+  // fragment read addressing: row r of the tile, 16-byte chunk c  ->  r * 128 + ((c ^ ((r >> 1) & 7)) * 16)
+  const int arow = wm * (BM / WM) + lr, brow = wn * (BN / WN) + lr;   // + 32 * tile index (keeps (row>>1)&7 pattern)
 
   const int nchunks = K / BK;
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nchunks) issue(s);
+
   for (int ch = 0; ch < nchunks; ++ch) {
-    const int cur = ch & 1;
-    if (ch + 1 < nchunks) load_chunk((ch + 1) * BK);
-    const char* pa = lA(cur) + (wm * 64 + lr) * LSTR + lh * 8 * ESZ;
-    const char* pb = lB(cur) + (wn * 64 + lr) * LSTR + lh * 8 * ESZ;
+    // chunk ch must have landed; chunks ch+1 .. ch+NSTAGE-2 may stay in flight (each is GA + GB LDS-DMA ops per wave)
+    if (NSTAGE == 2 || ch + 1 >= nchunks) wait_vmcnt<0>();
+    else if (NSTAGE == 3 || ch + 2 >= nchunks) wait_vmcnt<(GA + GB)>();
+    else wait_vmcnt<2 * (GA + GB)>();
+    __builtin_amdgcn_s_barrier();
+    if (ch + NSTAGE - 1 < nchunks) issue(ch + NSTAGE - 1);
+
+    const char* st = smem + (ch % NSTAGE) * STAGE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      Frag<T> fa[2], fb[2];
+      Frag<T> fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        frag_load(fa[i], reinterpret_cast<const T*>(pa + i * 32 * LSTR + ks * 16 * ESZ));
-        frag_load(fb[i], reinterpret_cast<const T*>(pb + i * 32 * LSTR + ks * 16 * ESZ));
+      for (int i = 0; i < TM; ++i) {
+        const int r = arow + 32 * i;
+        const int sw = (r >> 1) & 7;
+        if (ESZ == 2) {
+          frag_load(fa[i], reinterpret_cast<const T*>(st + r * ROWB + (((2 * ks + lh) ^ sw) << 4)));
+        } else {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * ROWB + (((4 * ks + 2 * lh) ^ sw) << 4));
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * ROWB + (((4 * ks + 2 * lh + 1) ^ sw) << 4));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { fa[i].set(j, lo[j]); fa[i].set(4 + j, hi[j]); }
+        }
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < TN; ++j) {
+        const int r = brow + 32 * j;
+        const int sw = (r >> 1) & 7;
+        const char* sb = st + A_BYTES;
+        if (ESZ == 2) {
+          frag_load(fb[j], reinterpret_cast<const T*>(sb + r * ROWB + (((2 * ks + lh) ^ sw) << 4)));
+        } else {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(sb + r * ROWB + (((4 * ks + 2 * lh) ^ sw) << 4));
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(sb + r * ROWB + (((4 * ks + 2 * lh + 1) ^ sw) << 4));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma32(acc[i][j], fa[i], fb[j]);
+          for (int jj = 0; jj < 4; ++jj) { fb[j].set(jj, lo[jj]); fb[j].set(4 + jj, hi[jj]); }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma32(acc[i][j], fa[i], fb[j]);
     }
-    if (ch + 1 < nchunks) store_chunk(cur ^ 1);
-    __syncthreads();
   }
 
-  // ---- epilogue ----
+  // ---- epilogue: per wave, 32 rows at a time through LDS (row-major fp32, 4-float pad), then 8-column vectors ----
+  __syncthreads();   // every wave is done with the operand stages
+  constexpr int WCOLS = 32 * TN;
+  constexpr int ESTR = WCOLS + 4;
+  float* ebuf = reinterpret_cast<float*>(smem) + wid * 32 * ESTR;
   T* out = reinterpret_cast<T*>(ep.out) + (long)bz * ep.bso;
   const T* res = ep.residual ? reinterpret_cast<const T*>(ep.residual) + (long)bz * ep.bsr : nullptr;
-  const int row0 = tm * BM + wm * 64, col0 = tn * BN + wn * 64;
-  if (ep.act == 1) {
-    // GEGLU: MFMA column tile 0 = h, tile 1 = gate of the same 32 output channels (weights packed by the host).
-    const int n = col0 + lr;               // packed column of h
-    const int ocol = (col0 >> 1) + lr;     // output column
-    const bool cok = (col0 + 32 + lr) < N;
-    const float bh = (ep.bias && cok) ? ep.bias[n] : 0.f;
-    const float bg = (ep.bias && cok) ? ep.bias[n + 32] : 0.f;
+  const int row0 = tm * BM + wm * (BM / WM), col0 = tn * BN + wn * (BN / WN);
+  const bool geglu = ep.act == 1;
+  constexpr int VPR = (32 * TN) / 8;                 // 8-column vectors per row
+  const float* zero = reinterpret_cast<const float*>(g_zero_page);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = row0 + i * 32 + acc_row(r, lane);
-        if (m < M && cok) {
-          float v = (acc[i][0][r] + bh) * gelu_erf_f(acc[i][1][r] + bg);
-          if (res) v += Elem<T>::ld(res + (long)m * ep.ldr + ocol);
-          Elem<T>::st(out + (long)m * ep.ldo + ocol, v);
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ebuf[acc_row(r, lane) * ESTR + j * 32 + lr] = acc[i][j][r];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int nvec = geglu ? 32 * (VPR / 2) : 32 * VPR;
+    for (int v = lane; v < nvec; v += 64) {
+      int rr, hcol, ncol;      // row in the 32-row slab, column of the (h) vector inside the wave tile, global column
+      long ocol;
+      if (geglu) {             // columns [0,32) of every 64 = h, [32,64) = gate of the same 32 output channels
+        const int per = VPR / 2;
+        rr = v / per;
+        const int g = v - rr * per;
+        const int blk = g >> 2, c8 = (g & 3) * 8;
+        hcol = blk * 64 + c8;
+        ncol = col0 + hcol;
+        ocol = (long)((col0 + blk * 64) >> 1) + c8;
+      } else {
+        rr = v / VPR;
+        hcol = (v - rr * VPR) * 8;
+        ncol = col0 + hcol;
+        ocol = ncol;
+      }
+      const int m = row0 + i * 32 + rr;
+      if (m >= M || ncol >= N) continue;
+      const float* hp = ebuf + rr * ESTR + hcol;
+      float o8[8];
+      {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(hp), x1 = *reinterpret_cast<const f32x4*>(hp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o8[e] = x0[e]; o8[4 + e] = x1[e]; }
+      }
+      if (ep.fast) {
+        // branch-free vector path: absent operands read a zero page
+        const float* bp = ep.bias ? ep.bias + ncol : zero;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o8[e] += b0[e]; o8[4 + e] += b1[e]; }
+        if (geglu) {
+          const float* gp = ep.bias ? ep.bias + ncol + 32 : zero;
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+          const f32x4 y0 = *reinterpret_cast<const f32x4*>(hp + 32), y1 = *reinterpret_cast<const f32x4*>(hp + 36);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o8[e] *= gelu_erf_f(y0[e] + g0[e]);
+            o8[4 + e] *= gelu_erf_f(y1[e] + g1[e]);
+          }
+        } else {
+          const float* b2p = ep.bias2 ? ep.bias2 + (long)(m / ep.bias2_rows) * N + ncol : zero;
+          const f32x4 c0 = *reinterpret_cast<const f32x4*>(b2p), c1 = *reinterpret_cast<const f32x4*>(b2p + 4);
+          const float rs = (ep.row_scale ? ep.row_scale[m] : 1.f) * ep.alpha;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o8[e] += c0[e]; o8[4 + e] += c1[e]; }
+          if (ep.act == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] = silu_f(o8[e]);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] *= rs;
+        }
+        T* op = out + (long)m * ep.ldo + ocol;
+        if (ESZ == 2) {
+          union { u32x4 u; bf16_t e[8]; } rv;
+          rv.u = *reinterpret_cast<const u32x4*>(res ? reinterpret_cast<const char*>(res + (long)m * ep.ldr + ocol)
+                                                     : reinterpret_cast<const char*>(zero));
+          union { bf16_t e[8]; u32x4 u; } pk;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pk.e[e] = f32_to_bf16(o8[e] + bf16_to_f32(rv.e[e]));
+          *reinterpret_cast<u32x4*>(op) = pk.u;
+        } else {
+          const float* rp = res ? reinterpret_cast<const float*>(res) + (long)m * ep.ldr + ocol : zero;
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+          *reinterpret_cast<f32x4*>(op) = (f32x4){o8[0] + r0[0], o8[1] + r0[1], o8[2] + r0[2], o8[3] + r0[3]};
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(op) + 4) =
+              (f32x4){o8[4] + r1[0], o8[5] + r1[1], o8[6] + r1[2], o8[7] + r1[3]};
+        }
+      } else {
+        // generic scalar path (ragged N or unaligned rows)
+        for (int e = 0; e < 8 && ncol + e < N; ++e) {
+          float x = o8[e];
+          if (ep.bias) x += ep.bias[ncol + e];
+          if (geglu) {
+            float gte = hp[32 + e];
+            if (ep.bias) gte += ep.bias[ncol + 32 + e];
+            x *= gelu_erf_f(gte);
+          } else {
+            if (ep.bias2) x += ep.bias2[(long)(m / ep.bias2_rows) * N + ncol + e];
+            if (ep.act == 2) x = silu_f(x);
+            x *= (ep.row_scale ? ep.row_scale[m] : 1.f) * ep.alpha;
+          }
+          if (res) x += Elem<T>::ld(res + (long)m * ep.ldr + ocol + e);
+          Elem<T>::st(out + (long)m * ep.ldo + ocol + e, x);
         }
       }
-    return;
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = col0 + j * 32 + lr;
-    const bool cok = n < N;
-    const float b = (ep.bias && cok) ? ep.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = row0 + i * 32 + acc_row(r, lane);
-        if (m < M && cok) {
-          float v = acc[i][j][r] + b;
-          if (ep.bias2) v += ep.bias2[(long)(m / ep.bias2_rows) * N + n];
-          if (ep.act == 2) v = silu_f(v);
-          if (ep.row_scale) v *= ep.row_scale[m];
-          v *= ep.alpha;
-          if (res) v += Elem<T>::ld(res + (long)m * ep.ldr + n);
-          Elem<T>::st(out + (long)m * ep.ldo + n, v);
-        }
-      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
 
-template <typename T, int MODE>
-int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE>
+int launch_cfg(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   dim3 grid(tiles_m * tiles_n, 1, batch);
-  const size_t lds = 4 * TILE_BYTES;
-  hipLaunchKernelGGL((gemm_kernel<T, MODE>), grid, dim3(256), lds, s, ad, reinterpret_cast<const char*>(W), bsw, ep, M, N,
-                     K, tiles_m, tiles_n);
+  constexpr int TN = BN / WN / 32;
+  const size_t stage = (size_t)NSTAGE * (BM + BN) * ROWB;
+  const size_t epi = (size_t)4 * 32 * (32 * TN + 4) * 4;
+  const size_t lds = stage > epi ? stage : epi;
+  auto kern = gemm_kernel<T, MODE, BM, BN, WM, WN, NSTAGE>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, ad, reinterpret_cast<const char*>(W), bsw, ep, M, N, K, tiles_m,
+                     tiles_n);
   MMGT_LAUNCH_CHECK();
   return 0;
+}
+
+int g_gemm_cfg = 0;   // 0 = heuristic; 1..5 force a tile configuration (mmgt_tune("gemm_cfg", v), benchmarking only)
+
+template <typename T, int MODE>
+int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
+  // Tile choice: 128 x 128 with a 3-deep ring for compute-bound shapes; for short reductions (the HBM-bound L0/L1
+  // projections) smaller tiles with several resident workgroups per CU keep more loads in flight.
+  const bool geglu = ep.act == 1;
+  int cfg = g_gemm_cfg;
+  if (cfg == 0) cfg = (!geglu && MODE == 0 && K <= 640) ? 3 : 2;
+  if (geglu && cfg > 2) cfg = 2;
+  switch (cfg) {
+    case 1: return launch_cfg<T, MODE, 128, 128, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
+    case 2: return launch_cfg<T, MODE, 128, 128, 2, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
+    case 3: return launch_cfg<T, MODE, 128, 64, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
+    case 4: return launch_cfg<T, MODE, 128, 64, 2, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
+    default: return launch_cfg<T, MODE, 64, 64, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
+  }
+}
+
+int epi_fast(const Epi& ep, int N, int n_out, int esz) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  bool ok = N % 8 == 0 && n_out % 8 == 0 && al16(ep.out) && (ep.ldo * esz) % 16 == 0 && (ep.bso * esz) % 16 == 0;
+  ok = ok && al16(ep.bias) && al16(ep.bias2);
+  if (ep.residual) ok = ok && al16(ep.residual) && (ep.ldr * esz) % 16 == 0 && (ep.bsr * esz) % 16 == 0;
+  return ok ? 1 : 0;
 }
 
 int check_common(int dtype, int M, int N, int K, int act) {
@@ -240,6 +388,12 @@ int check_common(int dtype, int M, int N, int K, int act) {
 
 }  // namespace
 
+extern "C" int mmgt_tune(const char* key, int value) {
+  if (key && !strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return 0; }
+  mmgt_set_error("tune: unknown key");
+  return 1;
+}
+
 extern "C" int mmgt_gemm(const void* A, long lda, const void* W, const float* bias, const float* bias2, int bias2_rows,
                          const float* row_scale, float alpha, const void* residual, long ldr, void* out, long ldo, int M,
                          int N, int K, int act, int batch, long bsA, long bsW, long bsR, long bsO, int dtype,
@@ -249,7 +403,8 @@ extern "C" int mmgt_gemm(const void* A, long lda, const void* W, const float* bi
   MMGT_CHECK(lda >= K && batch >= 1, "gemm: lda %ld < K %d or batch %d < 1", lda, K, batch);
   MMGT_CHECK(!bias2 || bias2_rows > 0, "gemm: bias2_rows must be positive");
   const int esz = dtype == MMGT_BF16 ? 2 : 4;
-  MMGT_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && (lda * esz) % 16 == 0,
+  MMGT_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && (lda * esz) % 16 == 0 && (bsA * esz) % 16 == 0 &&
+                 (bsW * esz) % 16 == 0,
              "gemm: A/W must be 16-byte aligned with 16-byte aligned rows");
   ADesc ad{};
   ad.src0 = (const char*)A;
@@ -259,6 +414,7 @@ extern "C" int mmgt_gemm(const void* A, long lda, const void* W, const float* bi
   ep.bias = bias; ep.bias2 = bias2; ep.bias2_rows = bias2_rows; ep.row_scale = row_scale; ep.alpha = alpha;
   ep.residual = (const char*)residual; ep.ldr = ldr; ep.out = (char*)out; ep.ldo = ldo; ep.act = act;
   ep.bsr = bsR; ep.bso = bsO;
+  ep.fast = epi_fast(ep, N, act == 1 ? N / 2 : N, esz);
   hipStream_t s = (hipStream_t)stream;
   return dtype == MMGT_BF16 ? launch<bf16_t, 0>(ad, W, bsW, ep, M, N, K, batch, s)
                             : launch<float, 0>(ad, W, bsW, ep, M, N, K, batch, s);
@@ -273,6 +429,8 @@ extern "C" int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1,
   MMGT_CHECK(C0 % 64 == 0 && C1 % 64 == 0 && (x1 != nullptr) == (C1 > 0),
              "conv3x3: channel counts must be multiples of 64 (C0=%d C1=%d)", C0, C1);
   MMGT_CHECK(act == 0 || act == 2, "conv3x3: act %d unsupported", act);
+  MMGT_CHECK(((uintptr_t)x0 % 16) == 0 && ((uintptr_t)x1 % 16) == 0 && ((uintptr_t)Wp % 16) == 0,
+             "conv3x3: pointers must be 16-byte aligned");
   const int VH = upsample ? IH * 2 : IH, VW = upsample ? IW * 2 : IW;
   const int OH = (VH + 2 - 3) / stride + 1, OW = (VW + 2 - 3) / stride + 1;
   const long M = (long)NB * OH * OW;
@@ -285,6 +443,7 @@ extern "C" int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1,
   Epi ep{};
   ep.bias = bias; ep.bias2 = bias2; ep.bias2_rows = bias2_rows; ep.alpha = 1.f; ep.residual = (const char*)residual;
   ep.ldr = Cout; ep.out = (char*)out; ep.ldo = Cout; ep.act = act;
+  ep.fast = epi_fast(ep, Cout, Cout, dtype == MMGT_BF16 ? 2 : 4);
   hipStream_t s = (hipStream_t)stream;
   return dtype == MMGT_BF16 ? launch<bf16_t, 1>(ad, Wp, 0, ep, (int)M, Cout, K, 1, s)
                             : launch<float, 1>(ad, Wp, 0, ep, (int)M, Cout, K, 1, s);

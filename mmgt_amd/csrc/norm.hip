@@ -9,7 +9,9 @@ namespace {
 constexpr int GN_MAXC = 2560;
 
 __host__ __device__ inline int gn_chunks(int HW) {
-  int c = (HW + 127) / 128;
+  // >= 128 rows per workgroup on large images (amortises the per-workgroup scale/shift table), 32 on small ones so that
+  // the grid still fills the chip
+  int c = HW >= 2048 ? (HW + 127) / 128 : (HW + 31) / 32;
   return c < 1 ? 1 : (c > 256 ? 256 : c);
 }
 
@@ -149,47 +151,57 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
   }
 }
 
-// ---- LayerNorm: one wave per row, row held in registers, exact two-pass statistics ----
+// ---- LayerNorm: LPR lanes per row (8 .. 64, so all 64 lanes stream 16-byte vectors even at C = 320), the row slice in
+// registers, exact two-pass statistics, reductions by xor-shuffles inside the LPR-lane group ----
 template <typename T>
 __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
                                                  const float* __restrict__ beta, float eps, const float* __restrict__ pe,
-                                                 int pe_div, int pe_mod, T* __restrict__ out, long ldo, int rows, int C) {
+                                                 int pe_div, int pe_mod, T* __restrict__ out, long ldo, int rows, int C,
+                                                 int lpr, int vpl) {
   constexpr int VEC = VecIO<T>::VEC;
-  constexpr int MAXS = 1280 / (VEC * 64) + 1;
+  constexpr int MAXV = 5;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const long row = (long)blockIdx.x * 4 + wid;
-  if (row >= rows) return;
-  const int nvec = C / VEC;
-  float f[MAXS][VEC];
+  const int rpw = 64 / lpr;                       // rows per wave
+  const int sub = lane / lpr, li = lane - sub * lpr;
+  const long row = ((long)blockIdx.x * 4 + wid) * rpw + sub;
+  const bool ok = row < rows;
+  const long rrow = ok ? row : rows - 1;
+  float f[MAXV][VEC];
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXS; ++i) {
-    const int vc = lane + 64 * i;
-    if (vc < nvec) {
-      VecIO<T>::load(x + row * ldx + vc * VEC, f[i]);
+  for (int i = 0; i < MAXV; ++i) {
+    if (i < vpl) {
+      VecIO<T>::load(x + rrow * ldx + (li + lpr * i) * VEC, f[i]);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) sum += f[i][e];
     }
   }
-  const float mean = wave_sum(sum) / (float)C;
+  for (int o = lpr >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)C;
   float sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXS; ++i) {
-    const int vc = lane + 64 * i;
-    if (vc < nvec)
+  for (int i = 0; i < MAXV; ++i) {
+    if (i < vpl)
 #pragma unroll
       for (int e = 0; e < VEC; ++e) { const float d = f[i][e] - mean; sq += d * d; }
   }
-  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  for (int o = lpr >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = rsqrtf(sq / (float)C + eps);
+  if (!ok) return;
   const float* perow = pe ? pe + (long)((row / pe_div) % pe_mod) * C : nullptr;
 #pragma unroll
-  for (int i = 0; i < MAXS; ++i) {
-    const int vc = lane + 64 * i;
-    if (vc < nvec) {
-      const int c = vc * VEC;
+  for (int i = 0; i < MAXV; ++i) {
+    if (i < vpl) {
+      const int c = (li + lpr * i) * VEC;
+      float g[VEC], b[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; e += 4) {
+        *reinterpret_cast<f32x4*>(&g[e]) = *reinterpret_cast<const f32x4*>(gamma + c + e);
+        *reinterpret_cast<f32x4*>(&b[e]) = *reinterpret_cast<const f32x4*>(beta + c + e);
+      }
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        float v = (f[i][e] - mean) * rstd * gamma[c + e] + beta[c + e];
+        float v = (f[i][e] - mean) * rstd * g[e] + b[e];
         if (perow) v += perow[c + e];
         f[i][e] = v;
       }
@@ -235,17 +247,24 @@ extern "C" int mmgt_layernorm(const void* x, long ldx, const float* gamma, const
   MMGT_CHECK(x && gamma && beta && out, "layernorm: null pointer");
   MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "layernorm: bad dtype %d", dtype);
   const int vec = dtype == MMGT_BF16 ? 8 : 4;
-  MMGT_CHECK(C > 0 && C <= 1280 && C % vec == 0 && ldx % vec == 0 && ldo % vec == 0, "layernorm: unsupported C=%d", C);
+  MMGT_CHECK(C > 0 && C % vec == 0 && ldx % vec == 0 && ldo % vec == 0, "layernorm: unsupported C=%d", C);
   MMGT_CHECK(rows > 0, "layernorm: no rows");
   MMGT_CHECK(!pe || (pe_div > 0 && pe_mod > 0), "layernorm: bad pe_div/pe_mod");
-  dim3 grid((rows + 3) / 4);
+  MMGT_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
+                 ((uintptr_t)beta % 16) == 0, "layernorm: pointers must be 16-byte aligned");
+  const int nvec = C / vec;
+  int lpr = 8;
+  while (lpr < 64 && (nvec % lpr != 0 || nvec / lpr > 5)) lpr <<= 1;
+  MMGT_CHECK(nvec % lpr == 0 && nvec / lpr <= 5, "layernorm: C=%d does not map onto 8..64 lanes x <=5 vectors", C);
+  const int vpl = nvec / lpr, rows_per_block = 4 * (64 / lpr);
+  dim3 grid((rows + rows_per_block - 1) / rows_per_block);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MMGT_BF16)
     hipLaunchKernelGGL(ln_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, gamma, beta, eps, pe, pe_div,
-                       pe_mod, (bf16_t*)out, ldo, rows, C);
+                       pe_mod, (bf16_t*)out, ldo, rows, C, lpr, vpl);
   else
     hipLaunchKernelGGL(ln_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, gamma, beta, eps, pe, pe_div, pe_mod,
-                       (float*)out, ldo, rows, C);
+                       (float*)out, ldo, rows, C, lpr, vpl);
   MMGT_LAUNCH_CHECK();
   return 0;
 }

@@ -20,6 +20,7 @@ _lib = None
 _SIGS = {
     "mmgt_abi_version": (c_int, []),
     "mmgt_last_error": (ctypes.c_char_p, []),
+    "mmgt_tune": (c_int, [ctypes.c_char_p, c_int]),
     "mmgt_gemm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_long,
                           c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_int,
                           c_void_p]),
@@ -67,6 +68,10 @@ def lib():
 def _check(rc, what):
     if rc != 0:
         raise RuntimeError(f"{what} failed (rc={rc}): {lib().mmgt_last_error().decode()}")
+
+
+def tune(key, value):
+    _check(lib().mmgt_tune(key.encode(), int(value)), "mmgt_tune")
 
 
 def dtype_code(dt):

@@ -13,6 +13,7 @@ from mmgt_amd.packing import pack_geglu  # noqa: E402
 
 dev = torch.device("cuda:0")
 DT = torch.bfloat16
+CFGS = [int(c) for c in os.environ.get("CFGS", "0").split(",")]
 
 
 def timeit(fn, reps=5, warm=2):
@@ -48,9 +49,14 @@ def bench_gemm():
         if epi == "geglu":
             w, bias = pack_geglu(w, bias)
         fn = lambda: hip.gemm(a, w, bias, out=out, residual=res, act=hip.ACT_GEGLU if epi == "geglu" else 0)
-        t = timeit(fn)
         byt = 2 * (M * K + N * K + M * nout * (2 if res is not None else 1))
-        print(f"M={M:7d} N={N:6d} K={K:5d} {epi:6s} {t*1e6:9.1f} us  {2*M*N*K/t/1e12:7.1f} TF/s  {byt/t/1e9:7.0f} GB/s(algorithmic)")
+        cells = []
+        for cfg in CFGS:
+            hip.tune("gemm_cfg", cfg)
+            t = timeit(fn)
+            cells.append(f"cfg{cfg}: {t*1e6:7.1f}us {2*M*N*K/t/1e12:6.1f}TF {byt/t/1e9:5.0f}GB/s")
+        hip.tune("gemm_cfg", 0)
+        print(f"M={M:7d} N={N:6d} K={K:5d} {epi:6s} | " + " | ".join(cells))
 
 
 def bench_conv():
@@ -63,10 +69,15 @@ def bench_conv():
         w = rnd(cout, 3, 3, cin, s=1 / math.sqrt(9 * cin))
         b = torch.zeros(cout, device=dev)
         fn = lambda: hip.conv3x3(x, w, b, stride=st, upsample=bool(up))
-        t = timeit(fn)
         oh = h * (2 if up else 1) // st
         fl = 2 * nb * oh * oh * cout * 9 * cin
-        print(f"nb={nb} h={h:3d} cin={cin:5d} cout={cout:5d} s={st} up={up} {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s")
+        cells = []
+        for cfg in CFGS:
+            hip.tune("gemm_cfg", cfg)
+            t = timeit(fn)
+            cells.append(f"cfg{cfg}: {t*1e6:7.1f}us {fl/t/1e12:6.1f}TF")
+        hip.tune("gemm_cfg", 0)
+        print(f"nb={nb} h={h:3d} cin={cin:5d} cout={cout:5d} s={st} up={up} | " + " | ".join(cells))
 
 
 def bench_attn():
