@@ -25,7 +25,7 @@ struct AttnParams {
 constexpr int KT = 64;  // keys per LDS tile
 
 template <typename T, int HD, int NW, bool VT>
-__global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
+__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {
   constexpr int ESZ = sizeof(T);
   constexpr int VEC = 16 / ESZ;                 // elements per 16-byte vector
   constexpr int HDK = (HD + 15) / 16 * 16;      // QK^T reduction length (zero padded)
@@ -70,158 +70,217 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(AttnParams p) {
   float m_run = -1e30f, l_run = 0.f;
   const float c = p.scale_log2e;
 
-  const int nseg = (p.k2 != nullptr && p.nk2 > 0 && b >= p.seg2_first_batch) ? 2 : 1;
-  for (int seg = 0; seg < nseg; ++seg) {
-    const T *kb, *vb;
-    long kts, vts;
-    int nks;
-    if (seg == 0) {
-      kb = reinterpret_cast<const T*>(p.k) + bo * p.k_bs0 + bi * p.k_bs1 + (long)head * HD;
-      vb = reinterpret_cast<const T*>(p.v) + bo * p.v_bs0 + bi * p.v_bs1;
-      kts = p.k_ts; vts = p.v_ts; nks = p.nk;
-    } else {
-      const int b2 = b / p.k2_bdiv;
-      kb = reinterpret_cast<const T*>(p.k2) + b2 * p.k2_bs + (long)head * HD;
-      vb = reinterpret_cast<const T*>(p.v2) + b2 * p.v2_bs;
-      kts = p.k2_ts; vts = p.v2_ts; nks = p.nk2;
-    }
-    // V addressing: row-major -> vb + key * vts + head*HD + d ; transposed -> vb + (head*HD + d) * vts + key
-    for (int kt = 0; kt < nks; kt += KT) {
-      __syncthreads();
-      // ---- stage K tile: KT rows x HDK columns ----
-      {
-        constexpr int NVK = HDK / VEC;
-        for (int idx = tid; idx < KT * NVK; idx += NT) {
-          const int row = idx / NVK, vc = idx - row * NVK;
-          const int key = kt + row, d = vc * VEC;
-          u32x4 val = (u32x4)(0u);
-          if (key < nks && d < HD) val = *reinterpret_cast<const u32x4*>(kb + (long)key * kts + d);
-          *reinterpret_cast<u32x4*>(lK + row * RSK + vc * 16) = val;
-        }
-      }
-      // ---- stage V tile ----
-      if (VT) {
-        constexpr int NVV = KT / VEC;
-        for (int idx = tid; idx < HDV * NVV; idx += NT) {
-          const int row = idx / NVV, vc = idx - row * NVV;
-          const int key0 = kt + vc * VEC;
-          union { u32x4 v; T e[VEC]; } val;
-          val.v = (u32x4)(0u);
-          if (row < HD) {
-            const T* src = vb + ((long)head * HD + row) * vts + key0;
-            if (key0 + VEC <= nks) {
-              val.v = *reinterpret_cast<const u32x4*>(src);
-            } else {
-#pragma unroll
-              for (int e = 0; e < VEC; ++e)
-                if (key0 + e < nks) val.e[e] = src[e];
-            }
-          }
-          if (ESZ == 2) {  // 136-byte rows: two 8-byte stores keep natural alignment
-            u32x2* dst = reinterpret_cast<u32x2*>(lV + row * RSV + vc * 16);
-            dst[0] = (u32x2){val.v[0], val.v[1]};
-            dst[1] = (u32x2){val.v[2], val.v[3]};
-          } else {
-            *reinterpret_cast<u32x4*>(lV + row * RSV + vc * 16) = val.v;
-          }
-        }
-      } else {
-        constexpr int NVV = HDV / VEC;
-        for (int idx = tid; idx < KT * NVV; idx += NT) {
-          const int row = idx / NVV, vc = idx - row * NVV;
-          const int key = kt + row, d = vc * VEC;
-          u32x4 val = (u32x4)(0u);
-          if (key < nks && d < HD) val = *reinterpret_cast<const u32x4*>(vb + (long)key * vts + (long)head * HD + d);
-          *reinterpret_cast<u32x4*>(lV + row * RSV + vc * 16) = val;
-        }
-      }
-      __syncthreads();
+  // ---- tile schedule: segment 0 = own keys, segment 1 = bank keys (conditional CFG half only) ----
+  const bool has2 = p.k2 != nullptr && p.nk2 > 0 && b >= p.seg2_first_batch;
+  const int nt0 = (p.nk + KT - 1) / KT;
+  const int ntiles = nt0 + (has2 ? (p.nk2 + KT - 1) / KT : 0);
+  const T* kb0 = reinterpret_cast<const T*>(p.k) + bo * p.k_bs0 + bi * p.k_bs1 + (long)head * HD;
+  const T* vb0 = reinterpret_cast<const T*>(p.v) + bo * p.v_bs0 + bi * p.v_bs1;
+  const int b2 = b / p.k2_bdiv;
+  const T* kb1 = has2 ? reinterpret_cast<const T*>(p.k2) + b2 * p.k2_bs + (long)head * HD : kb0;
+  const T* vb1 = has2 ? reinterpret_cast<const T*>(p.v2) + b2 * p.v2_bs : vb0;
 
-      // ---- S^T = K . Q^T for the two 32-key sub-tiles ----
-      f32x16 s[2];
+  // Only the HD valid columns (K) / rows (V^T) are ever staged; the zero padding up to HDK / HDV is written once.
+  constexpr int NVK = HD / VEC;                          // valid 16-byte vectors per K row
+  constexpr int NVV = VT ? KT / VEC : HD / VEC;          // vectors per V tile row
+  constexpr int VR = VT ? HD : KT;                       // staged V tile rows
+  constexpr bool PF = NW >= 4;                           // register prefetch only where a thread stages few vectors
+  constexpr int KVEC = PF ? (KT * NVK + NT - 1) / NT : 1;
+  constexpr int VVEC = PF ? (VR * NVV + NT - 1) / NT : 1;
+  u32x4 rk[KVEC], rv[VVEC];
+  for (int i = tid * 16; i < KT * RSK + VROWS * RSV; i += NT * 16) *reinterpret_cast<u32x4*>(smem + i) = (u32x4)(0u);
+
+  struct TileSrc { const T *kb, *vb; long kts, vts; int nks, kt; };
+  auto tile_src = [&](int it) {
+    TileSrc t;
+    const bool s1 = it >= nt0;
+    t.kb = s1 ? kb1 : kb0;
+    t.vb = s1 ? vb1 : vb0;
+    t.kts = s1 ? p.k2_ts : p.k_ts;
+    t.vts = s1 ? p.v2_ts : p.v_ts;
+    t.nks = s1 ? p.nk2 : p.nk;
+    t.kt = (s1 ? it - nt0 : it) * KT;
+    return t;
+  };
+  // One staged vector of K / V.  Rows past the end of the segment are CLAMPED to the last valid row (finite data; their
+  // scores are masked / their probabilities are exactly 0), so full tiles run without any per-vector branch.
+  auto load_k = [&](const TileSrc& t, int idx) -> u32x4 {
+    const int row = idx / NVK, vc = idx - row * NVK;
+    int key = t.kt + row;
+    key = key < t.nks ? key : t.nks - 1;
+    return *reinterpret_cast<const u32x4*>(t.kb + (long)key * t.kts + vc * VEC);
+  };
+  auto load_v = [&](const TileSrc& t, int idx, bool full) -> u32x4 {
+    const int row = idx / NVV, vc = idx - row * NVV;
+    if (VT) {
+      const int key0 = t.kt + vc * VEC;
+      const T* src = t.vb + ((long)head * HD + row) * t.vts + key0;
+      if (full || key0 + VEC <= t.nks) return *reinterpret_cast<const u32x4*>(src);
+      union { u32x4 v; T e[VEC]; } val;       // ragged tail of the last tile: element-wise, zero filled
+      val.v = (u32x4)(0u);
+      for (int e = 0; e < VEC; ++e)
+        if (key0 + e < t.nks) val.e[e] = src[e];
+      return val.v;
+    } else {
+      int key = t.kt + row;
+      key = key < t.nks ? key : t.nks - 1;
+      return *reinterpret_cast<const u32x4*>(t.vb + (long)key * t.vts + (long)head * HD + vc * VEC);
+    }
+  };
+  auto store_k = [&](int idx, u32x4 v) {
+    const int row = idx / NVK, vc = idx - row * NVK;
+    *reinterpret_cast<u32x4*>(lK + row * RSK + vc * 16) = v;
+  };
+  auto store_v = [&](int idx, u32x4 v) {
+    const int row = idx / NVV, vc = idx - row * NVV;
+    if (VT && ESZ == 2) {  // 136-byte rows: two 8-byte stores keep natural alignment
+      u32x2* dst = reinterpret_cast<u32x2*>(lV + row * RSV + vc * 16);
+      dst[0] = (u32x2){v[0], v[1]};
+      dst[1] = (u32x2){v[2], v[3]};
+    } else {
+      *reinterpret_cast<u32x4*>(lV + row * RSV + vc * 16) = v;
+    }
+  };
+
+  // issue-early / write-late staging (guide T14): the next tile's global loads fly under the current tile's MFMAs
+  auto prefetch = [&](int it) {
+    const TileSrc t = tile_src(it);
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        s[sub] = (f32x16)(0.f);
-        const char* kp = lK + (sub * 32 + lr) * RSK + lh * 8 * ESZ;
+    for (int i = 0; i < KVEC; ++i) {
+      const int idx = tid + i * NT;
+      if ((i + 1) * NT <= KT * NVK || idx < KT * NVK) rk[i] = load_k(t, idx);
+    }
+    if (t.kt + KT <= t.nks) {      // wave-uniform: full tiles take the branch-free path
 #pragma unroll
-        for (int ks = 0; ks < KSQ; ++ks) {
-          Frag<T> kf;
-          frag_load(kf, reinterpret_cast<const T*>(kp + ks * 16 * ESZ));
-          mma32(s[sub], kf, qf[ks]);
-        }
+      for (int i = 0; i < VVEC; ++i) {
+        const int idx = tid + i * NT;
+        if ((i + 1) * NT <= VR * NVV || idx < VR * NVV) rv[i] = load_v(t, idx, true);
       }
-      // ---- online softmax over this tile's 64 keys (lane = query column) ----
-      float mt = -1e30f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < VVEC; ++i) {
+        const int idx = tid + i * NT;
+        if ((i + 1) * NT <= VR * NVV || idx < VR * NVV) rv[i] = load_v(t, idx, false);
+      }
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < KVEC; ++i) {
+      const int idx = tid + i * NT;
+      if ((i + 1) * NT <= KT * NVK || idx < KT * NVK) store_k(idx, rk[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < VVEC; ++i) {
+      const int idx = tid + i * NT;
+      if ((i + 1) * NT <= VR * NVV || idx < VR * NVV) store_v(idx, rv[i]);
+    }
+  };
+  // single-wave variant (temporal / tiny sequences): straight global -> LDS staging, rolled loops, no prefetch registers
+  auto stage_direct = [&](int it) {
+    const TileSrc t = tile_src(it);
+    for (int idx = tid; idx < KT * NVK; idx += NT) store_k(idx, load_k(t, idx));
+    for (int idx = tid; idx < VR * NVV; idx += NT) store_v(idx, load_v(t, idx, false));
+  };
+
+  if (PF) prefetch(0);
+  for (int it = 0; it < ntiles; ++it) {
+    const bool s1 = it >= nt0;
+    const int nks = s1 ? p.nk2 : p.nk;
+    const int kt = (s1 ? it - nt0 : it) * KT;
+    __syncthreads();     // every wave has finished reading the previous tile
+    if (PF) commit();
+    else stage_direct(it);
+    __syncthreads();
+    if (PF && it + 1 < ntiles) prefetch(it + 1);
+
+    // ---- S^T = K . Q^T for the two 32-key sub-tiles ----
+    f32x16 s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      s[sub] = (f32x16)(0.f);
+      const char* kp = lK + (sub * 32 + lr) * RSK + lh * 8 * ESZ;
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) {
+        Frag<T> kf;
+        frag_load(kf, reinterpret_cast<const T*>(kp + ks * 16 * ESZ));
+        mma32(s[sub], kf, qf[ks]);
+      }
+    }
+    // ---- online softmax over this tile's 64 keys (lane = query column) ----
+    if (kt + KT > nks) {   // ragged last tile only: mask the keys past the end
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt + sub * 32 + acc_row(r, lane);
-          const float v = key < nks ? s[sub][r] : -1e30f;
-          s[sub][r] = v;
-          mt = fmaxf(mt, v);
-        }
-      mt = fmaxf(mt, __shfl_xor(mt, 32));
-      const float m_new = fmaxf(m_run, mt);
-      const float alpha = exp2f((m_run - m_new) * c);
-      const float mc = m_new * c;
-      float ls = 0.f;
+        for (int r = 0; r < 16; ++r)
+          if (kt + sub * 32 + acc_row(r, lane) >= nks) s[sub][r] = -1e30f;
+    }
+    float mt = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
+    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(s[0][r], s[1][r]));
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float m_new = fmaxf(m_run, mt);
+    const float mc = m_new * c;
+    float ls = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float pv = exp2f(s[sub][r] * c - mc);
-          s[sub][r] = pv;
-          ls += pv;
-        }
-      l_run = l_run * alpha + ls;
-      m_run = m_new;
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(s[sub][r] * c - mc);   // raw v_exp_f32 (inputs <= 0, flush is fine)
+        s[sub][r] = pv;
+        ls += pv;
+      }
+    if (__any(m_new > m_run)) {   // wave-uniform: rescale only when some query's running max moved
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      l_run *= alpha;
 #pragma unroll
       for (int i = 0; i < DT; ++i) o[i] *= alpha;
-
-      // ---- O^T += V^T . P^T ----
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          Frag<T> pf;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) pf.set(j, s[sub][8 * s2 + j]);
-          // element j of this lane <-> key  sub*32 + 16*s2 + 8*(j>>2) + 4*lh + (j&3)
-          const int kbase = sub * 32 + 16 * s2 + 4 * lh;
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            Frag<T> vf;
-            const int d = dt * 32 + lr;
-            if (VT) {
-              const T* vp = reinterpret_cast<const T*>(lV + d * RSV) + kbase;
-              if (ESZ == 2) {
-                const u32x2 lo = *reinterpret_cast<const u32x2*>(vp);
-                const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + 8);
-                union { u32x4 u; Frag<T> f; } cv;
-                cv.u = (u32x4){lo[0], lo[1], hi[0], hi[1]};
-                vf = cv.f;
-              } else {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(vp);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(vp + 8);
-                union { float f[8]; Frag<T> fr; } cv;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { cv.f[j] = lo[j]; cv.f[4 + j] = hi[j]; }
-                vf = cv.fr;
-              }
-            } else {
-              union { T e[8]; Frag<T> f; } cv;
-#pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                const int key = kbase + 8 * (j >> 2) + (j & 3);
-                cv.e[j] = *(reinterpret_cast<const T*>(lV + key * RSV) + d);
-              }
-              vf = cv.f;
-            }
-            mma32(o[dt], vf, pf);
-          }
-        }
+      m_run = m_new;
     }
+    l_run += ls;
+
+    // ---- O^T += V^T . P^T ----
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        Frag<T> pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf.set(j, s[sub][8 * s2 + j]);
+        // element j of this lane <-> key  sub*32 + 16*s2 + 8*(j>>2) + 4*lh + (j&3)
+        const int kbase = sub * 32 + 16 * s2 + 4 * lh;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          Frag<T> vf;
+          const int d = dt * 32 + lr;
+          if (VT) {
+            const T* vp = reinterpret_cast<const T*>(lV + d * RSV) + kbase;
+            if (ESZ == 2) {
+              const u32x2 lo = *reinterpret_cast<const u32x2*>(vp);
+              const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + 8);
+              union { u32x4 u; Frag<T> f; } cv;
+              cv.u = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+              vf = cv.f;
+            } else {
+              const f32x4 lo = *reinterpret_cast<const f32x4*>(vp);
+              const f32x4 hi = *reinterpret_cast<const f32x4*>(vp + 8);
+              union { float f[8]; Frag<T> fr; } cv;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { cv.f[j] = lo[j]; cv.f[4 + j] = hi[j]; }
+              vf = cv.fr;
+            }
+          } else {
+            union { T e[8]; Frag<T> f; } cv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int key = kbase + 8 * (j >> 2) + (j & 3);
+              cv.e[j] = *(reinterpret_cast<const T*>(lV + key * RSV) + d);
+            }
+            vf = cv.f;
+          }
+          mma32(o[dt], vf, pf);
+        }
+      }
   }
 
   // ---- normalise and store: lane (q, half) owns d = 32 dt + 8 g + 4 half + (0..3) ----

@@ -358,8 +358,13 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
   // projections) smaller tiles with several resident workgroups per CU keep more loads in flight.
   const bool geglu = ep.act == 1;
   int cfg = g_gemm_cfg;
-  if (cfg == 0) cfg = (!geglu && MODE == 0 && K <= 640) ? 3 : 2;
-  if (geglu && cfg > 2) cfg = 2;
+  if (cfg == 0) {
+    // measured on MI355X (tools/bench_kernels.py): the 2-stage 128x128 tile (2 workgroups / CU) wins on compute-bound
+    // shapes; 128x64 (3 workgroups / CU) wins on short reductions, narrow outputs and grids that would not fill the chip.
+    const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    cfg = (!geglu && ((MODE == 0 && (K <= 640 || N <= 320)) || tiles128 < 512)) ? 3 : 1;
+  }
+  if (geglu && cfg > 2) cfg = 1;
   switch (cfg) {
     case 1: return launch_cfg<T, MODE, 128, 128, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
     case 2: return launch_cfg<T, MODE, 128, 128, 2, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
