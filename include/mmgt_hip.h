@@ -27,6 +27,7 @@ extern "C" {
 #define MMGT_ACT_NONE 0
 #define MMGT_ACT_GEGLU 1 /* weights packed per 64 rows as [32 h | 32 gate]; output has N/2 columns */
 #define MMGT_ACT_SILU 2
+#define MMGT_ACT_RELU 3
 
 int mmgt_abi_version(void);
 const char* mmgt_last_error(void);
@@ -89,8 +90,10 @@ int mmgt_softmax_rows(const void* x, long ldx, void* out, long ldo, int rows, in
 /* Layout / dtype plumbing between the reference's (b, c, f, h, w) fp32 tensors and channels-last T:
  * out[(b*F + f), y, x, c] (c padded with zeros up to Cpad) <- in[b, c, f, y, x]; and the inverse (first C channels).
  * Replaces: the einops rearranges at resnet.py:13-15; transformer_3d.py:158,178-180,248-252,264. */
-int mmgt_ncfhw_to_nhwc(const float* in, void* out, int B, int C, int F, int H, int W, int Cpad, int dtype, void* stream);
-int mmgt_nhwc_to_ncfhw(const void* in, float* out, int B, int C, int F, int H, int W, int Cpad, int dtype, void* stream);
+int mmgt_ncfhw_to_nhwc(const float* in, void* out, int B, int C, int F, int H, int W, int Cpad, float scale, int dtype,
+                       void* stream);                       /* out = in * scale   (z / 0.18215 before the VAE, :114) */
+int mmgt_nhwc_to_ncfhw(const void* in, float* out, int B, int C, int F, int H, int W, int Cpad, float scale, float shift,
+                       int clamp01, int dtype, void* stream); /* out = clamp(in * scale + shift): (x/2+0.5).clamp(0,1), :122 */
 
 /* Sinusoidal timestep features: out[b][0:half] = cos(t_b * f_i), out[b][half:] = sin(t_b * f_i), f_i = 10000^(-i/half).
  * Replaces: diffusers Timesteps(flip_sin_to_cos=True, shift 0) at unet_3d.py:496.  timesteps: fp32 [B] device. */

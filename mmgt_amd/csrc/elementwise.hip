@@ -26,7 +26,7 @@ inline int grid_for(long n, int block = 256) {
 
 template <typename T>
 __global__ void ncfhw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int C, int F, int HW,
-                                     int Cpad) {
+                                     int Cpad, float scale) {
   const long total = (long)B * F * HW * Cpad;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = i % Cpad;
@@ -36,14 +36,14 @@ __global__ void ncfhw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict
     const int f = t % F;
     const int b = t / F;
     float v = 0.f;
-    if (c < C) v = in[(((long)b * C + c) * F + f) * HW + p];
+    if (c < C) v = in[(((long)b * C + c) * F + f) * HW + p] * scale;
     Elem<T>::st(out + i, v);
   }
 }
 
 template <typename T>
 __global__ void nhwc_to_ncfhw_kernel(const T* __restrict__ in, float* __restrict__ out, int B, int C, int F, int HW,
-                                     int Cpad) {
+                                     int Cpad, float scale, float shift, int clamp01) {
   const long total = (long)B * C * F * HW;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int p = i % HW;
@@ -52,7 +52,9 @@ __global__ void nhwc_to_ncfhw_kernel(const T* __restrict__ in, float* __restrict
     t /= F;
     const int c = t % C;
     const int b = t / C;
-    out[i] = Elem<T>::ld(in + (((long)b * F + f) * HW + p) * Cpad + c);
+    float v = Elem<T>::ld(in + (((long)b * F + f) * HW + p) * Cpad + c) * scale + shift;
+    if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+    out[i] = v;
   }
 }
 
@@ -127,32 +129,32 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__
 }  // namespace
 
 
-extern "C" int mmgt_ncfhw_to_nhwc(const float* in, void* out, int B, int C, int F, int H, int W, int Cpad, int dtype,
-                                  void* stream) {
+extern "C" int mmgt_ncfhw_to_nhwc(const float* in, void* out, int B, int C, int F, int H, int W, int Cpad, float scale,
+                                  int dtype, void* stream) {
   MMGT_CHECK(in && out && Cpad >= C && C > 0, "ncfhw_to_nhwc: bad arguments");
   MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "ncfhw_to_nhwc: bad dtype");
   const long total = (long)B * F * H * W * Cpad;
   if (dtype == MMGT_BF16)
     hipLaunchKernelGGL(ncfhw_to_nhwc_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
-                       (bf16_t*)out, B, C, F, H * W, Cpad);
+                       (bf16_t*)out, B, C, F, H * W, Cpad, scale);
   else
     hipLaunchKernelGGL(ncfhw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
-                       (float*)out, B, C, F, H * W, Cpad);
+                       (float*)out, B, C, F, H * W, Cpad, scale);
   MMGT_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int mmgt_nhwc_to_ncfhw(const void* in, float* out, int B, int C, int F, int H, int W, int Cpad, int dtype,
-                                  void* stream) {
+extern "C" int mmgt_nhwc_to_ncfhw(const void* in, float* out, int B, int C, int F, int H, int W, int Cpad, float scale,
+                                  float shift, int clamp01, int dtype, void* stream) {
   MMGT_CHECK(in && out && Cpad >= C && C > 0, "nhwc_to_ncfhw: bad arguments");
   MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "nhwc_to_ncfhw: bad dtype");
   const long total = (long)B * C * F * H * W;
   if (dtype == MMGT_BF16)
     hipLaunchKernelGGL(nhwc_to_ncfhw_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)in, out, B, C, F, H * W, Cpad);
+                       (const bf16_t*)in, out, B, C, F, H * W, Cpad, scale, shift, clamp01);
   else
     hipLaunchKernelGGL(nhwc_to_ncfhw_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)in, out, B, C, F, H * W, Cpad);
+                       (const float*)in, out, B, C, F, H * W, Cpad, scale, shift, clamp01);
   MMGT_LAUNCH_CHECK();
   return 0;
 }

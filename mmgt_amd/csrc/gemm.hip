@@ -49,7 +49,7 @@ struct Epi {
   long ldr, ldo, bsr, bso; // strides in elements; bs* = grid.z strides
   int bias2_rows;
   float alpha;
-  int act;                 // 0 none, 1 GEGLU (packed weights, out has N/2 columns), 2 SiLU
+  int act;                 // 0 none, 1 GEGLU (packed weights, out has N/2 columns), 2 SiLU, 3 ReLU
   int fast;                // 1: N % 8 == 0 and every row / pointer 16-byte aligned -> vectorised epilogue
 };
 
@@ -286,6 +286,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(ADesc ad, const char* __restr
           if (ep.act == 2) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) o8[e] = silu_f(o8[e]);
+          } else if (ep.act == 3) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] = fmaxf(o8[e], 0.f);
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) o8[e] *= rs;
@@ -318,6 +321,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ADesc ad, const char* __restr
           } else {
             if (ep.bias2) x += ep.bias2[(long)(m / ep.bias2_rows) * N + ncol + e];
             if (ep.act == 2) x = silu_f(x);
+            if (ep.act == 3) x = fmaxf(x, 0.f);
             x *= (ep.row_scale ? ep.row_scale[m] : 1.f) * ep.alpha;
           }
           if (res) x += Elem<T>::ld(res + (long)m * ep.ldr + ocol + e);
@@ -386,7 +390,7 @@ int check_common(int dtype, int M, int N, int K, int act) {
   MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "gemm: bad dtype %d", dtype);
   MMGT_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
   MMGT_CHECK(K % 64 == 0, "gemm: K=%d must be a multiple of 64 (pad channels on the host)", K);
-  MMGT_CHECK(act >= 0 && act <= 2, "gemm: bad act %d", act);
+  MMGT_CHECK(act >= 0 && act <= 3, "gemm: bad act %d", act);
   MMGT_CHECK(act != 1 || N % 64 == 0, "gemm: GEGLU needs N %% 64 == 0 (N=%d)", N);
   return 0;
 }
@@ -433,7 +437,7 @@ extern "C" int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1,
   MMGT_CHECK(!(upsample && stride != 1), "conv3x3: upsample requires stride 1");
   MMGT_CHECK(C0 % 64 == 0 && C1 % 64 == 0 && (x1 != nullptr) == (C1 > 0),
              "conv3x3: channel counts must be multiples of 64 (C0=%d C1=%d)", C0, C1);
-  MMGT_CHECK(act == 0 || act == 2, "conv3x3: act %d unsupported", act);
+  MMGT_CHECK(act == 0 || act == 2 || act == 3, "conv3x3: act %d unsupported", act);
   MMGT_CHECK(((uintptr_t)x0 % 16) == 0 && ((uintptr_t)x1 % 16) == 0 && ((uintptr_t)Wp % 16) == 0,
              "conv3x3: pointers must be 16-byte aligned");
   const int VH = upsample ? IH * 2 : IH, VW = upsample ? IW * 2 : IW;

@@ -32,10 +32,12 @@ struct VecIO {
   }
 };
 
-// ---- GroupNorm pass 1: per (image, row chunk) partial sum / sum of squares per group ----
+// ---- GroupNorm pass 1: per (image, row chunk) partial sum / sum of squares per group.
+// LPR lanes cover one pixel row (64 for wide tensors; 16 / 32 for the VAE's 128 / 256-channel tensors so that a wave
+// streams 64 / LPR rows at once with every lane busy); a lane always owns the same channels.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1,
-                                                       float* __restrict__ partial, int HW, int G, int chunks) {
+                                                       float* __restrict__ partial, int HW, int G, int chunks, int lpr) {
   constexpr int VEC = VecIO<T>::VEC;
   constexpr int MAXS = GN_MAXC / (VEC * 64);
   __shared__ float ssum[GN_MAXC], ssq[GN_MAXC];
@@ -44,6 +46,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x0,
   const int rows_per = (HW + chunks - 1) / chunks;
   const int r0 = chunk * rows_per, r1 = min(HW, r0 + rows_per);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int rpw = 64 / lpr, sub = lane / lpr, li = lane - sub * lpr;
 
   float s[MAXS][VEC], q[MAXS][VEC];
 #pragma unroll
@@ -51,11 +54,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x0,
 #pragma unroll
     for (int e = 0; e < VEC; ++e) s[i][e] = q[i][e] = 0.f;
 
-  for (int r = r0 + wid; r < r1; r += 4) {
+  for (int r = r0 + wid * rpw + sub; r < r1; r += 4 * rpw) {
     const long pix = (long)n * HW + r;
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
-      const int vc = lane + 64 * i;
+      const int vc = li + lpr * i;
       if (vc < nvec) {
         const int c = vc * VEC;
         const T* src = c < C0 ? x0 + pix * C0 + c : x1 + pix * C1 + (c - C0);
@@ -66,12 +69,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x0,
       }
     }
   }
-  // combine the four waves in a fixed order
+  // fold the wave's row slots together (fixed xor tree), then the four waves in a fixed order
+  for (int o = lpr; o < 64; o <<= 1) {
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { s[i][e] += __shfl_xor(s[i][e], o); q[i][e] += __shfl_xor(q[i][e], o); }
+  }
   for (int w = 0; w < 4; ++w) {
-    if (wid == w) {
+    if (wid == w && sub == 0) {
 #pragma unroll
       for (int i = 0; i < MAXS; ++i) {
-        const int vc = lane + 64 * i;
+        const int vc = li + lpr * i;
         if (vc < nvec)
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
@@ -98,7 +107,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ partial, T* __restrict__ out, int HW,
-                                                       int G, int chunks, float eps, int silu) {
+                                                       int G, int chunks, float eps, int silu, int lpr) {
   constexpr int VEC = VecIO<T>::VEC;
   constexpr int MAXS = GN_MAXC / (VEC * 64);
   __shared__ float sscale[GN_MAXC], sshift[GN_MAXC];
@@ -108,6 +117,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
   const int rows_per = (HW + chunks - 1) / chunks;
   const int r0 = chunk * rows_per, r1 = min(HW, r0 + rows_per);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int rpw = 64 / lpr, sub = lane / lpr, li = lane - sub * lpr;
   if (threadIdx.x < G) {
     float a = 0.f, b = 0.f;
     for (int ch = 0; ch < chunks; ++ch) {
@@ -130,11 +140,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
     sshift[c] = beta[c] - smean[g] * sc;
   }
   __syncthreads();
-  for (int r = r0 + wid; r < r1; r += 4) {
+  for (int r = r0 + wid * rpw + sub; r < r1; r += 4 * rpw) {
     const long pix = (long)n * HW + r;
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
-      const int vc = lane + 64 * i;
+      const int vc = li + lpr * i;
       if (vc < nvec) {
         const int c = vc * VEC;
         const T* src = c < C0 ? x0 + pix * C0 + c : x1 + pix * C1 + (c - C0);
@@ -227,16 +237,19 @@ extern "C" int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C
   const int chunks = gn_chunks(HW);
   dim3 grid(chunks, NB);
   hipStream_t s = (hipStream_t)stream;
+  const int nvec = C / vec;
+  int lpr = 64;
+  if (nvec <= 32) { lpr = 8; while (lpr < nvec) lpr <<= 1; }
   if (dtype == MMGT_BF16) {
     hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x0, C0, (const bf16_t*)x1, C1,
-                       workspace, HW, G, chunks);
+                       workspace, HW, G, chunks, lpr);
     hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x0, C0, (const bf16_t*)x1, C1, gamma,
-                       beta, workspace, (bf16_t*)out, HW, G, chunks, eps, silu);
+                       beta, workspace, (bf16_t*)out, HW, G, chunks, eps, silu, lpr);
   } else {
     hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x0, C0, (const float*)x1, C1,
-                       workspace, HW, G, chunks);
+                       workspace, HW, G, chunks, lpr);
     hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x0, C0, (const float*)x1, C1, gamma,
-                       beta, workspace, (float*)out, HW, G, chunks, eps, silu);
+                       beta, workspace, (float*)out, HW, G, chunks, eps, silu, lpr);
   }
   MMGT_LAUNCH_CHECK();
   return 0;

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmgt_hip.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_GEGLU, ACT_SILU = 0, 1, 2
+ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
 
 _lib = None
 
@@ -36,8 +36,9 @@ _SIGS = {
                                c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                c_int, c_int, c_void_p]),
     "mmgt_softmax_rows": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_float, c_int, c_void_p]),
-    "mmgt_ncfhw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "mmgt_nhwc_to_ncfhw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_ncfhw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "mmgt_nhwc_to_ncfhw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
+                                   c_int, c_void_p]),
     "mmgt_timestep_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mmgt_silu": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "mmgt_cfg_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_float,
@@ -138,6 +139,17 @@ def gemm_batched_wx(w, x, bias_unused=None, *, out):
     return out
 
 
+def gemm_batched(a, w, *, out):
+    """out[b] (M, N) = a[b] (M, K) @ w[b] (N, K)^T for dense 3-D operands (one problem per grid.z)."""
+    _dev(a, w, out)
+    B, M, K = a.shape
+    N = w.shape[1]
+    assert a.is_contiguous() and w.is_contiguous() and out.is_contiguous() and w.shape == (B, N, K) and out.shape == (B, M, N)
+    _check(lib().mmgt_gemm(_ptr(a), K, _ptr(w), None, None, 0, None, 1.0, None, 0, _ptr(out), N, M, N, K, ACT_NONE, B,
+                           M * K, N * K, 0, M * N, dtype_code(a.dtype), _stream()), "mmgt_gemm(batched)")
+    return out
+
+
 def conv3x3(x, wp, bias=None, *, stride=1, upsample=False, bias2=None, bias2_rows=0, residual=None, act=ACT_NONE,
             x1=None, out=None):
     """x (NB, H, W, C0) channels-last [+ x1 (NB, H, W, C1)], wp [Cout][3][3][C0+C1] -> (NB, OH, OW, Cout)."""
@@ -219,25 +231,26 @@ def softmax_rows(x, scale=1.0, out=None):
 
 # ------------------------------------------------------------------------------------------------------------ plumbing
 
-def ncfhw_to_nhwc(x, cpad, dtype):
-    """(B, C, F, H, W) fp32 -> (B*F, H, W, cpad) channels-last `dtype`, zero padded channels."""
+def ncfhw_to_nhwc(x, cpad, dtype, scale=1.0):
+    """(B, C, F, H, W) fp32 -> (B*F, H, W, cpad) channels-last `dtype` (times `scale`), zero padded channels."""
     _dev(x)
     assert x.dim() == 5 and x.dtype == torch.float32 and x.is_contiguous()
     B, C, F, H, W = x.shape
     out = torch.empty((B * F, H, W, cpad), device=x.device, dtype=dtype)
-    _check(lib().mmgt_ncfhw_to_nhwc(_ptr(x), _ptr(out), B, C, F, H, W, cpad, dtype_code(dtype), _stream()),
+    _check(lib().mmgt_ncfhw_to_nhwc(_ptr(x), _ptr(out), B, C, F, H, W, cpad, scale, dtype_code(dtype), _stream()),
            "mmgt_ncfhw_to_nhwc")
     return out
 
 
-def nhwc_to_ncfhw(x, B, C):
-    """(B*F, H, W, cpad) -> (B, C, F, H, W) fp32 (first C channels)."""
+def nhwc_to_ncfhw(x, B, C, scale=1.0, shift=0.0, clamp01=False):
+    """(B*F, H, W, cpad) -> (B, C, F, H, W) fp32 (first C channels), out = clamp(x * scale + shift)."""
     _dev(x)
     assert x.dim() == 4 and x.is_contiguous()
     BF, H, W, cpad = x.shape
     F = BF // B
     out = torch.empty((B, C, F, H, W), device=x.device, dtype=torch.float32)
-    _check(lib().mmgt_nhwc_to_ncfhw(_ptr(x), _ptr(out), B, C, F, H, W, cpad, dtype_code(x.dtype), _stream()),
+    _check(lib().mmgt_nhwc_to_ncfhw(_ptr(x), _ptr(out), B, C, F, H, W, cpad, scale, shift, int(clamp01),
+                                    dtype_code(x.dtype), _stream()),
            "mmgt_nhwc_to_ncfhw")
     return out
 

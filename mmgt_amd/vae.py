@@ -1,0 +1,203 @@
+"""AutoencoderKL decoder (sd-vae-ft-mse) on MI355X: the `decode_latents` leg of the Stage-2 sampler.
+
+Mirrors what src/pipelines/pipeline_pose2vid_long.py:112-125 asks of diffusers' `AutoencoderKL.decode`, with the
+diffusers 0.24.0 state-dict key names so `sd-vae-ft-mse` checkpoints load by name.  All frames of a clip are decoded as
+one channels-last batch (the reference loops frame by frame; every op is per-frame, so results are identical) on the same
+HIP kernels as the UNet: implicit-GEMM conv3x3 (fused nearest-2x upsample), GroupNorm+SiLU, GEMM; the single 512-wide
+attention head of the mid block uses materialised scores (GEMM -> row softmax -> GEMM), 34 GFLOP per frame.
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import hip
+from .packing import pack_conv3x3, pad_cols, pad_rows, round_up
+
+_UP_CH = ((512, 512), (512, 512), (512, 256), (256, 128))     # (in, out) of decoder.up_blocks.0..3
+
+
+def vae_decoder_spec():
+    s = OrderedDict()
+
+    def norm(p, c):
+        s[p + ".weight"] = (c,)
+        s[p + ".bias"] = (c,)
+
+    def conv(p, cin, cout, k=3):
+        s[p + ".weight"] = (cout, cin, k, k)
+        s[p + ".bias"] = (cout,)
+
+    def resnet(p, cin, cout):
+        norm(p + ".norm1", cin)
+        conv(p + ".conv1", cin, cout)
+        norm(p + ".norm2", cout)
+        conv(p + ".conv2", cout, cout)
+        if cin != cout:
+            conv(p + ".conv_shortcut", cin, cout, 1)
+
+    conv("post_quant_conv", 4, 4, 1)
+    conv("decoder.conv_in", 4, 512)
+    resnet("decoder.mid_block.resnets.0", 512, 512)
+    a = "decoder.mid_block.attentions.0"
+    norm(a + ".group_norm", 512)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        s[f"{a}.{n}.weight"] = (512, 512)
+        s[f"{a}.{n}.bias"] = (512,)
+    resnet("decoder.mid_block.resnets.1", 512, 512)
+    for i, (cin, cout) in enumerate(_UP_CH):
+        for j in range(3):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+        if i != 3:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", cout, cout)
+    norm("decoder.conv_norm_out", 128)
+    conv("decoder.conv_out", 128, 3)
+    return s
+
+
+class _Cfg:
+    block_out_channels = (128, 256, 512, 512)
+    scaling_factor = 0.18215
+
+
+class DecoderOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+class AutoencoderKL:
+    """Decoder half (the encoder is only used once per clip for the reference image: prologue)."""
+    config = _Cfg()
+
+    def __init__(self, device="cuda", dtype=torch.bfloat16):
+        self._device, self._dtype = torch.device(device), dtype
+        hip.dtype_code(dtype)
+        self.spec = vae_decoder_spec()
+        self.w = {}
+        self._loaded = False
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def device(self):
+        return self._device
+
+    def to(self, *a, **k):
+        return self
+
+    def _t(self, x):
+        return x.to(device=self._device, dtype=self._dtype).contiguous()
+
+    def _f(self, x):
+        return x.to(device=self._device, dtype=torch.float32).contiguous()
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self.spec if k not in sd]
+        if missing:
+            raise RuntimeError(f"AutoencoderKL.load_state_dict: missing {len(missing)} decoder keys, e.g. {missing[:3]}")
+        w = self.w
+        for k, shape in self.spec.items():
+            if tuple(sd[k].shape) != tuple(shape):
+                raise RuntimeError(f"shape mismatch for {k}: {tuple(sd[k].shape)} vs {shape}")
+        for k in self.spec:
+            if not k.endswith(".weight"):
+                continue
+            p = k[:-len(".weight")]
+            wt, b = sd[k], sd[p + ".bias"]
+            if wt.dim() == 1:                                        # GroupNorm affine
+                w[p + ".g"], w[p + ".b"] = self._f(wt), self._f(b)
+            elif wt.dim() == 4 and wt.shape[2] == 3:                 # conv3x3 (channels padded to multiples of 64)
+                cin_pad, cout_pad = round_up(wt.shape[1], 64), round_up(wt.shape[0], 64)
+                w[p + ".w"] = self._t(pack_conv3x3(wt, cin_pad, cout_pad))
+                w[p + ".bias"] = self._f(pad_rows(b, cout_pad))
+            elif wt.dim() == 4:                                      # 1x1 conv as GEMM
+                m = wt.reshape(wt.shape[0], -1)
+                w[p + ".w"] = self._t(pad_rows(pad_cols(m, round_up(m.shape[1], 64)), round_up(m.shape[0], 64)))
+                w[p + ".bias"] = self._f(pad_rows(b, round_up(m.shape[0], 64)))
+        a = "decoder.mid_block.attentions.0"
+        f32 = lambda t: t.to(torch.float32)
+        w[a + ".q.w"], w[a + ".q.bias"] = self._t(sd[a + ".to_q.weight"]), self._f(sd[a + ".to_q.bias"])
+        w[a + ".k.w"], w[a + ".k.bias"] = self._t(sd[a + ".to_k.weight"]), self._f(sd[a + ".to_k.bias"])
+        w[a + ".v.w"] = self._t(sd[a + ".to_v.weight"])
+        w[a + ".o.w"] = self._t(sd[a + ".to_out.0.weight"])
+        # softmax rows sum to 1, so P (V + 1 b_v^T) = P V + b_v^T: the value bias moves into the output bias
+        w[a + ".o.bias"] = self._f(f32(sd[a + ".to_out.0.weight"]) @ f32(sd[a + ".to_v.bias"]) + f32(sd[a + ".to_out.0.bias"]))
+        self._loaded = True
+        return [], [k for k in sd if k not in self.spec]
+
+    # ------------------------------------------------------------------------------------------------ blocks
+    def _gn(self, p, x, silu):
+        nb, h, ww, c = x.shape
+        return hip.groupnorm(x.view(nb, h * ww, c), self.w[p + ".g"], self.w[p + ".b"], 32, 1e-6, silu=silu).view(nb, h, ww, c)
+
+    def _resnet(self, p, x):
+        nb, h, ww, cin = x.shape
+        hdn = hip.conv3x3(self._gn(p + ".norm1", x, True), self.w[p + ".conv1.w"], self.w[p + ".conv1.bias"])
+        hdn = self._gn(p + ".norm2", hdn, True)
+        res = x
+        if (p + ".conv_shortcut.w") in self.w:
+            res = hip.gemm(x.view(nb * h * ww, cin), self.w[p + ".conv_shortcut.w"], self.w[p + ".conv_shortcut.bias"])
+            res = res.view(nb, h, ww, -1)
+        return hip.conv3x3(hdn, self.w[p + ".conv2.w"], self.w[p + ".conv2.bias"], residual=res)
+
+    def _mid_attention(self, x):
+        a = "decoder.mid_block.attentions.0"
+        nb, h, ww, c = x.shape
+        n = h * ww
+        t = self._gn(a + ".group_norm", x, False).view(nb * n, c)
+        q = hip.gemm(t, self.w[a + ".q.w"], self.w[a + ".q.bias"]).view(nb, n, c)
+        k = hip.gemm(t, self.w[a + ".k.w"], self.w[a + ".k.bias"]).view(nb, n, c)
+        vt = torch.empty((nb, c, n), device=self._device, dtype=self._dtype)
+        hip.gemm_batched_wx(self.w[a + ".v.w"], t.view(nb, n, c), out=vt)                    # V^T without its bias
+        s_ = torch.empty((nb, n, n), device=self._device, dtype=self._dtype)
+        hip.gemm_batched(q, k, out=s_)                                                        # scores, one frame per z
+        hip.softmax_rows(s_.view(nb * n, n), c ** -0.5, out=s_.view(nb * n, n))
+        o = torch.empty((nb, n, c), device=self._device, dtype=self._dtype)
+        hip.gemm_batched(s_, vt, out=o)
+        out = hip.gemm(o.view(nb * n, c), self.w[a + ".o.w"], self.w[a + ".o.bias"], residual=x.view(nb * n, c))
+        return out.view(nb, h, ww, c)
+
+    # ------------------------------------------------------------------------------------------------ API
+    def decode_nhwc(self, z):
+        """z: (nb, h, w, 64) channels-last latents (4 valid channels, already divided by 0.18215) -> (nb, 8h, 8w, 64)
+        with 3 valid channels."""
+        if not self._loaded:
+            raise RuntimeError("AutoencoderKL.decode before load_state_dict")
+        nb, h, ww, _ = z.shape
+        x = hip.gemm(z.view(nb * h * ww, 64), self.w["post_quant_conv.w"], self.w["post_quant_conv.bias"]).view(nb, h, ww, 64)
+        x = hip.conv3x3(x, self.w["decoder.conv_in.w"], self.w["decoder.conv_in.bias"])
+        x = self._resnet("decoder.mid_block.resnets.0", x)
+        x = self._mid_attention(x)
+        x = self._resnet("decoder.mid_block.resnets.1", x)
+        for i in range(4):
+            for j in range(3):
+                x = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", x)
+            if i != 3:
+                p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+                x = hip.conv3x3(x, self.w[p + ".w"], self.w[p + ".bias"], upsample=True)
+        x = self._gn("decoder.conv_norm_out", x, True)
+        return hip.conv3x3(x, self.w["decoder.conv_out.w"], self.w["decoder.conv_out.bias"])
+
+    def decode(self, z):
+        """diffusers-style: z (n, 4, h, w) -> DecoderOutput(sample (n, 3, 8h, 8w))."""
+        zz = z.to(self._device, torch.float32).contiguous()[:, :, None]                         # (n, 4, 1, h, w)
+        n = zz.shape[0]
+        x = hip.ncfhw_to_nhwc(zz.permute(2, 1, 0, 3, 4).contiguous(), 64, self._dtype)          # frames as the f axis
+        y = self.decode_nhwc(x)
+        out = hip.nhwc_to_ncfhw(y, 1, 3)                                                        # (1, 3, n, H, W)
+        return DecoderOutput(out[0].permute(1, 0, 2, 3).to(z.dtype))
+
+    def decode_video(self, latents, frames_per_batch=8):
+        """Pose2VideoPipeline.decode_latents (pipeline_pose2vid_long.py:112-125): latents (b, 4, f, h, w) ->
+        (b, 3, f, 8h, 8w) fp32 in [0, 1] on the GPU; z / 0.18215 and (x / 2 + 0.5).clamp(0, 1) are fused into the layout
+        kernels."""
+        lat = latents.to(self._device, torch.float32).contiguous()
+        b, c, f, h, ww = lat.shape
+        outs = []
+        for f0 in range(0, f, frames_per_batch):
+            chunk = lat[:, :, f0:f0 + frames_per_batch].contiguous()
+            x = hip.ncfhw_to_nhwc(chunk, 64, self._dtype, scale=1.0 / 0.18215)
+            y = self.decode_nhwc(x)
+            outs.append(hip.nhwc_to_ncfhw(y, b, 3, scale=0.5, shift=0.5, clamp01=True))
+        return torch.cat(outs, dim=2)
