@@ -402,7 +402,7 @@ class UNet3DConditionModel:
                       v_str=(inner * npad, 0, npad), o_str=(n * inner, 0, inner), v_transposed=True, **kw)
         return o
 
-    def _spatial_transformer(self, p, x, ehs, frames):
+    def _spatial_transformer(self, p, x, ehs, frames, write=None):
         """Transformer3DModel + TemporalBasicTransformerBlock in bank-read mode (transformer_3d.py:139-268,
         mutual_self_attention.py:149-230)."""
         nb, h, ww, c = x.shape
@@ -413,7 +413,10 @@ class UNet3DConditionModel:
         hid = self._lin(p + ".proj_in", xn.view(m, c))
         inner = hid.shape[1]
         n1 = self._ln(t + ".norm1", hid)
-        o = self._self_attention(t + ".attn1", n1, nb, n, inner, bank=self._banks.get(p), frames=frames)
+        if write is not None:            # ReferenceNet "write" mode: bank.append(norm_hidden_states) (mutual_self_attention.py:139-148)
+            write[p] = n1.view(nb, n, inner).float()
+        o = self._self_attention(t + ".attn1", n1, nb, n, inner, bank=None if write is not None else self._banks.get(p),
+                                 frames=frames)
         if ehs.shape[1] == 1:
             # one key: softmax == 1, attn2 output is the per-CFG-row constant to_out(to_v(e))
             e = ehs.reshape(ehs.shape[0], -1).to(self._dtype).contiguous()
@@ -557,7 +560,10 @@ class UNet3DConditionModel:
         x = hip.ncfhw_to_nhwc(x_in, 64, self._dtype)
         pose = None
         if pose_cond_fea is not None:
-            pose = hip.ncfhw_to_nhwc(pose_cond_fea.to(torch.float32).contiguous(), self.boc[0], self._dtype)
+            if pose_cond_fea.dim() == 4:      # already channels-last ((b f), h, w, 320) in the model dtype (PoseGuider.forward_nhwc)
+                pose = pose_cond_fea.to(self._dtype).contiguous()
+            else:
+                pose = hip.ncfhw_to_nhwc(pose_cond_fea.to(torch.float32).contiguous(), self.boc[0], self._dtype)
         x = hip.conv3x3(x, self.w["conv_in.w"], self.w["conv_in.bias"], residual=pose)
         audio = None
         if audio_embedding is not None:

@@ -155,3 +155,13 @@ def unet3d_spec(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=7
     s["conv_out.weight"] = (out_channels, boc[0], 3, 3)
     s["conv_out.bias"] = (out_channels,)
     return s
+
+
+def unet2d_reference_spec(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768, in_channels=4,
+                          layers_per_block=2):
+    """Keys of the reference's ReferenceNet (src/models/unet_2d_condition.py: SD-1.5 UNet2D without conv_norm_out /
+    conv_out, :645-653): the 3-D table minus motion / audio modules and the output head (682 keys)."""
+    full = unet3d_spec(block_out_channels, cross_attention_dim, cross_attention_dim, in_channels, 4, layers_per_block)
+    return OrderedDict((k, v) for k, v in full.items()
+                       if "motion_modules" not in k and "audio_modules" not in k
+                       and not k.startswith("conv_norm_out") and not k.startswith("conv_out"))

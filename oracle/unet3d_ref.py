@@ -287,6 +287,69 @@ def unet3d_forward(sd: Dict[str, torch.Tensor], cfg: UNet3DConfig, sample, times
     return x.reshape(b, f, -1, hh, ww).permute(0, 2, 1, 3, 4).contiguous()
 
 
+# --------------------------------------------------------------------------------------------- ReferenceNet
+
+def reference_net_banks(sd, cfg: UNet3DConfig, latents, timestep, encoder_hidden_states):
+    """ReferenceNet = the reference's UNet2DConditionModel (src/models/unet_2d_condition.py:872-1308, conv_out disabled
+    :1296-1299) run once per clip in "write" mode: every BasicTransformerBlock stores its LayerNorm'd input
+    (mutual_self_attention.py:139-148).  Returns {reader prefix: (b, N, C)} in module order down -> up -> mid.
+
+    latents (b, 4, h, w); encoder_hidden_states (b, 1, 768).
+    """
+    b, _, hh, ww = latents.shape
+    boc = list(cfg.block_out_channels)
+    t = torch.as_tensor(timestep)
+    t = t.reshape(1).expand(b) if t.dim() == 0 else t.expand(b)
+    emb = timestep_embedding(sd, t, boc[0])
+    banks = {}
+
+    def transformer(p, x):
+        bf, c, h, w = x.shape
+        res = x
+        hdn = _gn(sd, p + ".norm", x, cfg.norm_num_groups, 1e-6)
+        hdn = _conv(sd, p + ".proj_in", hdn, padding=0)
+        inner = hdn.shape[1]
+        hdn = hdn.permute(0, 2, 3, 1).reshape(bf, h * w, inner)
+        tb = p + ".transformer_blocks.0"
+        n1 = _ln(sd, tb + ".norm1", hdn)
+        banks[p] = n1.clone()
+        hdn = attention(sd, tb + ".attn1", n1, n1, cfg.heads) + hdn
+        hdn = attention(sd, tb + ".attn2", _ln(sd, tb + ".norm2", hdn), encoder_hidden_states, cfg.heads) + hdn
+        hdn = feed_forward(sd, tb + ".ff", _ln(sd, tb + ".norm3", hdn)) + hdn
+        hdn = hdn.reshape(bf, h, w, inner).permute(0, 3, 1, 2)
+        return _conv(sd, p + ".proj_out", hdn, padding=0) + res
+
+    x = _conv(sd, "conv_in", latents)
+    skips = [x]
+    for i in range(len(boc)):
+        p = f"down_blocks.{i}"
+        for j in range(cfg.layers_per_block):
+            x = resnet_block(sd, f"{p}.resnets.{j}", x, emb, cfg, 1)
+            if cfg.down_has_attn[i]:
+                x = transformer(f"{p}.attentions.{j}", x)
+            skips.append(x)
+        if i != len(boc) - 1:
+            x = _conv(sd, f"{p}.downsamplers.0.conv", x, stride=2, padding=1)
+            skips.append(x)
+    x = resnet_block(sd, "mid_block.resnets.0", x, emb, cfg, 1)
+    mid_bank_holder = {}
+    x = transformer("mid_block.attentions.0", x)
+    mid = banks.pop("mid_block.attentions.0")
+    x = resnet_block(sd, "mid_block.resnets.1", x, emb, cfg, 1)
+    for i in range(len(boc)):
+        p = f"up_blocks.{i}"
+        for j in range(cfg.layers_per_block + 1):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = resnet_block(sd, f"{p}.resnets.{j}", x, emb, cfg, 1)
+            if cfg.up_has_attn[i]:
+                x = transformer(f"{p}.attentions.{j}", x)
+        if i != len(boc) - 1:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = _conv(sd, f"{p}.upsamplers.0.conv", x)
+    banks["mid_block.attentions.0"] = mid
+    return banks, x
+
+
 # --------------------------------------------------------------------------------------------- side models
 
 def pose_guider_forward(sd, cond):

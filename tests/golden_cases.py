@@ -95,3 +95,16 @@ def side_inputs():
 
 def interp_inputs():
     return dict(v0=hash_uniform("interp.v0", (1, 4, 8, 8), 1.7), v1=hash_uniform("interp.v1", (1, 4, 8, 8), 1.7))
+
+
+REFNET_CASES = {
+    "tiny": dict(block_out_channels=(32, 64, 128, 128), cross_attention_dim=64, latent=8),
+    "full": dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768, latent=8),
+}
+
+
+def refnet_inputs(case, tag="rn"):
+    cad, h = case["cross_attention_dim"], case["latent"]
+    lat = hash_uniform(tag + ".latents", (1, 4, h, h), 1.0).repeat(2, 1, 1, 1)      # same latents in both CFG rows
+    ehs = torch.cat([torch.zeros(1, 1, cad), hash_uniform(tag + ".ehs", (1, 1, cad), 1.0)])
+    return dict(latents=lat, ehs=ehs, timestep=torch.tensor(0))

@@ -198,3 +198,33 @@ def test_unet3d_spec_matches_reference_keys(golden_dir):
     mine = unet3d_spec()
     assert len(ref) == 1526 and set(ref) == set(mine)
     assert all(tuple(ref[k]) == tuple(mine[k]) for k in ref)
+
+
+# ----------------------------------------------------------------------------------------------- ReferenceNet (U10)
+
+def _refnet_oracle(case_name):
+    from mmgt_amd.unet3d_spec import unet2d_reference_spec
+    case = gc.REFNET_CASES[case_name]
+    cfg = R.UNet3DConfig(block_out_channels=case["block_out_channels"], cross_attention_dim=case["cross_attention_dim"])
+    sd = synth_state_dict(unet2d_reference_spec(case["block_out_channels"], case["cross_attention_dim"]), prefix="refnet.")
+    inp = gc.refnet_inputs(case)
+    with torch.no_grad():
+        return R.reference_net_banks(sd, cfg, inp["latents"], inp["timestep"], inp["ehs"])
+
+
+@pytest.mark.parametrize("case_name", ["tiny", "full"])
+def test_reference_net_banks_match_reference(golden_dir, case_name):
+    g = _load(golden_dir, "refnet_" + case_name)
+    banks, sample = _refnet_oracle(case_name)
+    assert list(banks) == [k[len("bank."):] for k in g if k.startswith("bank.")]      # module order down -> up -> mid
+    for k, v in banks.items():
+        torch.testing.assert_close(v, g["bank." + k], **TOL)
+    torch.testing.assert_close(sample, g["sample"], **TOL)
+
+
+def test_unet2d_reference_spec_matches_reference_keys(golden_dir):
+    import json
+    from mmgt_amd.unet3d_spec import unet2d_reference_spec
+    ref = json.load(open(os.path.join(golden_dir, "unet2d_keys_full.json")))
+    mine = unet2d_reference_spec()
+    assert len(ref) == 682 and set(ref) == set(mine) and all(tuple(ref[k]) == tuple(mine[k]) for k in ref)

@@ -1,0 +1,90 @@
+"""ReferenceNet (write mode + bank hand-off), PoseGuider and AudioProjModel on the HIP kernels vs the oracle / the
+reference's golden outputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mmgt_amd.synthetic import synth_state_dict  # noqa: E402
+from oracle import unet3d_ref as R  # noqa: E402
+from tests import golden_cases as gc  # noqa: E402
+
+F32 = dict(rtol=1e-3, atol=1e-4)
+
+
+def _g(golden_dir, name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, name + ".npz")).items()}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_reference_net_banks(golden_dir, dtype):
+    from mmgt_amd.reference_unet import UNet2DConditionModel
+    from mmgt_amd.unet3d_spec import unet2d_reference_spec
+    g = _g(golden_dir, "refnet_full")
+    sd = synth_state_dict(unet2d_reference_spec(), prefix="refnet.", device="cuda:0")
+    m = UNet2DConditionModel(device="cuda:0", dtype=dtype)
+    m.load_state_dict(sd)
+    inp = gc.refnet_inputs(gc.REFNET_CASES["full"])
+    out = m(inp["latents"].cuda(), inp["timestep"], encoder_hidden_states=inp["ehs"].cuda(), return_dict=False)[0]
+    assert list(m.bank) == [k[len("bank."):] for k in g if k.startswith("bank.")]
+    tol = F32 if dtype == torch.float32 else dict(rtol=0, atol=8e-2)
+    for k, v in m.bank.items():
+        torch.testing.assert_close(v.cpu(), g["bank." + k], **tol)
+    torch.testing.assert_close(out.float().cpu(), g["sample"], **(F32 if dtype == torch.float32 else dict(rtol=0, atol=1e-1)))
+
+
+def test_reference_attention_control_handoff(golden_dir):
+    """writer.update -> reader banks: same pairing as the reference, fp16 round trip, then the denoiser runs with them."""
+    from mmgt_amd.reference_unet import ReferenceAttentionControl, UNet2DConditionModel
+    from mmgt_amd.unet3d import UNet3DConditionModel
+    from mmgt_amd.unet3d_spec import unet2d_reference_spec, unet3d_spec
+    ref = UNet2DConditionModel(device="cuda:0", dtype=torch.float32)
+    ref.load_state_dict(synth_state_dict(unet2d_reference_spec(), prefix="refnet.", device="cuda:0"))
+    den = UNet3DConditionModel(device="cuda:0", dtype=torch.float32)
+    sd3 = synth_state_dict(unet3d_spec(), device="cuda:0")
+    den.load_state_dict(sd3)
+    den.enable_gradient_checkpointing()
+    writer = ReferenceAttentionControl(ref, do_classifier_free_guidance=True, mode="write", batch_size=1, fusion_blocks="full")
+    reader = ReferenceAttentionControl(den, do_classifier_free_guidance=True, mode="read", batch_size=1, fusion_blocks="full")
+    rin = gc.refnet_inputs(gc.REFNET_CASES["full"])
+    ref(rin["latents"].cuda(), torch.tensor(0), encoder_hidden_states=rin["ehs"].cuda(), return_dict=False)
+    reader.update(writer)
+    assert set(den._banks) == set(ref.bank) and len(den._banks) == 16
+    case = dict(gc.UNET_CASES["full_cfg1"], frames=2)
+    inp = gc.unet_inputs(case)
+    mv = lambda t: t.cuda()
+    out = den(mv(inp["sample"]), inp["timestep"], encoder_hidden_states=mv(inp["ehs"]), audio_embedding=mv(inp["audio"]),
+              pose_cond_fea=mv(inp["pose"]), full_mask=[mv(x) for x in inp["full"]], face_mask=[mv(x) for x in inp["face"]],
+              body_mask=[mv(x) for x in inp["lips"]], motion_scale=inp["motion_scale"], return_dict=False)[0].cpu()
+    # oracle: same banks (the golden ones = what the reference's ReferenceNet wrote), fp16 round trip inside
+    g = _g(golden_dir, "refnet_full")
+    banks = {k[len("bank."):]: v for k, v in g.items() if k.startswith("bank.")}
+    sd_cpu = {k: v.cpu() for k, v in sd3.items()}
+    with torch.no_grad():
+        want = R.unet3d_forward(sd_cpu, R.UNet3DConfig(), inp["sample"], inp["timestep"], inp["ehs"], inp["audio"],
+                                inp["pose"], inp["full"], inp["face"], inp["lips"], inp["motion_scale"], banks)
+    torch.testing.assert_close(out, want, **F32)
+    reader.clear()
+    writer.clear()
+    assert not den._banks and not ref.bank
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pose_guider_and_audio_proj(golden_dir, dtype):
+    from mmgt_amd.side_models import AudioProjModel, PoseGuider
+    g = _g(golden_dir, "side_models")
+    inp = gc.side_inputs()
+    pg = PoseGuider(320, block_out_channels=(16, 32, 96, 256), device="cuda:0", dtype=dtype)
+    pg.load_state_dict(synth_state_dict(pg.spec, prefix="pose_guider."))
+    out = pg(inp["pose_rgb"].cuda()).cpu()
+    tol = F32 if dtype == torch.float32 else dict(rtol=0, atol=5e-3)
+    torch.testing.assert_close(out, g["pose_guider"], **tol)
+    nhwc = pg.forward_nhwc(inp["pose_rgb"].cuda())
+    assert nhwc.shape == (2, 8, 8, 320) and nhwc.dtype == dtype
+    ap = AudioProjModel(device="cuda:0", dtype=dtype)
+    ap.load_state_dict(synth_state_dict(ap.spec, prefix="audioproj."))
+    out = ap(inp["audio_feats"].cuda()).cpu()
+    torch.testing.assert_close(out, g["audio_proj"], **(F32 if dtype == torch.float32 else dict(rtol=0, atol=6e-2)))

@@ -158,6 +158,36 @@ def gen_side_models():
     save("side_models", pose_guider=pose, audio_proj=aud)
 
 
+def gen_refnet(case_name):
+    """ReferenceNet in write mode: the 16 banks ReferenceAttentionControl.update() would hand to the denoiser."""
+    from src.models.unet_2d_condition import UNet2DConditionModel
+    from src.models.mutual_self_attention import ReferenceAttentionControl
+    from src.models.attention import BasicTransformerBlock
+    case = gc.REFNET_CASES[case_name]
+    cfg = dict(sample_size=64, in_channels=4, out_channels=4, center_input_sample=False, flip_sin_to_cos=True,
+               freq_shift=0, down_block_types=["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"],
+               mid_block_type="UNetMidBlock2DCrossAttn", up_block_types=["UpBlock2D"] + ["CrossAttnUpBlock2D"] * 3,
+               block_out_channels=list(case["block_out_channels"]), layers_per_block=2, downsample_padding=1,
+               mid_block_scale_factor=1, act_fn="silu", norm_num_groups=32, norm_eps=1e-5,
+               cross_attention_dim=case["cross_attention_dim"], attention_head_dim=8)
+    m = UNet2DConditionModel.from_config(cfg).eval()          # from_pretrained => eval (scripts/pose2vid.py:146-148)
+    m.load_state_dict(synth_state_dict(m.state_dict(), prefix="refnet."))
+    ReferenceAttentionControl(m, do_classifier_free_guidance=True, mode="write", batch_size=1, fusion_blocks="full")
+    inp = gc.refnet_inputs(case)
+    with torch.no_grad():
+        out = m(inp["latents"], inp["timestep"], encoder_hidden_states=inp["ehs"], return_dict=False)[0]
+    banks = {}
+    for name, mod in m.named_modules():
+        if isinstance(mod, BasicTransformerBlock):
+            assert len(mod.bank) == 1
+            banks[name.replace(".transformer_blocks.0", "")] = mod.bank[0]
+    print(case_name, "refnet keys", len(m.state_dict()), "banks", len(banks), "out", tuple(out.shape))
+    save("refnet_" + case_name, sample=out, **{"bank." + k: v for k, v in banks.items()})
+    if case_name == "full":
+        import json
+        json.dump({k: list(v.shape) for k, v in m.state_dict().items()}, open(os.path.join(OUT, "unet2d_keys_full.json"), "w"))
+
+
 def gen_interp():
     from src.pipelines.utils import linear, slerp
     inp = gc.interp_inputs()
@@ -173,6 +203,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_grad_enabled(True)
     steps = {"context": gen_context, "interp": gen_interp, "side": gen_side_models, "blocks": gen_blocks,
+             "refnet_tiny": lambda: gen_refnet("tiny"), "refnet_full": lambda: gen_refnet("full"),
              "tiny": lambda: gen_unet("tiny"), "full": lambda: gen_unet("full_cfg1")}
     for k, fn in steps.items():
         if a.only and k != a.only:

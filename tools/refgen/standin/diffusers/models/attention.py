@@ -28,7 +28,7 @@ class FeedForward(nn.Module):
         dim_out = dim_out if dim_out is not None else dim
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out)])
 
-    def forward(self, x):
+    def forward(self, x, scale=1.0):
         for m in self.net:
             x = m(x)
         return x

@@ -71,3 +71,11 @@ class AttnProcessor2_0:
 
 
 AttentionProcessor = Union[AttnProcessor, AttnProcessor2_0]
+
+
+class AttnAddedKVProcessor:
+    pass
+
+
+ADDED_KV_ATTENTION_PROCESSORS = (AttnAddedKVProcessor,)
+CROSS_ATTENTION_PROCESSORS = (AttnProcessor, AttnProcessor2_0)

@@ -36,11 +36,31 @@ class Timesteps(nn.Module):
 
 
 class TimestepEmbedding(nn.Module):
-    def __init__(self, in_channels, time_embed_dim, act_fn="silu"):
+    def __init__(self, in_channels, time_embed_dim, act_fn="silu", out_dim=None, post_act_fn=None, cond_proj_dim=None):
         super().__init__()
+        assert act_fn == "silu" and post_act_fn is None and cond_proj_dim is None and out_dim is None
         self.linear_1 = nn.Linear(in_channels, time_embed_dim)
         self.act = nn.SiLU()
         self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
 
-    def forward(self, sample):
+    def forward(self, sample, condition=None):
         return self.linear_2(self.act(self.linear_1(sample)))
+
+
+def _stub(name):
+    class _S(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError(name)
+    _S.__name__ = name
+    return _S
+
+
+GaussianFourierProjection = _stub("GaussianFourierProjection")
+ImageHintTimeEmbedding = _stub("ImageHintTimeEmbedding")
+ImageProjection = _stub("ImageProjection")
+ImageTimeEmbedding = _stub("ImageTimeEmbedding")
+PositionNet = _stub("PositionNet")
+TextImageProjection = _stub("TextImageProjection")
+TextImageTimeEmbedding = _stub("TextImageTimeEmbedding")
+TextTimeEmbedding = _stub("TextTimeEmbedding")
+CaptionProjection = _stub("CaptionProjection")

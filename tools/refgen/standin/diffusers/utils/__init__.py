@@ -26,3 +26,22 @@ class _Logging:
 
 
 logging = _Logging()
+
+
+USE_PEFT_BACKEND = False
+
+
+def deprecate(*a, **k):
+    pass
+
+
+def is_torch_version(op, ver):
+    return True
+
+
+def scale_lora_layers(*a, **k):
+    pass
+
+
+def unscale_lora_layers(*a, **k):
+    pass
