@@ -24,9 +24,18 @@
 #include "common.h"
 #include "mmgt_hip.h"
 
+// Main-loop variant (A/B-able by building a second library with -DMMGT_GEMM_VARIANT=n, tools/ab_gemm.py):
+//   bit 0: fragments of K-step ks+1 are read while the MFMAs of K-step ks run (register double buffering) + s_setprio
+//   bit 1: dense 8-wave tiles spread the next chunk's LDS-DMA issue between the MFMA groups instead of one burst
+#ifndef MMGT_GEMM_VARIANT
+#define MMGT_GEMM_VARIANT 3
+#endif
+
 namespace {
 
 constexpr int ROWB = 128;  // bytes of K per tile row per chunk
+constexpr bool V_FRAGDB = (MMGT_GEMM_VARIANT & 1) != 0;
+constexpr bool V_ILV = (MMGT_GEMM_VARIANT & 2) != 0;
 
 __device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
 
@@ -63,9 +72,9 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// MODE 0 dense, 1 conv3x3.  WM x WN waves (WM * WN == 4).
+// MODE 0 dense, 1 conv3x3.  WM x WN waves (4 or 8 per workgroup).
 template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(256) void gemm_kernel(ADesc ad, const char* __restrict__ W, long bsw, Epi ep, int M, int N,
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ADesc ad, const char* __restrict__ W, long bsw, Epi ep, int M, int N,
                                                    int K, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr int ESZ = sizeof(T);
@@ -73,8 +82,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(ADesc ad, const char* __restr
   constexpr int KS = BK / 16;                    // MFMA K-steps per chunk
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int GA = BM / 8 / 4, GB = BN / 8 / 4;   // 8-row LDS-DMA groups per wave for A and B
-  static_assert(WM * WN == 4 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile");
+  constexpr int NW = WM * WN;
+  constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;   // 8-row LDS-DMA groups per wave for A and B
+  static_assert((NW == 4 || NW == 8) && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && BM % (8 * NW) == 0 &&
+                    BN % (8 * NW) == 0, "tile");
 
   const int nwg = tiles_m * tiles_n;
   int bid = blockIdx.x;
@@ -124,12 +135,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(ADesc ad, const char* __restr
     wptr[i] = reinterpret_cast<const char*>(wbase + (long)n * K) + chunk * 16;
   }
 
-  auto issue = [&](int ch) {  // chunk index -> LDS stage ch % NSTAGE
-    char* st = smem + (ch % NSTAGE) * STAGE_BYTES;
+  // LDS-DMA ops of one chunk are issued in slices spread between the MFMA groups of the previous chunk (a burst of 8
+  // global_load_lds costs as many issue cycles as the chunk's 16 MFMAs).  `prep` resolves the per-lane source pointers
+  // of the A operand once per chunk (conv: tap / channel decomposition + padding test), `issue` only launches DMAs.
+  const char* asrc[GA];
+  auto prep = [&](int ch) {
     const long kb = (long)ch * ROWB;   // byte offset along K
     if (MODE == 0) {
 #pragma unroll
-      for (int i = 0; i < GA; ++i) glds16(aptr[i] + kb, st + (wid * GA + i) * 1024);
+      for (int i = 0; i < GA; ++i) asrc[i] = aptr[i] + kb;
     } else {
       const int cin = ad.C0 + ad.C1;
       const int kc = ch * BK;
@@ -148,12 +162,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(ADesc ad, const char* __restr
         const int sy = ad.up ? iy >> 1 : iy, sx = ad.up ? ix >> 1 : ix;
         const char* p = reinterpret_cast<const char*>(base + (((long)cn[i] * ad.IH + sy) * ad.IW + sx) * cpp + cc) +
                         achunk[i];
-        if (!ok) p = reinterpret_cast<const char*>(g_zero_page) + spos * 16;
-        glds16(p, st + (wid * GA + i) * 1024);
+        asrc[i] = ok ? p : reinterpret_cast<const char*>(g_zero_page) + spos * 16;
       }
     }
+  };
+  auto issue = [&](int ch, int part, int nparts) {  // chunk index -> LDS stage ch % NSTAGE
+    char* st = smem + (ch % NSTAGE) * STAGE_BYTES;
+    const long kb = (long)ch * ROWB;
 #pragma unroll
-    for (int i = 0; i < GB; ++i) glds16(wptr[i] + kb, st + A_BYTES + (wid * GB + i) * 1024);
+    for (int i = 0; i < GA; ++i)
+      if (i % nparts == part) glds16(asrc[i], st + (wid * GA + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < GB; ++i)
+      if (i % nparts == part) glds16(wptr[i] + kb, st + A_BYTES + (wid * GB + i) * 1024);
   };
 
   f32x16 acc[TM][TN];
@@ -168,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(ADesc ad, const char* __restr
   const int nchunks = K / BK;
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < nchunks) issue(s);
+    if (s < nchunks) { prep(s); issue(s, 0, 1); }
 
   for (int ch = 0; ch < nchunks; ++ch) {
     // chunk ch must have landed; chunks ch+1 .. ch+NSTAGE-2 may stay in flight (each is GA + GB LDS-DMA ops per wave)
@@ -176,23 +197,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(ADesc ad, const char* __restr
     else if (NSTAGE == 3 || ch + 2 >= nchunks) wait_vmcnt<(GA + GB)>();
     else wait_vmcnt<2 * (GA + GB)>();
     __builtin_amdgcn_s_barrier();
-    if (ch + NSTAGE - 1 < nchunks) issue(ch + NSTAGE - 1);
+    // Spreading the DMA issue between MFMA groups pays for the dense 8-wave tiles (+7% at 8192^3); for the conv gather
+    // and the 4-wave tiles the burst right after the barrier measured faster.
+    constexpr bool ILV = V_ILV && (NW == 8 && MODE == 0);
+    const bool more = ch + NSTAGE - 1 < nchunks;
+    if (more) {
+      prep(ch + NSTAGE - 1);
+      if (!ILV) issue(ch + NSTAGE - 1, 0, 1);
+    }
 
     const char* st = smem + (ch % NSTAGE) * STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      Frag<T> fa[TM], fb[TN];
+    // fragments of K-step ks+1 are read from LDS while the MFMAs of K-step ks run (register double buffering)
+    Frag<T> fa[2][TM], fb[2][TN];
+    auto load_frags = [&](int ks, Frag<T>* pa, Frag<T>* pb) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int r = arow + 32 * i;
         const int sw = (r >> 1) & 7;
         if (ESZ == 2) {
-          frag_load(fa[i], reinterpret_cast<const T*>(st + r * ROWB + (((2 * ks + lh) ^ sw) << 4)));
+          frag_load(pa[i], reinterpret_cast<const T*>(st + r * ROWB + (((2 * ks + lh) ^ sw) << 4)));
         } else {
           const f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * ROWB + (((4 * ks + 2 * lh) ^ sw) << 4));
           const f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * ROWB + (((4 * ks + 2 * lh + 1) ^ sw) << 4));
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { fa[i].set(j, lo[j]); fa[i].set(4 + j, hi[j]); }
+          for (int j = 0; j < 4; ++j) { pa[i].set(j, lo[j]); pa[i].set(4 + j, hi[j]); }
         }
       }
 #pragma unroll
@@ -201,18 +229,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(ADesc ad, const char* __restr
         const int sw = (r >> 1) & 7;
         const char* sb = st + A_BYTES;
         if (ESZ == 2) {
-          frag_load(fb[j], reinterpret_cast<const T*>(sb + r * ROWB + (((2 * ks + lh) ^ sw) << 4)));
+          frag_load(pb[j], reinterpret_cast<const T*>(sb + r * ROWB + (((2 * ks + lh) ^ sw) << 4)));
         } else {
           const f32x4 lo = *reinterpret_cast<const f32x4*>(sb + r * ROWB + (((4 * ks + 2 * lh) ^ sw) << 4));
           const f32x4 hi = *reinterpret_cast<const f32x4*>(sb + r * ROWB + (((4 * ks + 2 * lh + 1) ^ sw) << 4));
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj) { fb[j].set(jj, lo[jj]); fb[j].set(4 + jj, hi[jj]); }
+          for (int jj = 0; jj < 4; ++jj) { pb[j].set(jj, lo[jj]); pb[j].set(4 + jj, hi[jj]); }
         }
+      }
+    };
+    if (V_FRAGDB) load_frags(0, fa[0], fb[0]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (V_FRAGDB) {
+        if (ks + 1 < KS) load_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+        __builtin_amdgcn_s_setprio(1);
+      } else {
+        load_frags(ks, fa[ks & 1], fb[ks & 1]);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) mma32(acc[i][j], fa[i], fb[j]);
+        for (int j = 0; j < TN; ++j) mma32(acc[i][j], fa[ks & 1][i], fb[ks & 1][j]);
+      if (V_FRAGDB) __builtin_amdgcn_s_setprio(0);
+      if (ILV && more) issue(ch + NSTAGE - 1, ks, KS);   // this slice's LDS-DMA issues under the MFMAs just queued
     }
   }
 
@@ -340,7 +380,7 @@ int launch_cfg(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, i
   dim3 grid(tiles_m * tiles_n, 1, batch);
   constexpr int TN = BN / WN / 32;
   const size_t stage = (size_t)NSTAGE * (BM + BN) * ROWB;
-  const size_t epi = (size_t)4 * 32 * (32 * TN + 4) * 4;
+  const size_t epi = (size_t)(WM * WN) * 32 * (32 * TN + 4) * 4;
   const size_t lds = stage > epi ? stage : epi;
   auto kern = gemm_kernel<T, MODE, BM, BN, WM, WN, NSTAGE>;
   static bool attr_done = false;
@@ -348,7 +388,7 @@ int launch_cfg(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, i
     hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, ad, reinterpret_cast<const char*>(W), bsw, ep, M, N, K, tiles_m,
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, ad, reinterpret_cast<const char*>(W), bsw, ep, M, N, K, tiles_m,
                      tiles_n);
   MMGT_LAUNCH_CHECK();
   return 0;
@@ -363,18 +403,28 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
   const bool geglu = ep.act == 1;
   int cfg = g_gemm_cfg;
   if (cfg == 0) {
-    // measured on MI355X (tools/bench_kernels.py): the 2-stage 128x128 tile (2 workgroups / CU) wins on compute-bound
-    // shapes; 128x64 (3 workgroups / CU) wins on short reductions, narrow outputs and grids that would not fill the chip.
+    // Measured on MI355X with tools/ab_gemm.py / tools/bench_kernels.py (one process, one device):
+    //   cfg 6 (256x128, 8 waves, 3-deep ring)  long reductions, GEGLU, and the widest L0 projections;
+    //   cfg 1 (128x128, 2 workgroups / CU)      the conv gather;
+    //   cfg 3 (128x64, 3 workgroups / CU)       short reductions, narrow outputs, grids that would not fill the chip.
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
-    cfg = (!geglu && ((MODE == 0 && (K <= 640 || N <= 320)) || tiles128 < 512)) ? 3 : 1;
+    const long tiles256 = (long)((M + 255) / 256) * ((N + 127) / 128) * batch;
+    if (MODE == 1) cfg = tiles128 < 512 ? 3 : 1;
+    else if (geglu) cfg = tiles256 >= 256 ? 6 : 1;
+    else if (K >= 1280) cfg = tiles256 >= 256 ? 6 : 3;
+    else if (M >= 131072 && N >= 640) cfg = 6;
+    else cfg = 3;
   }
-  if (geglu && cfg > 2) cfg = 1;
+  if (geglu && (cfg == 3 || cfg == 4 || cfg == 5 || cfg >= 8)) cfg = 1;
   switch (cfg) {
     case 1: return launch_cfg<T, MODE, 128, 128, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
     case 2: return launch_cfg<T, MODE, 128, 128, 2, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
     case 3: return launch_cfg<T, MODE, 128, 64, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
     case 4: return launch_cfg<T, MODE, 128, 64, 2, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
-    default: return launch_cfg<T, MODE, 64, 64, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
+    case 5: return launch_cfg<T, MODE, 64, 64, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
+    case 6: return launch_cfg<T, MODE, 256, 128, 4, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
+    case 7: return launch_cfg<T, MODE, 256, 128, 4, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
+    default: return launch_cfg<T, MODE, 256, 64, 4, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
   }
 }
 
