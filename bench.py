@@ -69,6 +69,17 @@ def cpu_baseline(sd_cpu, frames_sample=2):
             "cpu": _cpu_name()}
 
 
+def pmc_traffic():
+    """HBM-side bytes per denoise step from the committed rocprofv3 PMC passes (profiles/r*/pmc_traffic*.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate runs of this same command, gfx950 FETCH_SIZE x2 correction applied)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic*.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    return d["total_GB_per_step"] * 1e9, os.path.relpath(files[-1], ROOT)
+
+
 def _cpu_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -161,6 +172,7 @@ def main():
     if rank == 0:
         per_gpu = a.steps / elapsed
         ach = ALGO_TFLOP_PER_STEP * a.steps / (dev_ms / 1e3)
+        traffic, traffic_src = pmc_traffic()
         res = {
             "metric": "UNet3D denoise-steps/sec at 512x512x24 bf16", "value": world * per_gpu, "unit": "steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
@@ -170,9 +182,10 @@ def main():
                                    "weights", "frames": FRAMES, "latent": [LATENT, LATENT], "parallelism": f"clip-parallel x{world}",
                        "device_ms_per_step_rank0": dev_ms / a.steps},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
+                         "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
                          "note": f"whole denoise step on one GPU: {ALGO_TFLOP_PER_STEP} TFLOP algorithmic per step "
-                                 f"(SURVEY 8d; {EXEC_TFLOP_PER_STEP} as executed by the reference) / HIP-event time"},
+                                 f"(SURVEY 8d; {EXEC_TFLOP_PER_STEP} as executed by the reference) / HIP-event time; "
+                                 f"traffic = bytes per step from {traffic_src}"},
         }
         if sd_cpu is not None:
             res["cpu_baseline"] = cpu_baseline(sd_cpu)

@@ -19,6 +19,7 @@ struct AttnParams {
   long k2_bs, k2_ts, v2_bs, v2_ts;
   int bdiv, k2_bdiv, nk2, seg2_first_batch;
   int nq, nk;
+  int nqb, npairs, heads;
   float scale_log2e;
 };
 
@@ -42,9 +43,25 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.z, head = blockIdx.y;
+  // XCD-aware mapping (1-D grid): workgroup ids are dealt round-robin over the 8 XCDs, so id = slot * 8 + xcd.  All query
+  // blocks of one (batch, head) pair are placed on ONE XCD (pair = xcd + 8 * (slot / nqb)): their K/V tiles are then
+  // re-read from that XCD's L2 instead of crossing the fabric once per query block.
+  int pair, qblk;
+  {
+    const int nqb = p.nqb, npairs = p.npairs;
+    const int id = blockIdx.x;
+    if ((npairs & 7) == 0) {
+      const int xcd = id & 7, slot = id >> 3;
+      pair = xcd + 8 * (slot / nqb);
+      qblk = slot % nqb;
+    } else {
+      pair = id / nqb;
+      qblk = id - pair * nqb;
+    }
+  }
+  const int b = pair / p.heads, head = pair - b * p.heads;
   const int bo = b / p.bdiv, bi = b - bo * p.bdiv;
-  const int q0 = (blockIdx.x * NW + wid) * 32;
+  const int q0 = (qblk * NW + wid) * 32;
 
   const T* qb = reinterpret_cast<const T*>(p.q) + bo * p.q_bs0 + bi * p.q_bs1 + (long)head * HD;
   T* ob = reinterpret_cast<T*>(p.o) + bo * p.o_bs0 + bi * p.o_bs1 + (long)head * HD;
@@ -312,14 +329,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {
 }
 
 template <typename T, int HD>
-int launch_hd(const AttnParams& p, int batch, int heads, int vt, hipStream_t s) {
+int launch_hd(AttnParams p, int batch, int heads, int vt, hipStream_t s) {
   // Short sequences (temporal attention, <= 32 frames) use one wave per workgroup; spatial sequences four.
+  p.heads = heads;
+  p.npairs = batch * heads;
   if (p.nq <= 32) {
-    dim3 grid(1, heads, batch);
+    p.nqb = 1;
+    dim3 grid(batch * heads);
     if (vt) hipLaunchKernelGGL((attn_kernel<T, HD, 1, true>), grid, dim3(64), 0, s, p);
     else hipLaunchKernelGGL((attn_kernel<T, HD, 1, false>), grid, dim3(64), 0, s, p);
   } else {
-    dim3 grid((p.nq + 127) / 128, heads, batch);
+    p.nqb = (p.nq + 127) / 128;
+    dim3 grid((unsigned)((long)p.nqb * batch * heads));
     if (vt) hipLaunchKernelGGL((attn_kernel<T, HD, 4, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((attn_kernel<T, HD, 4, false>), grid, dim3(256), 0, s, p);
   }
@@ -347,7 +368,7 @@ extern "C" int mmgt_attention(const void* q, long q_bs0, long q_bs1, long q_ts, 
   MMGT_CHECK(q && k && v && o, "attention: null pointer");
   MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "attention: bad dtype %d", dtype);
   MMGT_CHECK(batch > 0 && heads > 0 && nq > 0 && nk > 0 && bdiv > 0, "attention: empty problem");
-  MMGT_CHECK(batch <= 65535 && heads <= 65535, "attention: batch %d / heads %d exceed the grid limits", batch, heads);
+  MMGT_CHECK((long)batch * heads * ((nq + 127) / 128) < (1l << 31), "attention: grid too large");
   MMGT_CHECK((k2 == nullptr) == (v2 == nullptr), "attention: k2/v2 must come together");
   MMGT_CHECK(!k2 || (k2_bdiv > 0 && nk2 >= 0), "attention: bad second segment");
   const int esz = dtype == MMGT_BF16 ? 2 : 4;
