@@ -26,7 +26,7 @@ struct AttnParams {
 constexpr int KT = 64;  // keys per LDS tile
 
 template <typename T, int HD, int NW, bool VT>
-__global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {
+__global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_kernel(AttnParams p) {
   constexpr int ESZ = sizeof(T);
   constexpr int VEC = 16 / ESZ;                 // elements per 16-byte vector
   constexpr int HDK = (HD + 15) / 16 * 16;      // QK^T reduction length (zero padded)
@@ -159,25 +159,53 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_kernel(AttnParams p) {
     }
   };
 
-  // issue-early / write-late staging (guide T14): the next tile's global loads fly under the current tile's MFMAs
-  auto prefetch = [&](int it) {
-    const TileSrc t = tile_src(it);
+  // issue-early / write-late staging (guide T14): the next tile's global loads fly under the current tile's MFMAs.
+  // Full tiles use running per-thread pointers (two adds per vector per tile: the kernel is VALU-bound, so the address
+  // arithmetic matters); the ragged last tile of a segment recomputes clamped / zero-filled addresses.
+  const T* pk[KVEC];
+  const T* pv[VVEC];
+  auto seg_init = [&](const TileSrc& t) {
 #pragma unroll
     for (int i = 0; i < KVEC; ++i) {
       const int idx = tid + i * NT;
-      if ((i + 1) * NT <= KT * NVK || idx < KT * NVK) rk[i] = load_k(t, idx);
+      const int row = idx / NVK, vc = idx - row * NVK;
+      pk[i] = t.kb + (long)row * t.kts + vc * VEC;
     }
-    if (t.kt + KT <= t.nks) {      // wave-uniform: full tiles take the branch-free path
+#pragma unroll
+    for (int i = 0; i < VVEC; ++i) {
+      const int idx = tid + i * NT;
+      const int row = idx / NVV, vc = idx - row * NVV;
+      pv[i] = VT ? t.vb + ((long)head * HD + row) * t.vts + vc * VEC
+                 : t.vb + (long)row * t.vts + (long)head * HD + vc * VEC;
+    }
+  };
+  auto prefetch = [&](int it) {
+    const TileSrc t = tile_src(it);
+    if (HD <= 80 && t.kt == 0) seg_init(t);
+    if (HD <= 80 && t.kt + KT <= t.nks) {      // wave-uniform: full tiles take the branch-free path
+      const long kstep = (long)KT * t.kts, vstep = VT ? (long)KT : (long)KT * t.vts;
+#pragma unroll
+      for (int i = 0; i < KVEC; ++i) {
+        const int idx = tid + i * NT;
+        if ((i + 1) * NT <= KT * NVK || idx < KT * NVK) rk[i] = *reinterpret_cast<const u32x4*>(pk[i]);
+        pk[i] += kstep;
+      }
 #pragma unroll
       for (int i = 0; i < VVEC; ++i) {
         const int idx = tid + i * NT;
-        if ((i + 1) * NT <= VR * NVV || idx < VR * NVV) rv[i] = load_v(t, idx, true);
+        if ((i + 1) * NT <= VR * NVV || idx < VR * NVV) rv[i] = *reinterpret_cast<const u32x4*>(pv[i]);
+        pv[i] += vstep;
       }
     } else {
 #pragma unroll
+      for (int i = 0; i < KVEC; ++i) {
+        const int idx = tid + i * NT;
+        if ((i + 1) * NT <= KT * NVK || idx < KT * NVK) rk[i] = load_k(t, idx);
+      }
+#pragma unroll
       for (int i = 0; i < VVEC; ++i) {
         const int idx = tid + i * NT;
-        if ((i + 1) * NT <= VR * NVV || idx < VR * NVV) rv[i] = load_v(t, idx, false);
+        if ((i + 1) * NT <= VR * NVV || idx < VR * NVV) rv[i] = load_v(t, idx, HD > 80 && t.kt + KT <= t.nks);
       }
     }
   };
