@@ -139,31 +139,40 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ADesc ad, const char
   // global_load_lds costs as many issue cycles as the chunk's 16 MFMAs).  `prep` resolves the per-lane source pointers
   // of the A operand once per chunk (conv: tap / channel decomposition + padding test), `issue` only launches DMAs.
   const char* asrc[GA];
+  // Chunks are prepared strictly in order, so the conv view keeps a running position (tap, channel): inside one tap and
+  // one source tensor consecutive chunks are 128 B apart, and the (ky, kx) / padding / pixel address arithmetic is redone
+  // only when the tap or the source changes (every Cin / 64 chunks instead of every chunk).
+  int p_tap = 0, p_c = 0;
+  unsigned okbits = 0;
   auto prep = [&](int ch) {
-    const long kb = (long)ch * ROWB;   // byte offset along K
     if (MODE == 0) {
+      const long kb = (long)ch * ROWB;   // byte offset along K
 #pragma unroll
       for (int i = 0; i < GA; ++i) asrc[i] = aptr[i] + kb;
     } else {
       const int cin = ad.C0 + ad.C1;
-      const int kc = ch * BK;
-      const int tap = kc / cin;
-      const int c = kc - tap * cin;
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const int vh = ad.up ? ad.IH * 2 : ad.IH, vw = ad.up ? ad.IW * 2 : ad.IW;
-      const bool second = c >= ad.C0;
-      const T* base = second ? a1 : a0;
-      const long cpp = second ? ad.C1 : ad.C0;
-      const int cc = second ? c - ad.C0 : c;
+      if (p_c == 0 || p_c == ad.C0) {
+        const int ky = p_tap / 3, kx = p_tap - ky * 3;
+        const int vh = ad.up ? ad.IH * 2 : ad.IH, vw = ad.up ? ad.IW * 2 : ad.IW;
+        const bool second = p_c >= ad.C0 && ad.C1 > 0;
+        const T* base = second ? a1 : a0;
+        const long cpp = second ? ad.C1 : ad.C0;
+        okbits = 0;
 #pragma unroll
-      for (int i = 0; i < GA; ++i) {
-        const int iy = coy[i] * ad.stride + ky - 1, ix = cox[i] * ad.stride + kx - 1;
-        const bool ok = iy >= 0 && iy < vh && ix >= 0 && ix < vw;
-        const int sy = ad.up ? iy >> 1 : iy, sx = ad.up ? ix >> 1 : ix;
-        const char* p = reinterpret_cast<const char*>(base + (((long)cn[i] * ad.IH + sy) * ad.IW + sx) * cpp + cc) +
-                        achunk[i];
-        asrc[i] = ok ? p : reinterpret_cast<const char*>(g_zero_page) + spos * 16;
+        for (int i = 0; i < GA; ++i) {
+          const int iy = coy[i] * ad.stride + ky - 1, ix = cox[i] * ad.stride + kx - 1;
+          const bool ok = iy >= 0 && iy < vh && ix >= 0 && ix < vw;
+          const int sy = ad.up ? iy >> 1 : iy, sx = ad.up ? ix >> 1 : ix;
+          const char* p = reinterpret_cast<const char*>(base + (((long)cn[i] * ad.IH + sy) * ad.IW + sx) * cpp) + achunk[i];
+          asrc[i] = ok ? p : reinterpret_cast<const char*>(g_zero_page) + spos * 16;
+          okbits |= ok ? (1u << i) : 0u;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < GA; ++i) asrc[i] += (okbits >> i & 1u) ? ROWB : 0;
       }
+      p_c += BK;
+      if (p_c == cin) { p_c = 0; ++p_tap; }
     }
   };
   auto issue = [&](int ch, int part, int nparts) {  // chunk index -> LDS stage ch % NSTAGE
