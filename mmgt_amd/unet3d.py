@@ -42,6 +42,35 @@ class _Config(dict):
     __getattr__ = dict.__getitem__
 
 
+def default_init(spec, seed=0):
+    """The reference constructor's initialisation for keys no checkpoint provides: nn.Linear / nn.Conv2d default
+    (kaiming-uniform(a=sqrt 5) == U(+-1/sqrt(fan_in)) for weight and bias), norm affine (1, 0), zero_module for the
+    MM-HAA zero-convs and the motion modules' proj_out (attention.py:556-566, motion_module.py:72-75), sinusoid `pe`."""
+    from .synthetic import sinusoid_pe
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    fan = {}
+    for k, shape in spec.items():
+        if k.endswith(".weight") and len(shape) > 1:
+            f = 1
+            for s in shape[1:]:
+                f *= s
+            fan[k[:-len(".weight")]] = f
+    for k, shape in spec.items():
+        leaf = k.rsplit(".", 1)[-1]
+        base = k[:-len(leaf) - 1]
+        if leaf == "pe":
+            out[k] = sinusoid_pe(shape[1], shape[2])
+        elif any(z in k for z in ("zero_conv_", "temporal_transformer.proj_out")):
+            out[k] = torch.zeros(shape)
+        elif len(shape) == 1 and base not in fan:                       # norm affine
+            out[k] = torch.ones(shape) if leaf == "weight" else torch.zeros(shape)
+        else:
+            bound = 1.0 / math.sqrt(fan.get(base, shape[0]))
+            out[k] = (torch.rand(shape, generator=g) * 2 - 1) * bound
+    return out
+
+
 class UNet3DConditionModel:
     _supports_gradient_checkpointing = True
 
@@ -167,10 +196,13 @@ class UNet3DConditionModel:
         for k in self.spec:
             if k in sd and tuple(sd[k].shape) != tuple(self.spec[k]):
                 raise RuntimeError(f"load_state_dict: shape mismatch for {k}: {tuple(sd[k].shape)} vs {self.spec[k]}")
-        if missing:
-            if not self._loaded:
-                raise RuntimeError(f"load_state_dict(strict=False) on an empty model still needs every key; missing "
-                                   f"{len(missing)} e.g. {missing[:3]}")
+        if missing and not self._loaded:
+            # strict=False on a fresh model (from_pretrained_2d, unet_3d.py:710): the reference keeps the constructor's
+            # initialisation for keys the checkpoints do not hold (audio modules before stage-2 training, ...)
+            sd = dict(sd)
+            sd.update(default_init({k: self.spec[k] for k in missing}))
+        elif missing:
+            raise RuntimeError("partial load_state_dict on an already packed model is not supported: pass every key")
         self._pack(sd)
         self._loaded = True
         self._banks = {}

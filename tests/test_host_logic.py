@@ -186,3 +186,37 @@ def test_clip_parallel_plumbing_world_size_2():
         assert p.exitcode == 0
     assert res[0][1] and res[1][1]
     assert res[0][2] == [0, 2, 4] and res[1][2] == [1, 3]
+
+
+# ------------------------------------------------------------------------------------------------ conditioning layout
+def test_process_audio_emb_matches_reference_loop():
+    from mmgt_amd.conditioning import process_audio_emb
+    x = torch.arange(7 * 3, dtype=torch.float32).reshape(7, 3)
+    want = torch.stack([torch.stack([x[max(min(i + j, 6), 0)] for j in range(-2, 3)]) for i in range(7)])   # pose2vid.py:82-88
+    assert torch.equal(process_audio_emb(x), want) and process_audio_emb(x).shape == (7, 5, 3)
+
+
+def test_mask_pyramid_layout():
+    from mmgt_amd.conditioning import full_mask_from_lips, mask_pyramid
+    m = torch.zeros(3, 64, 64, dtype=torch.uint8)
+    m[:, 16:32, 16:32] = 255
+    pyr = mask_pyramid(m, 512)
+    assert [tuple(p.shape) for p in pyr] == [(3, 4096), (3, 1024), (3, 256), (3, 64)]
+    assert float(pyr[0].max()) == 1.0 and all(float(p.min()) >= 0 for p in pyr)
+    torch.testing.assert_close(pyr[0].mean(), pyr[3].mean(), rtol=0.05, atol=0.01)       # area preserved across levels
+    assert float(full_mask_from_lips(pyr)[0].max()) == 2.0
+
+
+def test_default_init_for_missing_checkpoint_keys():
+    from mmgt_amd.unet3d import default_init
+    from mmgt_amd.unet3d_spec import unet3d_spec
+    spec = {k: v for k, v in unet3d_spec().items() if "down_blocks.0.audio_modules.0" in k or "down_blocks.0.motion_modules.0" in k}
+    d = default_init(spec)
+    assert set(d) == set(spec)
+    t = "down_blocks.0.audio_modules.0.transformer_blocks.0"
+    assert d[t + ".zero_conv_full.weight"].abs().sum() == 0 and d[t + ".norm1.weight"].min() == 1
+    w = d[t + ".attn1.to_q.weight"]
+    assert w.abs().max() <= 1 / 320 ** 0.5 and w.std() > 0.02
+    assert d["down_blocks.0.motion_modules.0.temporal_transformer.proj_out.weight"].abs().sum() == 0
+    pe = d["down_blocks.0.motion_modules.0.temporal_transformer.transformer_blocks.0.attention_blocks.0.pos_encoder.pe"]
+    assert pe.shape == (1, 32, 320) and pe[0, 0, 1] == 1
