@@ -76,7 +76,20 @@ __device__ __forceinline__ void frag_load(Frag<float>& f, const float* p) {
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+// Exact-erf GELU, x * Phi(x), with Phi from Abramowitz & Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. fp32 round-off level;
+// the libm erff costs ~4x more VALU issue slots and made the GEGLU epilogue longer than a K = 320 main loop).
+//   erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3 + a4 t^4 + a5 t^5) exp(-z^2),  t = 1 / (1 + p z),  z = |x| / sqrt(2)
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  poly *= t;
+  const float h = 0.5f * poly * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);   // 0.5 * exp(-x^2 / 2)
+  return x * (x >= 0.f ? 1.0f - h : h);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ADesc ad, const char
   // N = K = 320 projections).  They are the oldest VMEM ops, so the counted vmcnt waits below are unaffected.
   constexpr int EVPR = (32 * TN) / 8;               // 8-column vectors per row of a wave's 32-row slab
   constexpr int ENV = EVPR / 2;                     // vectors per lane per slab (32 rows x EVPR / 64 lanes)
-  constexpr bool RES_PF = ESZ == 2;
+  constexpr bool RES_PF = ESZ == 2 && TN <= 2;      // wide wave tiles have no registers to spare for it
   u32x4 rres[RES_PF ? TM : 1][RES_PF ? ENV : 1];
   const bool res_pf = RES_PF && ep.residual != nullptr && ep.fast && ep.act != 1;
   if (res_pf) {
