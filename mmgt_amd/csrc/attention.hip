@@ -78,14 +78,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
       const int d = 16 * ks + 8 * lh;
       if (d < HD) frag_load(qf[ks], qrow + d);
       else qf[ks].zero();
+      // fold softmax scale * log2(e) into Q once: the MFMA then yields scores directly in the exp2 domain
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[ks].set(j, frag_get(qf[ks], j) * p.scale_log2e);
     }
   }
 
   f32x16 o[DT];
 #pragma unroll
   for (int i = 0; i < DT; ++i) o[i] = (f32x16)(0.f);
-  float m_run = -1e30f, l_run = 0.f;
-  const float c = p.scale_log2e;
+  // Online softmax in the log2 domain.  The running reference M enters the score MFMA chain as its initial accumulator
+  // (-M per query column), so exp2 applies to the accumulator as it stands: no per-element subtract (the kernel is
+  // VALU-bound).  When some query's tile maximum exceeds its reference (wave-uniform test) the tile takes the slow path:
+  // shift the scores, move M, rescale O and l -- exactly the classic update.
+  float m_run = 0.f, l_run = 0.f;
 
   // ---- tile schedule: segment 0 = own keys, segment 1 = bank keys (conditional CFG half only) ----
   const bool has2 = p.k2 != nullptr && p.nk2 > 0 && b >= p.seg2_first_batch;
@@ -239,11 +245,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
     __syncthreads();
     if (PF && it + 1 < ntiles) prefetch(it + 1);
 
-    // ---- S^T = K . Q^T for the two 32-key sub-tiles ----
+    // ---- S^T - M = K . Q'^T - M for the two 32-key sub-tiles ----
     f32x16 s[2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
-      s[sub] = (f32x16)(0.f);
+      s[sub] = (f32x16)(-m_run);
       const char* kp = lK + (sub * 32 + lr) * RSK + lh * 8 * ESZ;
 #pragma unroll
       for (int ks = 0; ks < KSQ; ++ks) {
@@ -252,7 +258,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
         mma32(s[sub], kf, qf[ks]);
       }
     }
-    // ---- online softmax over this tile's 64 keys (lane = query column) ----
     if (kt + KT > nks) {   // ragged last tile only: mask the keys past the end
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub)
@@ -264,24 +269,26 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
 #pragma unroll
     for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(s[0][r], s[1][r]));
     mt = fmaxf(mt, __shfl_xor(mt, 32));
-    const float m_new = fmaxf(m_run, mt);
-    const float mc = m_new * c;
+    if (it == 0 || __any(mt > 0.f)) {
+      // the first tile fixes M at the tile maximum (either sign); later tiles only ever raise it
+      const float delta = it == 0 ? mt : fmaxf(mt, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      m_run += delta;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) o[i] *= alpha;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) s[sub] -= delta;
+    }
     float ls = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(s[sub][r] * c - mc);   // raw v_exp_f32 (inputs <= 0, flush is fine)
+        const float pv = __builtin_amdgcn_exp2f(s[sub][r]);
         s[sub][r] = pv;
         ls += pv;
       }
-    if (__any(m_new > m_run)) {   // wave-uniform: rescale only when some query's running max moved
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < DT; ++i) o[i] *= alpha;
-      m_run = m_new;
-    }
     l_run += ls;
 
     // ---- O^T += V^T . P^T ----

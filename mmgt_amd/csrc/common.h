@@ -73,6 +73,9 @@ __device__ __forceinline__ void frag_load(Frag<float>& f, const float* p) {
   for (int j = 0; j < 4; ++j) { f.v[j] = lo[j]; f.v[4 + j] = hi[j]; }
 }
 
+__device__ __forceinline__ float frag_get(const Frag<bf16_t>& f, int j) { return bf16_to_f32((bf16_t)f.v[j]); }
+__device__ __forceinline__ float frag_get(const Frag<float>& f, int j) { return f.v[j]; }
+
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
