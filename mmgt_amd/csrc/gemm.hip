@@ -73,6 +73,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // MODE 0 dense, 1 conv3x3.  WM x WN waves (4 or 8 per workgroup).
+//
+// The grid is persistent: workgroup b computes tiles b, b + gridDim.x, ... and the chunk stream of its LDS ring keeps
+// rolling across tile boundaries -- while the last chunks of tile t are multiplied the first chunks of tile t + 1 are
+// already in flight, and the epilogue of tile t (which borrows the ring stage consumed last) runs with them landing
+// and its stores draining under the next main loop.  Measured before this: a 256 x 128 tile paid about 7 us of launch +
+// first-load latency + store drain per tile, as much as a K = 640 main loop.
 template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ADesc ad, const char* __restrict__ W, long bsw, Epi ep, int M, int N,
                                                    int K, int tiles_m, int tiles_n) {
@@ -88,17 +94,19 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ADesc ad, const char
                     BN % (8 * NW) == 0, "tile");
 
   const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-  }
-  const int tm = bid / tiles_n, tn = bid % tiles_n;
   const int bz = blockIdx.z;
-
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid % WN;
   const int lr = lane & 31, lh = lane >> 5;
+
+  // virtual tile id -> (tm, tn): XCD x (= id & 7, the hardware's round-robin placement) owns a contiguous run of tiles,
+  // n fastest, so the tiles that share an A row panel are computed next to each other on one L2.
+  auto decode = [&](int v, int& tm, int& tn) {
+    const int q = nwg >> 3, r = nwg & 7, x = v & 7;
+    const int t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (v >> 3);
+    tm = t / tiles_n;
+    tn = t - tm * tiles_n;
+  };
 
   // ---- LDS-DMA source addressing: wave `wid` fills 8-row groups g = wid * GA + i; lane -> (row l>>3, slot l&7) ----
   const int srow = lane >> 3, spos = lane & 7;
@@ -109,41 +117,45 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ADesc ad, const char
   const char* aptr[GA];      // dense: pointer to (row, swizzled chunk) at k = 0
   int cn[GA], coy[GA], cox[GA], achunk[GA];
   const char* wptr[GB];
-#pragma unroll
-  for (int i = 0; i < GA; ++i) {
-    const int row = (wid * GA + i) * 8 + srow;
-    const int chunk = spos ^ ((row >> 1) & 7);
-    int m = tm * BM + row;
-    if (m >= M) m = M - 1;
-    if (MODE == 0) {
-      aptr[i] = reinterpret_cast<const char*>(a0 + (long)m * ad.ld0) + chunk * 16;
-    } else {
-      const int hw = ad.OH * ad.OW;
-      cn[i] = m / hw;
-      const int rem = m - cn[i] * hw;
-      coy[i] = rem / ad.OW;
-      cox[i] = rem - coy[i] * ad.OW;
-      achunk[i] = chunk * 16;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < GB; ++i) {
-    const int row = (wid * GB + i) * 8 + srow;
-    const int chunk = spos ^ ((row >> 1) & 7);
-    int n = tn * BN + row;
-    if (n >= N) n = N - 1;
-    wptr[i] = reinterpret_cast<const char*>(wbase + (long)n * K) + chunk * 16;
-  }
-
-  // LDS-DMA ops of one chunk are issued in slices spread between the MFMA groups of the previous chunk (a burst of 8
-  // global_load_lds costs as many issue cycles as the chunk's 16 MFMAs).  `prep` resolves the per-lane source pointers
-  // of the A operand once per chunk (conv: tap / channel decomposition + padding test), `issue` only launches DMAs.
-  const char* asrc[GA];
   // Chunks are prepared strictly in order, so the conv view keeps a running position (tap, channel): inside one tap and
   // one source tensor consecutive chunks are 128 B apart, and the (ky, kx) / padding / pixel address arithmetic is redone
   // only when the tap or the source changes (every Cin / 64 chunks instead of every chunk).
   int p_tap = 0, p_c = 0;
   unsigned okbits = 0;
+  auto setup = [&](int tm, int tn) {   // operand addresses of tile (tm, tn), the tile the DMA stream is in
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+      const int row = (wid * GA + i) * 8 + srow;
+      const int chunk = spos ^ ((row >> 1) & 7);
+      int m = tm * BM + row;
+      if (m >= M) m = M - 1;
+      if (MODE == 0) {
+        aptr[i] = reinterpret_cast<const char*>(a0 + (long)m * ad.ld0) + chunk * 16;
+      } else {
+        const int hw = ad.OH * ad.OW;
+        cn[i] = m / hw;
+        const int rem = m - cn[i] * hw;
+        coy[i] = rem / ad.OW;
+        cox[i] = rem - coy[i] * ad.OW;
+        achunk[i] = chunk * 16;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      const int row = (wid * GB + i) * 8 + srow;
+      const int chunk = spos ^ ((row >> 1) & 7);
+      int n = tn * BN + row;
+      if (n >= N) n = N - 1;
+      wptr[i] = reinterpret_cast<const char*>(wbase + (long)n * K) + chunk * 16;
+    }
+    p_tap = 0;
+    p_c = 0;
+  };
+
+  // LDS-DMA ops of one chunk are issued in slices spread between the MFMA groups of the previous chunk (a burst of 8
+  // global_load_lds costs as many issue cycles as the chunk's 16 MFMAs).  `prep` resolves the per-lane source pointers
+  // of the A operand once per chunk (conv: tap / channel decomposition + padding test), `issue` only launches DMAs.
+  const char* asrc[GA];
   auto prep = [&](int ch) {
     if (MODE == 0) {
       const long kb = (long)ch * ROWB;   // byte offset along K
@@ -175,8 +187,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ADesc ad, const char
       if (p_c == cin) { p_c = 0; ++p_tap; }
     }
   };
-  auto issue = [&](int ch, int part, int nparts) {  // chunk index -> LDS stage ch % NSTAGE
-    char* st = smem + (ch % NSTAGE) * STAGE_BYTES;
+  auto issue = [&](int stage, int ch, int part, int nparts) {  // chunk `ch` of the DMA-side tile -> LDS stage `stage`
+    char* st = smem + stage * STAGE_BYTES;
     const long kb = (long)ch * ROWB;
 #pragma unroll
     for (int i = 0; i < GA; ++i)
@@ -186,243 +198,334 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ADesc ad, const char
       if (i % nparts == part) glds16(wptr[i] + kb, st + A_BYTES + (wid * GB + i) * 1024);
   };
 
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16)(0.f);
-
   // fragment read addressing: row r of the tile, 16-byte chunk c  ->  r * 128 + ((c ^ ((r >> 1) & 7)) * 16)
   const int arow = wm * (BM / WM) + lr, brow = wn * (BN / WN) + lr;   // + 32 * tile index (keeps (row>>1)&7 pattern)
 
-  // ---- residual prefetch (bf16 fast path): the epilogue's residual vectors are requested before the main loop, so
-  // their HBM latency hides under it instead of being exposed once per 32-row slab (measured: -35% on the L0
-  // N = K = 320 projections).  They are the oldest VMEM ops, so the counted vmcnt waits below are unaffected.
-  constexpr int EVPR = (32 * TN) / 8;               // 8-column vectors per row of a wave's 32-row slab
-  constexpr int ENV = EVPR / 2;                     // vectors per lane per slab (32 rows x EVPR / 64 lanes)
-  constexpr bool RES_PF = ESZ == 2 && TN <= 2;      // wide wave tiles have no registers to spare for it
-  u32x4 rres[RES_PF ? TM : 1][RES_PF ? ENV : 1];
-  const bool res_pf = RES_PF && ep.residual != nullptr && ep.fast && ep.act != 1;
-  if (res_pf) {
-    const T* resb = reinterpret_cast<const T*>(ep.residual) + (long)bz * ep.bsr;
-    const int row0p = tm * BM + wm * (BM / WM), col0p = tn * BN + wn * (BN / WN);
-#pragma unroll
-    for (int i = 0; i < (RES_PF ? TM : 1); ++i)
-#pragma unroll
-      for (int t = 0; t < (RES_PF ? ENV : 1); ++t) {
-        const int v = lane + 64 * t;
-        const int rr = v / EVPR, hc = (v - rr * EVPR) * 8;
-        const int m = row0p + i * 32 + rr, n = col0p + hc;
-        rres[i][t] = (m < M && n < N) ? *reinterpret_cast<const u32x4*>(resb + (long)m * ep.ldr + n) : (u32x4)(0u);
-      }
-  }
-
-  const int nchunks = K / BK;
-#pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < nchunks) { prep(s); issue(s, 0, 1); }
-
-  for (int ch = 0; ch < nchunks; ++ch) {
-    // chunk ch must have landed; chunks ch+1 .. ch+NSTAGE-2 may stay in flight (each is GA + GB LDS-DMA ops per wave)
-    if (NSTAGE == 2 || ch + 1 >= nchunks) wait_vmcnt<0>();
-    else if (NSTAGE == 3 || ch + 2 >= nchunks) wait_vmcnt<(GA + GB)>();
-    else wait_vmcnt<2 * (GA + GB)>();
-    __builtin_amdgcn_s_barrier();
-    // Spreading the DMA issue between MFMA groups pays for the dense 8-wave tiles (+7% at 8192^3); for the conv gather
-    // and the 4-wave tiles the burst right after the barrier measured faster.
-    constexpr bool ILV = V_ILV && (NW == 8 && MODE == 0);
-    const bool more = ch + NSTAGE - 1 < nchunks;
-    if (more) {
-      prep(ch + NSTAGE - 1);
-      if (!ILV) issue(ch + NSTAGE - 1, 0, 1);
-    }
-
-    const char* st = smem + (ch % NSTAGE) * STAGE_BYTES;
-    // fragments of K-step ks+1 are read from LDS while the MFMAs of K-step ks run (register double buffering)
-    Frag<T> fa[2][TM], fb[2][TN];
-    auto load_frags = [&](int ks, Frag<T>* pa, Frag<T>* pb) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int r = arow + 32 * i;
-        const int sw = (r >> 1) & 7;
-        if (ESZ == 2) {
-          frag_load(pa[i], reinterpret_cast<const T*>(st + r * ROWB + (((2 * ks + lh) ^ sw) << 4)));
-        } else {
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * ROWB + (((4 * ks + 2 * lh) ^ sw) << 4));
-          const f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * ROWB + (((4 * ks + 2 * lh + 1) ^ sw) << 4));
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { pa[i].set(j, lo[j]); pa[i].set(4 + j, hi[j]); }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int r = brow + 32 * j;
-        const int sw = (r >> 1) & 7;
-        const char* sb = st + A_BYTES;
-        if (ESZ == 2) {
-          frag_load(pb[j], reinterpret_cast<const T*>(sb + r * ROWB + (((2 * ks + lh) ^ sw) << 4)));
-        } else {
-          const f32x4 lo = *reinterpret_cast<const f32x4*>(sb + r * ROWB + (((4 * ks + 2 * lh) ^ sw) << 4));
-          const f32x4 hi = *reinterpret_cast<const f32x4*>(sb + r * ROWB + (((4 * ks + 2 * lh + 1) ^ sw) << 4));
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) { pb[j].set(jj, lo[jj]); pb[j].set(4 + jj, hi[jj]); }
-        }
-      }
-    };
-    if (V_FRAGDB) load_frags(0, fa[0], fb[0]);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (V_FRAGDB) {
-        if (ks + 1 < KS) load_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-        __builtin_amdgcn_s_setprio(1);
-      } else {
-        load_frags(ks, fa[ks & 1], fb[ks & 1]);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) mma32(acc[i][j], fa[ks & 1][i], fb[ks & 1][j]);
-      if (V_FRAGDB) __builtin_amdgcn_s_setprio(0);
-      if (ILV && more) issue(ch + NSTAGE - 1, ks, KS);   // this slice's LDS-DMA issues under the MFMAs just queued
-    }
-  }
-
-  // ---- epilogue: per wave, 32 rows at a time through LDS (row-major fp32, 4-float pad), then 8-column vectors ----
-  __syncthreads();   // every wave is done with the operand stages
+  // ---- epilogue geometry: per wave, SLAB rows at a time through LDS (row-major fp32, 4-float pad), then 8-column
+  // vectors.  The transpose buffer of all waves must fit into ONE ring stage (the other stages hold the next tile).
   constexpr int WCOLS = 32 * TN;
   constexpr int ESTR = WCOLS + 4;
-  float* ebuf = reinterpret_cast<float*>(smem) + wid * 32 * ESTR;
-  T* out = reinterpret_cast<T*>(ep.out) + (long)bz * ep.bso;
-  const T* res = ep.residual ? reinterpret_cast<const T*>(ep.residual) + (long)bz * ep.bsr : nullptr;
-  const int row0 = tm * BM + wm * (BM / WM), col0 = tn * BN + wn * (BN / WN);
-  const bool geglu = ep.act == 1;
-  constexpr int VPR = (32 * TN) / 8;                 // 8-column vectors per row
-  const float* zero = reinterpret_cast<const float*>(g_zero_page);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ebuf[acc_row(r, lane) * ESTR + j * 32 + lr] = acc[i][j][r];
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int nvec = geglu ? 32 * (VPR / 2) : 32 * VPR;
-#pragma unroll
-    for (int t = 0; t < ENV; ++t) {
-      const int v = lane + 64 * t;
-      if (v >= nvec) continue;
-      int rr, hcol, ncol;      // row in the 32-row slab, column of the (h) vector inside the wave tile, global column
-      long ocol;
-      if (geglu) {             // columns [0,32) of every 64 = h, [32,64) = gate of the same 32 output channels
-        const int per = VPR / 2;
-        rr = v / per;
-        const int g = v - rr * per;
-        const int blk = g >> 2, c8 = (g & 3) * 8;
-        hcol = blk * 64 + c8;
-        ncol = col0 + hcol;
-        ocol = (long)((col0 + blk * 64) >> 1) + c8;
-      } else {
-        rr = v / VPR;
-        hcol = (v - rr * VPR) * 8;
-        ncol = col0 + hcol;
-        ocol = ncol;
-      }
-      const int m = row0 + i * 32 + rr;
-      if (m >= M || ncol >= N) continue;
-      const float* hp = ebuf + rr * ESTR + hcol;
-      float o8[8];
-      {
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(hp), x1 = *reinterpret_cast<const f32x4*>(hp + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { o8[e] = x0[e]; o8[4 + e] = x1[e]; }
-      }
-      if (ep.fast) {
-        // branch-free vector path: absent operands read a zero page
-        const float* bp = ep.bias ? ep.bias + ncol : zero;
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { o8[e] += b0[e]; o8[4 + e] += b1[e]; }
-        if (geglu) {
-          const float* gp = ep.bias ? ep.bias + ncol + 32 : zero;
-          const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-          const f32x4 y0 = *reinterpret_cast<const f32x4*>(hp + 32), y1 = *reinterpret_cast<const f32x4*>(hp + 36);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o8[e] *= gelu_erf_f(y0[e] + g0[e]);
-            o8[4 + e] *= gelu_erf_f(y1[e] + g1[e]);
-          }
-        } else {
-          const float* b2p = ep.bias2 ? ep.bias2 + (long)(m / ep.bias2_rows) * N + ncol : zero;
-          const f32x4 c0 = *reinterpret_cast<const f32x4*>(b2p), c1 = *reinterpret_cast<const f32x4*>(b2p + 4);
-          const float rs = (ep.row_scale ? ep.row_scale[m] : 1.f) * ep.alpha;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { o8[e] += c0[e]; o8[4 + e] += c1[e]; }
-          if (ep.act == 2) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] = silu_f(o8[e]);
-          } else if (ep.act == 3) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] = fmaxf(o8[e], 0.f);
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] *= rs;
-        }
-        T* op = out + (long)m * ep.ldo + ocol;
-        if (ESZ == 2) {
-          union { u32x4 u; bf16_t e[8]; } rv;
-          if (res_pf) rv.u = rres[RES_PF ? i : 0][RES_PF ? t : 0];
-          else rv.u = *reinterpret_cast<const u32x4*>(res ? reinterpret_cast<const char*>(res + (long)m * ep.ldr + ocol)
-                                                          : reinterpret_cast<const char*>(zero));
-          union { bf16_t e[8]; u32x4 u; } pk;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pk.e[e] = f32_to_bf16(o8[e] + bf16_to_f32(rv.e[e]));
-          *reinterpret_cast<u32x4*>(op) = pk.u;
-        } else {
-          const float* rp = res ? reinterpret_cast<const float*>(res) + (long)m * ep.ldr + ocol : zero;
-          const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
-          *reinterpret_cast<f32x4*>(op) = (f32x4){o8[0] + r0[0], o8[1] + r0[1], o8[2] + r0[2], o8[3] + r0[3]};
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(op) + 4) =
-              (f32x4){o8[4] + r1[0], o8[5] + r1[1], o8[6] + r1[2], o8[7] + r1[3]};
-        }
-      } else {
-        // generic scalar path (ragged N or unaligned rows)
-        for (int e = 0; e < 8 && ncol + e < N; ++e) {
-          float x = o8[e];
-          if (ep.bias) x += ep.bias[ncol + e];
-          if (geglu) {
-            float gte = hp[32 + e];
-            if (ep.bias) gte += ep.bias[ncol + 32 + e];
-            x *= gelu_erf_f(gte);
-          } else {
-            if (ep.bias2) x += ep.bias2[(long)(m / ep.bias2_rows) * N + ncol + e];
-            if (ep.act == 2) x = silu_f(x);
-            if (ep.act == 3) x = fmaxf(x, 0.f);
-            x *= (ep.row_scale ? ep.row_scale[m] : 1.f) * ep.alpha;
-          }
-          if (res) x += Elem<T>::ld(res + (long)m * ep.ldr + ocol + e);
-          Elem<T>::st(out + (long)m * ep.ldo + ocol + e, x);
-        }
+  constexpr int SLAB = (NW * 32 * ESTR * 4 <= STAGE_BYTES) ? 32 : 16;
+  static_assert(NW * SLAB * ESTR * 4 <= STAGE_BYTES, "epilogue buffer must fit one stage");
+  constexpr int NSLAB = TM * (32 / SLAB);
+  constexpr int VPR = WCOLS / 8;                    // 8-column vectors per row of a wave's slab
+  constexpr int ENV = SLAB * VPR / 64;              // vectors per lane per slab
+  constexpr bool RES_PF = ESZ == 2 && TN <= 2;      // wide wave tiles have no registers to spare for it
+
+  // ---- the chunk stream of this workgroup: tiles vt = blockIdx.x + k * gridDim.x, nchunks chunks each ----
+  const int nchunks = K / BK;
+  const int G = gridDim.x;
+  const int my_tiles = (nwg - (int)blockIdx.x + G - 1) / G;
+  const int total = my_tiles * nchunks;
+  int vt_i = blockIdx.x, ich = 0, gi = 0, sl = 0;   // DMA side: tile, chunk in tile, chunks issued so far, stage to fill next
+  int gc = 0, sc = 0;                               // MFMA side: chunks consumed so far, stage to read next
+  {
+    int tm, tn;
+    decode(vt_i, tm, tn);
+    setup(tm, tn);
+  }
+  auto advance_dma = [&]() {   // bookkeeping after chunk (vt_i, ich) has been issued
+    ++gi;
+    sl = sl + 1 == NSTAGE ? 0 : sl + 1;
+    if (++ich == nchunks) {
+      ich = 0;
+      vt_i += G;
+      if (vt_i < nwg) {
+        int tm, tn;
+        decode(vt_i, tm, tn);
+        setup(tm, tn);
       }
     }
-    __builtin_amdgcn_wave_barrier();
+  };
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (gi < total) { prep(ich); issue(sl, ich, 0, 1); advance_dma(); }
+
+  for (int vt = blockIdx.x; vt < nwg; vt += G) {
+    int tm, tn;
+    decode(vt, tm, tn);
+    const int row0 = tm * BM + wm * (BM / WM), col0 = tn * BN + wn * (BN / WN);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16)(0.f);
+
+    // ---- residual prefetch (bf16 fast path): the epilogue's residual vectors are requested before the main loop, so
+    // their HBM latency hides under it instead of being exposed once per slab (measured: -35% on the L0 N = K = 320
+    // projections).  vmcnt completes in order, so older / younger extra ops only make the counted waits conservative.
+    u32x4 rres[RES_PF ? NSLAB : 1][RES_PF ? ENV : 1];
+    const bool res_pf = RES_PF && ep.residual != nullptr && ep.fast && ep.act != 1;
+    if (res_pf) {
+      const T* resb = reinterpret_cast<const T*>(ep.residual) + (long)bz * ep.bsr;
+#pragma unroll
+      for (int sb = 0; sb < (RES_PF ? NSLAB : 1); ++sb)
+#pragma unroll
+        for (int t = 0; t < (RES_PF ? ENV : 1); ++t) {
+          const int v = lane + 64 * t;
+          const int rr = v / VPR, hc = (v - rr * VPR) * 8;
+          const int m = row0 + sb * SLAB + rr, n = col0 + hc;
+          rres[sb][t] = (m < M && n < N) ? *reinterpret_cast<const u32x4*>(resb + (long)m * ep.ldr + n) : (u32x4)(0u);
+        }
+    }
+
+    // ---- bias prefetch (8-wave tiles = one workgroup per CU, where nothing else hides an L2 round trip per slab): a
+    // lane's vector slot t covers the same 8 columns in every slab, so the bias (and GEGLU gate bias) vectors are loaded
+    // once per tile, before the main loop.  The 4-wave tiles keep the per-slab loads: they have no registers to spare
+    // and two or three resident workgroups to cover the latency.
+    constexpr bool BIAS_PF = NW == 8;
+    f32x4 bvec[BIAS_PF ? ENV : 1][2], gvec[BIAS_PF ? ENV : 1][2];
+    auto load_bias = [&]() {
+      const float* zero = reinterpret_cast<const float*>(g_zero_page);
+      const bool geglu = ep.act == 1;
+#pragma unroll
+      for (int t = 0; t < (BIAS_PF ? ENV : 1); ++t) {
+        const int v = lane + 64 * t;
+        int hcol;
+        if (geglu) {
+          const int per = VPR / 2, g = v % per;
+          hcol = (g >> 2) * 64 + (g & 3) * 8;
+        } else {
+          hcol = (v % VPR) * 8;
+        }
+        const int ncol = col0 + hcol;
+        const bool ok = ep.fast && ep.bias != nullptr && ncol < N;
+        const float* bp = ok ? ep.bias + ncol : zero;
+        const float* gp = ok && geglu ? ep.bias + ncol + 32 : zero;
+        bvec[t][0] = *reinterpret_cast<const f32x4*>(bp);
+        bvec[t][1] = *reinterpret_cast<const f32x4*>(bp + 4);
+        gvec[t][0] = *reinterpret_cast<const f32x4*>(gp);
+        gvec[t][1] = *reinterpret_cast<const f32x4*>(gp + 4);
+      }
+    };
+    if (BIAS_PF) load_bias();
+
+    for (int ch = 0; ch < nchunks; ++ch, ++gc) {
+      // chunk gc must have landed; up to NSTAGE-2 younger chunks may stay in flight (GA + GB LDS-DMA ops per wave each)
+      const int younger = total - 1 - gc;
+      if (NSTAGE == 2 || younger < 1) wait_vmcnt<0>();
+      else if (NSTAGE == 3 || younger < 2) wait_vmcnt<(GA + GB)>();
+      else wait_vmcnt<2 * (GA + GB)>();
+      __builtin_amdgcn_s_barrier();
+      // Spreading the DMA issue between MFMA groups pays for the dense 8-wave tiles (+7% at 8192^3); for the conv gather
+      // and the 4-wave tiles the burst right after the barrier measured faster.
+      constexpr bool ILV = V_ILV && (NW == 8 && MODE == 0);
+      const bool more = gi < total;
+      const int st_i = sl, ch_i = ich;
+      if (more) {
+        prep(ich);
+        if (!ILV) issue(st_i, ch_i, 0, 1);
+      }
+
+      const char* st = smem + sc * STAGE_BYTES;
+      // fragments of K-step ks+1 are read from LDS while the MFMAs of K-step ks run (register double buffering)
+      Frag<T> fa[2][TM], fb[2][TN];
+      auto load_frags = [&](int ks, Frag<T>* pa, Frag<T>* pb) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int r = arow + 32 * i;
+          const int sw = (r >> 1) & 7;
+          if (ESZ == 2) {
+            frag_load(pa[i], reinterpret_cast<const T*>(st + r * ROWB + (((2 * ks + lh) ^ sw) << 4)));
+          } else {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * ROWB + (((4 * ks + 2 * lh) ^ sw) << 4));
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * ROWB + (((4 * ks + 2 * lh + 1) ^ sw) << 4));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pa[i].set(j, lo[j]); pa[i].set(4 + j, hi[j]); }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int r = brow + 32 * j;
+          const int sw = (r >> 1) & 7;
+          const char* sb = st + A_BYTES;
+          if (ESZ == 2) {
+            frag_load(pb[j], reinterpret_cast<const T*>(sb + r * ROWB + (((2 * ks + lh) ^ sw) << 4)));
+          } else {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(sb + r * ROWB + (((4 * ks + 2 * lh) ^ sw) << 4));
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(sb + r * ROWB + (((4 * ks + 2 * lh + 1) ^ sw) << 4));
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) { pb[j].set(jj, lo[jj]); pb[j].set(4 + jj, hi[jj]); }
+          }
+        }
+      };
+      if (V_FRAGDB) load_frags(0, fa[0], fb[0]);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (V_FRAGDB) {
+          if (ks + 1 < KS) load_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+          __builtin_amdgcn_s_setprio(1);
+        } else {
+          load_frags(ks, fa[ks & 1], fb[ks & 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) mma32(acc[i][j], fa[ks & 1][i], fb[ks & 1][j]);
+        if (V_FRAGDB) __builtin_amdgcn_s_setprio(0);
+        if (ILV && more) issue(st_i, ch_i, ks, KS);   // this slice's LDS-DMA issues under the MFMAs just queued
+      }
+      if (more) advance_dma();
+      sc = sc + 1 == NSTAGE ? 0 : sc + 1;
+    }
+
+    // ---- epilogue.  Every wave is done with the stage consumed last (raw barrier: the DMAs of the next tile stay in
+    // flight); that stage is the transpose buffer, and the next DMA into it is issued behind the next tile's first
+    // barrier, which every wave reaches only after its own LDS reads below have completed.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int se = sc == 0 ? NSTAGE - 1 : sc - 1;
+    float* ebuf = reinterpret_cast<float*>(smem + se * STAGE_BYTES) + wid * SLAB * ESTR;
+    T* out = reinterpret_cast<T*>(ep.out) + (long)bz * ep.bso;
+    const T* res = ep.residual ? reinterpret_cast<const T*>(ep.residual) + (long)bz * ep.bsr : nullptr;
+    const bool geglu = ep.act == 1;
+    const float* zero = reinterpret_cast<const float*>(g_zero_page);
+#pragma unroll
+    for (int sb = 0; sb < NSLAB; ++sb) {
+      const int i = sb / (32 / SLAB), half = sb % (32 / SLAB);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < SLAB / 2; ++r) {
+          const int reg = SLAB == 32 ? r : half * 8 + r;
+          const int lrow = SLAB == 32 ? acc_row(reg, lane) : (r & 3) + 8 * (r >> 2) + 4 * lh;
+          ebuf[lrow * ESTR + j * 32 + lr] = acc[i][j][reg];
+        }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int nvec = geglu ? SLAB * (VPR / 2) : SLAB * VPR;
+#pragma unroll
+      for (int t = 0; t < ENV; ++t) {
+        const int v = lane + 64 * t;
+        if (v >= nvec) continue;
+        int rr, hcol, ncol;      // row in the slab, column of the (h) vector inside the wave tile, global column
+        long ocol;
+        if (geglu) {             // columns [0,32) of every 64 = h, [32,64) = gate of the same 32 output channels
+          const int per = VPR / 2;
+          rr = v / per;
+          const int g = v - rr * per;
+          const int blk = g >> 2, c8 = (g & 3) * 8;
+          hcol = blk * 64 + c8;
+          ncol = col0 + hcol;
+          ocol = (long)((col0 + blk * 64) >> 1) + c8;
+        } else {
+          rr = v / VPR;
+          hcol = (v - rr * VPR) * 8;
+          ncol = col0 + hcol;
+          ocol = ncol;
+        }
+        const int m = row0 + sb * SLAB + rr;
+        if (m >= M || ncol >= N) continue;
+        const float* hp = ebuf + rr * ESTR + hcol;
+        float o8[8];
+        {
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(hp), x1 = *reinterpret_cast<const f32x4*>(hp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o8[e] = x0[e]; o8[4 + e] = x1[e]; }
+        }
+        if (ep.fast) {
+          // branch-free vector path: absent operands read a zero page
+          const float* bp = ep.bias ? ep.bias + ncol : zero;
+          const f32x4 b0 = BIAS_PF ? bvec[BIAS_PF ? t : 0][0] : *reinterpret_cast<const f32x4*>(bp);
+          const f32x4 b1 = BIAS_PF ? bvec[BIAS_PF ? t : 0][1] : *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o8[e] += b0[e]; o8[4 + e] += b1[e]; }
+          if (geglu) {
+            const float* gp = ep.bias ? ep.bias + ncol + 32 : zero;
+            const f32x4 g0 = BIAS_PF ? gvec[BIAS_PF ? t : 0][0] : *reinterpret_cast<const f32x4*>(gp);
+            const f32x4 g1 = BIAS_PF ? gvec[BIAS_PF ? t : 0][1] : *reinterpret_cast<const f32x4*>(gp + 4);
+            const f32x4 y0 = *reinterpret_cast<const f32x4*>(hp + 32), y1 = *reinterpret_cast<const f32x4*>(hp + 36);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o8[e] *= gelu_erf_f(y0[e] + g0[e]);
+              o8[4 + e] *= gelu_erf_f(y1[e] + g1[e]);
+            }
+          } else {
+            const float* b2p = ep.bias2 ? ep.bias2 + (long)(m / ep.bias2_rows) * N + ncol : zero;
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(b2p), c1 = *reinterpret_cast<const f32x4*>(b2p + 4);
+            const float rs = (ep.row_scale ? ep.row_scale[m] : 1.f) * ep.alpha;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o8[e] += c0[e]; o8[4 + e] += c1[e]; }
+            if (ep.act == 2) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o8[e] = silu_f(o8[e]);
+            } else if (ep.act == 3) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o8[e] = fmaxf(o8[e], 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] *= rs;
+          }
+          T* op = out + (long)m * ep.ldo + ocol;
+          if (ESZ == 2) {
+            union { u32x4 u; bf16_t e[8]; } rv;
+            if (res_pf) rv.u = rres[RES_PF ? sb : 0][RES_PF ? t : 0];
+            else rv.u = *reinterpret_cast<const u32x4*>(res ? reinterpret_cast<const char*>(res + (long)m * ep.ldr + ocol)
+                                                            : reinterpret_cast<const char*>(zero));
+            union { bf16_t e[8]; u32x4 u; } pk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk.e[e] = f32_to_bf16(o8[e] + bf16_to_f32(rv.e[e]));
+            *reinterpret_cast<u32x4*>(op) = pk.u;
+          } else {
+            const float* rp = res ? reinterpret_cast<const float*>(res) + (long)m * ep.ldr + ocol : zero;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+            *reinterpret_cast<f32x4*>(op) = (f32x4){o8[0] + r0[0], o8[1] + r0[1], o8[2] + r0[2], o8[3] + r0[3]};
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(op) + 4) =
+                (f32x4){o8[4] + r1[0], o8[5] + r1[1], o8[6] + r1[2], o8[7] + r1[3]};
+          }
+        } else {
+          // generic scalar path (ragged N or unaligned rows)
+          for (int e = 0; e < 8 && ncol + e < N; ++e) {
+            float x = o8[e];
+            if (ep.bias) x += ep.bias[ncol + e];
+            if (geglu) {
+              float gte = hp[32 + e];
+              if (ep.bias) gte += ep.bias[ncol + 32 + e];
+              x *= gelu_erf_f(gte);
+            } else {
+              if (ep.bias2) x += ep.bias2[(long)(m / ep.bias2_rows) * N + ncol + e];
+              if (ep.act == 2) x = silu_f(x);
+              if (ep.act == 3) x = fmaxf(x, 0.f);
+              x *= (ep.row_scale ? ep.row_scale[m] : 1.f) * ep.alpha;
+            }
+            if (res) x += Elem<T>::ld(res + (long)m * ep.ldr + ocol + e);
+            Elem<T>::st(out + (long)m * ep.ldo + ocol + e, x);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
   }
 }
 
 template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_cfg(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  dim3 grid(tiles_m * tiles_n, 1, batch);
-  constexpr int TN = BN / WN / 32;
-  const size_t stage = (size_t)NSTAGE * (BM + BN) * ROWB;
-  const size_t epi = (size_t)(WM * WN) * 32 * (32 * TN + 4) * 4;
-  const size_t lds = stage > epi ? stage : epi;
+  const size_t lds = (size_t)NSTAGE * (BM + BN) * ROWB;
   auto kern = gemm_kernel<T, MODE, BM, BN, WM, WN, NSTAGE>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+  static int resident = 0;   // workgroups of this instantiation the whole device holds at once
+  if (!resident) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess) {
+      mmgt_set_error("gemm: cannot reserve %zu bytes of LDS", lds);
+      return 2;
+    }
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, WM * WN * 64, lds) != hipSuccess || per_cu < 1 ||
+        hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      mmgt_set_error("gemm: occupancy query failed");
+      return 2;
+    }
+    resident = per_cu * prop.multiProcessorCount;
   }
+  // persistent grid: as many workgroups as stay resident (a multiple of 8 keeps id & 7 = XCD), each walks its tiles
+  long gx = (resident + batch - 1) / batch;
+  gx = (gx + 7) / 8 * 8;
+  if (gx > (long)tiles_m * tiles_n) gx = (long)tiles_m * tiles_n;
+  dim3 grid((unsigned)gx, 1, batch);
   hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, ad, reinterpret_cast<const char*>(W), bsw, ep, M, N, K, tiles_m,
                      tiles_n);
   MMGT_LAUNCH_CHECK();

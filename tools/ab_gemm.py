@@ -63,6 +63,21 @@ def gemm_case(M, N, K):
     return f"gemm M={M} N={N} K={K}", make
 
 
+def gemm_epi_case(M, N, K, act=0):
+    """bias + residual (attention to_out / ff2) or bias + GEGLU (ff1): the epilogues the UNet actually runs."""
+    def make():
+        a, w = rnd(M, K), rnd(N, K, s=1 / math.sqrt(K))
+        no = N // 2 if act == 1 else N
+        b = torch.rand(N, device=dev) - 0.5
+        r = None if act == 1 else rnd(M, no)
+        o = torch.empty((M, no), device=dev, dtype=torch.bfloat16)
+        call = lambda L, st: L.mmgt_gemm(a.data_ptr(), K, w.data_ptr(), b.data_ptr(), None, 0, None, 1.0,
+                                         r.data_ptr() if r is not None else None, no, o.data_ptr(), no, M, N, K, act, 1, 0,
+                                         0, 0, 0, 1, st)
+        return call, 2 * M * N * K
+    return f"gemm+epi M={M} N={N} K={K} act={act}", make
+
+
 def conv_case(nb, h, cin, cout):
     def make():
         x, w = rnd(nb, h, h, cin), rnd(cout, 3, 3, cin, s=1 / math.sqrt(9 * cin))
@@ -76,6 +91,14 @@ def conv_case(nb, h, cin, cout):
 if __name__ == "__main__":
     cfgs = [int(c) for c in os.environ.get("CFGS", "1,6").split(",")]
     print("libs:", list(libs))
+    if os.environ.get("EPI"):
+        run([gemm_epi_case(196608, 320, 320), gemm_epi_case(196608, 2560, 320, 1), gemm_epi_case(196608, 320, 1280),
+             gemm_epi_case(49152, 640, 640), gemm_epi_case(49152, 5120, 640, 1), gemm_case(196608, 960, 320),
+             gemm_epi_case(12288, 1280, 1280)], cfgs)
+        sys.exit(0)
+    if os.environ.get("BIG"):
+        run([gemm_case(8192, 8192, 8192), gemm_case(12288, 1280, 5120), gemm_case(49152, 5120, 640)], cfgs)
+        sys.exit(0)
     run([gemm_case(8192, 8192, 8192), gemm_case(12288, 1280, 5120), gemm_case(49152, 640, 2560),
          gemm_case(196608, 320, 1280), gemm_case(196608, 640, 320), gemm_case(49152, 1280, 640),
          conv_case(48, 64, 320, 320), conv_case(48, 32, 640, 640), conv_case(48, 32, 1920, 640),

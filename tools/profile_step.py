@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Per call-site profile of one 512x512x24 denoise step: wraps the mmgt_amd.hip entry points with HIP events and prints
+time by (op, shape), so the shapes that matter are known before a kernel is tuned.   python tools/profile_step.py [steps]"""
+import collections
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from mmgt_amd import hip  # noqa: E402
+
+records = []
+
+
+def key_of(name, args, kw):
+    if name == "gemm":
+        a, w = args[0], args[1]
+        epi = ("geglu" if kw.get("act") == hip.ACT_GEGLU else "") + ("+res" if kw.get("residual") is not None else "") + \
+              ("+b2" if kw.get("bias2") is not None else "") + ("+rs" if kw.get("row_scale") is not None else "")
+        return f"gemm M={a.shape[0]} N={w.shape[0]} K={a.shape[1]} {epi}", 2 * a.shape[0] * w.shape[0] * a.shape[1]
+    if name == "gemm_batched_wx":
+        w, x = args[0], args[1]
+        return f"gemm_wx B={x.shape[0]} R={w.shape[0]} ntok={x.shape[1]} K={x.shape[2]}", 2 * x.shape[0] * w.shape[0] * x.shape[1] * x.shape[2]
+    if name == "gemm_batched":
+        a, w = args[0], args[1]
+        return f"gemm_b B={a.shape[0]} M={a.shape[1]} N={w.shape[1]} K={a.shape[2]}", 2 * a.shape[0] * a.shape[1] * w.shape[1] * a.shape[2]
+    if name == "conv3x3":
+        x, wp = args[0], args[1]
+        cin = wp.numel() // (9 * wp.shape[0])
+        st, up = kw.get("stride", 1), kw.get("upsample", False)
+        oh = x.shape[1] * (2 if up else 1) // st
+        return (f"conv nb={x.shape[0]} h={x.shape[1]} cin={cin} cout={wp.shape[0]} s={st} up={int(up)}",
+                2 * x.shape[0] * oh * oh * wp.shape[0] * 9 * cin)
+    if name == "attention":
+        fl = 4 * kw["batch"] * kw["heads"] * kw["hd"] * kw["nq"] * (kw["nk"] + kw.get("nk2", 0))
+        return (f"attn b={kw['batch']} h={kw['heads']} hd={kw['hd']} nq={kw['nq']} nk={kw['nk']} nk2={kw.get('nk2', 0)} "
+                f"vt={int(kw.get('v_transposed', False))}", fl)
+    if name == "groupnorm":
+        x = args[0]
+        c = x.shape[2] + (kw["x1"].shape[2] if kw.get("x1") is not None else 0)
+        return f"groupnorm nb={x.shape[0]} hw={x.shape[1]} c={c} silu={int(kw.get('silu', False))}", 0
+    if name == "layernorm":
+        x = args[0]
+        return f"layernorm rows={x.shape[0]} c={x.shape[1]} pe={int(kw.get('pe') is not None)}", 0
+    t = next((a for a in args if torch.is_tensor(a)), None)
+    return f"{name} {tuple(t.shape) if t is not None else ''}", 0
+
+
+def wrap(name):
+    fn = getattr(hip, name)
+
+    def inner(*args, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*args, **kw)
+        e1.record()
+        records.append((key_of(name, args, kw), e0, e1))
+        return r
+    setattr(hip, name, inner)
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    for n in ["gemm", "gemm_batched_wx", "gemm_batched", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
+              "ncfhw_to_nhwc", "nhwc_to_ncfhw", "timestep_features", "silu", "cfg_ddim_step", "accumulate_window"]:
+        wrap(n)
+    sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline"]
+    import io
+    import contextlib
+    # run bench.main() (its own warmup is recorded too: drop those records afterwards)
+    buf = io.StringIO()
+    marks = []
+    orig_run = None
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    torch.cuda.synchronize()
+    per = len(records) // (steps + 1)
+    recs = records[per:]                                        # drop the warmup step
+    agg = collections.OrderedDict()
+    for (k, fl), e0, e1 in recs:
+        t = e0.elapsed_time(e1) * 1e3
+        a = agg.setdefault(k, [0, 0.0, 0])
+        a[0] += 1
+        a[1] += t
+        a[2] += fl
+    tot = sum(a[1] for a in agg.values())
+    print(f"bench: {buf.getvalue().strip()[:200]}")
+    print(f"total inside calls: {tot / steps / 1e3:.2f} ms/step, {len(recs) // steps} calls/step")
+    fam = collections.Counter()
+    for k, (n, t, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        fam[k.split()[0]] += t
+        tf = f"{fl / t / 1e6:7.0f} TF/s" if fl else " " * 12
+        print(f"{t / steps / 1e3:8.3f} ms {100 * t / tot:5.1f}%  x{n // steps:4d}  {t / n:8.1f} us  {tf}  {k}")
+    print({k: round(v / steps / 1e3, 2) for k, v in fam.most_common()})
+
+
+if __name__ == "__main__":
+    main()
