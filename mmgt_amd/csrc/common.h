@@ -79,19 +79,42 @@ __device__ __forceinline__ float frag_get(const Frag<float>& f, int j) { return 
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
-// Exact-erf GELU, x * Phi(x), with Phi from Abramowitz & Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. fp32 round-off level;
-// the libm erff costs ~4x more VALU issue slots and made the GEGLU epilogue longer than a K = 320 main loop).
-//   erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3 + a4 t^4 + a5 t^5) exp(-z^2),  t = 1 / (1 + p z),  z = |x| / sqrt(2)
+// Exact-erf GELU, x * Phi(x), with erf from Abramowitz & Stegun 7.1.28:
+//   erf(z) = 1 - (1 + a1 z + a2 z^2 + ... + a6 z^6)^-16,  |error| <= 3e-7  (fp32 evaluation: |gelu error| < 1e-6)
+// i.e. six FMAs, four squarings and ONE reciprocal per value -- the libm erff costs ~4x more VALU issue slots, and
+// 7.1.26 needs a reciprocal AND an exponential (both quarter rate).  z = |x| / sqrt(2) is folded into the coefficients.
+// The two-wide form compiles to v_pk_fma_f32 / v_pk_mul_f32 (two values per issue slot).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+#define MMGT_GELU_C1 0.04986734694f       /* 0.0705230784 / 2^(1/2) */
+#define MMGT_GELU_C2 0.02114100615f       /* 0.0422820123 / 2       */
+#define MMGT_GELU_C3 0.003277626324f      /* 0.0092705272 / 2^(3/2) */
+#define MMGT_GELU_C4 0.000038003575f      /* 0.0001520143 / 4       */
+#define MMGT_GELU_C5 0.000048890636f      /* 0.0002765672 / 2^(5/2) */
+#define MMGT_GELU_C6 0.00000538297500f    /* 0.0000430638 / 8       */
 __device__ __forceinline__ float gelu_erf_f(float x) {
-  const float ax = fabsf(x);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  poly *= t;
-  const float h = 0.5f * poly * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);   // 0.5 * exp(-x^2 / 2)
+  const float z = fabsf(x);
+  float p = fmaf(MMGT_GELU_C6, z, MMGT_GELU_C5);
+  p = fmaf(p, z, MMGT_GELU_C4);
+  p = fmaf(p, z, MMGT_GELU_C3);
+  p = fmaf(p, z, MMGT_GELU_C2);
+  p = fmaf(p, z, MMGT_GELU_C1);
+  p = fmaf(p, z, 1.0f);
+  p *= p; p *= p; p *= p; p *= p;
+  const float h = 0.5f * __builtin_amdgcn_rcpf(p);          // (1 - erf(z)) / 2;  p = inf -> 0
   return x * (x >= 0.f ? 1.0f - h : h);
+}
+__device__ __forceinline__ f32x2 gelu_erf_f2(f32x2 x) {
+  const f32x2 z = {fabsf(x[0]), fabsf(x[1])};
+  f32x2 p = z * MMGT_GELU_C6 + MMGT_GELU_C5;
+  p = p * z + MMGT_GELU_C4;
+  p = p * z + MMGT_GELU_C3;
+  p = p * z + MMGT_GELU_C2;
+  p = p * z + MMGT_GELU_C1;
+  p = p * z + 1.0f;
+  p *= p; p *= p; p *= p; p *= p;
+  const f32x2 h = {0.5f * __builtin_amdgcn_rcpf(p[0]), 0.5f * __builtin_amdgcn_rcpf(p[1])};
+  const f32x2 phi = {x[0] >= 0.f ? 1.0f - h[0] : h[0], x[1] >= 0.f ? 1.0f - h[1] : h[1]};
+  return x * phi;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -72,6 +72,49 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Transpose of 16-byte elements between the S (4 or 2) lanes r = lane & (S - 1) of a DPP quad and a lane's S registers:
+// afterwards x[s] of lane r holds what x[r] of lane s held (an involution).  Butterfly of quad_perm moves: per exchanged
+// register pair and dword one select for the value sent, one v_mov_dpp, two selects.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_quad(unsigned v) {
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+template <int S>
+__device__ __forceinline__ void quad_transpose(u32x4 (&x)[S], int lane) {
+  static_assert(S == 2 || S == 4, "quad_transpose");
+  unsigned a[S][4];   // scalars: element-wise selects on arrays of vectors are lowered through scratch
+#pragma unroll
+  for (int k = 0; k < S; ++k)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) a[k][d] = x[k][d];
+  {
+    const bool bit = (lane & 1) != 0;
+#pragma unroll
+    for (int lo = 0; lo < S; lo += 2)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const unsigned p = a[lo][d], q = a[lo + 1][d];
+        const unsigned recv = dpp_quad<0xB1>(bit ? p : q);   // quad_perm [1, 0, 3, 2]
+        a[lo][d] = bit ? recv : p;
+        a[lo + 1][d] = bit ? q : recv;
+      }
+  }
+  if (S == 4) {
+    const bool bit = (lane & 2) != 0;
+#pragma unroll
+    for (int lo = 0; lo < 2; ++lo)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const unsigned p = a[lo][d], q = a[lo + 2 < S ? lo + 2 : lo][d];
+        const unsigned recv = dpp_quad<0x4E>(bit ? p : q);   // quad_perm [2, 3, 0, 1]
+        a[lo][d] = bit ? recv : p;
+        a[lo + 2 < S ? lo + 2 : lo][d] = bit ? q : recv;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < S; ++k) x[k] = (u32x4){a[k][0], a[k][1], a[k][2], a[k][3]};
+}
+
 // MODE 0 dense, 1 conv3x3.  WM x WN waves (4 or 8 per workgroup).
 //
 // The grid is persistent: workgroup b computes tiles b, b + gridDim.x, ... and the chunk stream of its LDS ring keeps
@@ -80,7 +123,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // and its stores draining under the next main loop.  Measured before this: a 256 x 128 tile paid about 7 us of launch +
 // first-load latency + store drain per tile, as much as a K = 640 main loop.
 template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ADesc ad, const char* __restrict__ W, long bsw, Epi ep, int M, int N,
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN / WN / 32) <= 2) ? 3 : 2) void gemm_kernel(ADesc ad, const char* __restrict__ W, long bsw, Epi ep, int M, int N,
                                                    int K, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   constexpr int ESZ = sizeof(T);
@@ -201,17 +244,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ADesc ad, const char
   // fragment read addressing: row r of the tile, 16-byte chunk c  ->  r * 128 + ((c ^ ((r >> 1) & 7)) * 16)
   const int arow = wm * (BM / WM) + lr, brow = wn * (BN / WN) + lr;   // + 32 * tile index (keeps (row>>1)&7 pattern)
 
-  // ---- epilogue geometry: per wave, SLAB rows at a time through LDS (row-major fp32, 4-float pad), then 8-column
-  // vectors.  The transpose buffer of all waves must fit into ONE ring stage (the other stages hold the next tile).
-  constexpr int WCOLS = 32 * TN;
-  constexpr int ESTR = WCOLS + 4;
-  constexpr int SLAB = (NW * 32 * ESTR * 4 <= STAGE_BYTES) ? 32 : 16;
-  static_assert(NW * SLAB * ESTR * 4 <= STAGE_BYTES, "epilogue buffer must fit one stage");
-  constexpr int NSLAB = TM * (32 / SLAB);
-  constexpr int VPR = WCOLS / 8;                    // 8-column vectors per row of a wave's slab
-  constexpr int ENV = SLAB * VPR / 64;              // vectors per lane per slab
-  constexpr bool RES_PF = ESZ == 2 && TN <= 2;      // wide wave tiles have no registers to spare for it
-
+  // ---- epilogue geometry.  The MFMAs run with the operands swapped (D = W_frag x A_frag), so a lane holds ONE output row
+  // m = lane & 31 and, per 32 x 32 accumulator tile, sixteen columns n = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+  // Two v_permlane32_swap per register pair turn that into two runs of 8 consecutive columns per lane ("octets": lane
+  // half h owns columns 16 * g2 + 8 * h .. + 7); these are finished in fp32 and packed.  Stored like that, one store
+  // instruction would touch 32 rows x 32 bytes, and the texture path spends ~5 cycles per 128-byte line touched
+  // (measured with TA_BUSY: 166 cycles per 1 KiB store instruction against 19 for an LDS-DMA load) -- the store time of the
+  // short-K GEMMs added to their load time.  So the S = 2 TN octets of a row block are transposed across the DPP quad
+  // (quad_transpose): store s of lane (r, h) then covers row S * (lane >> 2 or 1) + s, columns of octet slot r, and one
+  // instruction writes 64 / S rows of S * 32 contiguous bytes (full 128-byte lines for a 64-column wave tile).  No LDS
+  // round trip, no barrier: waves drift into the next tile's chunks independently.
+  static_assert(TN <= 2, "epilogue: wave tiles wider than 64 columns are not laid out");
+  constexpr bool RES_PF = ESZ == 2 && TM * TN <= 4;   // wide wave tiles have no registers to spare for it
   // ---- the chunk stream of this workgroup: tiles vt = blockIdx.x + k * gridDim.x, nchunks chunks each ----
   const int nchunks = K / BK;
   const int G = gridDim.x;
@@ -252,54 +296,49 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ADesc ad, const char
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16)(0.f);
 
-    // ---- residual prefetch (bf16 fast path): the epilogue's residual vectors are requested before the main loop, so
-    // their HBM latency hides under it instead of being exposed once per slab (measured: -35% on the L0 N = K = 320
-    // projections).  vmcnt completes in order, so older / younger extra ops only make the counted waits conservative.
-    u32x4 rres[RES_PF ? NSLAB : 1][RES_PF ? ENV : 1];
-    const bool res_pf = RES_PF && ep.residual != nullptr && ep.fast && ep.act != 1;
+    // ---- epilogue operands requested before the main loop, so their latency hides under it:
+    //  * residual (bf16 fast path): the lane's 16-byte vectors in the octet layout of the epilogue (measured, earlier
+    //    layout: -35% on the L0 N = K = 320 projections);
+    //  * bias[n] + bias2[batch row][n] of the lane's W row n = col0 + 32 j + (lane & 31), for the (at most two) bias2
+    //    rows the tile touches.  They enter the accumulators as ONE more K-step after the main loop (see below).
+    // vmcnt completes in order, so these older ops only make the counted waits of the ring conservative.
+    const bool fast = ep.fast != 0;
+    const bool geglu = ep.act == 1;
+    const bool res_pf = RES_PF && ep.residual != nullptr && fast;
+    // Store-layout coordinates of this lane (non-GEGLU: S = 2 TN slots per row block; see "epilogue geometry"):
+    // vector s of row block i is row 32 i + S * (lr / S) + s, columns 32 * (r >> 1) + 16 * (r & 1) + 8 h with r = lr % S
+    // (for S = 2: 16 r + 8 h).
+    constexpr int SN = 2 * TN;
+    const int sr = lr & (SN - 1), srow = lr & ~(SN - 1);
+    const int scol = (SN == 4 ? 32 * (sr >> 1) + 16 * (sr & 1) : 16 * sr) + 8 * lh;
+    u32x4 rres[RES_PF ? TM : 1][RES_PF ? SN : 1];
     if (res_pf) {
       const T* resb = reinterpret_cast<const T*>(ep.residual) + (long)bz * ep.bsr;
 #pragma unroll
-      for (int sb = 0; sb < (RES_PF ? NSLAB : 1); ++sb)
+      for (int i = 0; i < (RES_PF ? TM : 1); ++i)
 #pragma unroll
-        for (int t = 0; t < (RES_PF ? ENV : 1); ++t) {
-          const int v = lane + 64 * t;
-          const int rr = v / VPR, hc = (v - rr * VPR) * 8;
-          const int m = row0 + sb * SLAB + rr, n = col0 + hc;
-          rres[sb][t] = (m < M && n < N) ? *reinterpret_cast<const u32x4*>(resb + (long)m * ep.ldr + n) : (u32x4)(0u);
+        for (int sidx = 0; sidx < (RES_PF ? SN : 1); ++sidx) {
+          const int m = row0 + 32 * i + srow + sidx, n = col0 + scol;
+          rres[i][sidx] = (m < M && n < N && !geglu) ? *reinterpret_cast<const u32x4*>(resb + (long)m * ep.ldr + n)
+                                                     : (u32x4)(0u);
         }
     }
-
-    // ---- bias prefetch (8-wave tiles = one workgroup per CU, where nothing else hides an L2 round trip per slab): a
-    // lane's vector slot t covers the same 8 columns in every slab, so the bias (and GEGLU gate bias) vectors are loaded
-    // once per tile, before the main loop.  The 4-wave tiles keep the per-slab loads: they have no registers to spare
-    // and two or three resident workgroups to cover the latency.
-    constexpr bool BIAS_PF = NW == 8;
-    f32x4 bvec[BIAS_PF ? ENV : 1][2], gvec[BIAS_PF ? ENV : 1][2];
-    auto load_bias = [&]() {
-      const float* zero = reinterpret_cast<const float*>(g_zero_page);
-      const bool geglu = ep.act == 1;
+    // bias2 rows of this tile: b2r0 (rows m with m / bias2_rows == b2r0) and b2r0 + 1; the host guarantees
+    // bias2_rows >= BM on the fast path, so a tile touches at most two.
+    const int b2div = ep.bias2 ? ep.bias2_rows : 0x7fffffff;
+    const int b2r0 = (tm * BM) / b2div;
+    int mlast = tm * BM + BM - 1;
+    if (mlast >= M) mlast = M - 1;
+    const bool b2two = mlast / b2div > b2r0;
+    float bsum[TN][2];
 #pragma unroll
-      for (int t = 0; t < (BIAS_PF ? ENV : 1); ++t) {
-        const int v = lane + 64 * t;
-        int hcol;
-        if (geglu) {
-          const int per = VPR / 2, g = v % per;
-          hcol = (g >> 2) * 64 + (g & 3) * 8;
-        } else {
-          hcol = (v % VPR) * 8;
-        }
-        const int ncol = col0 + hcol;
-        const bool ok = ep.fast && ep.bias != nullptr && ncol < N;
-        const float* bp = ok ? ep.bias + ncol : zero;
-        const float* gp = ok && geglu ? ep.bias + ncol + 32 : zero;
-        bvec[t][0] = *reinterpret_cast<const f32x4*>(bp);
-        bvec[t][1] = *reinterpret_cast<const f32x4*>(bp + 4);
-        gvec[t][0] = *reinterpret_cast<const f32x4*>(gp);
-        gvec[t][1] = *reinterpret_cast<const f32x4*>(gp + 4);
-      }
-    };
-    if (BIAS_PF) load_bias();
+    for (int j = 0; j < TN; ++j) {
+      const int n = col0 + 32 * j + lr;
+      const bool ok = fast && n < N;
+      const float b = (ok && ep.bias) ? ep.bias[n] : 0.f;
+      bsum[j][0] = b + ((ok && ep.bias2) ? ep.bias2[(long)b2r0 * N + n] : 0.f);
+      bsum[j][1] = b + ((ok && ep.bias2 && b2two) ? ep.bias2[(long)(b2r0 + 1) * N + n] : 0.f);
+    }
 
     for (int ch = 0; ch < nchunks; ++ch, ++gc) {
       // chunk gc must have landed; up to NSTAGE-2 younger chunks may stay in flight (GA + GB LDS-DMA ops per wave each)
@@ -362,7 +401,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ADesc ad, const char
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) mma32(acc[i][j], fa[ks & 1][i], fb[ks & 1][j]);
+          for (int j = 0; j < TN; ++j) mma32(acc[i][j], fb[ks & 1][j], fa[ks & 1][i]);   // D[n][m]
         if (V_FRAGDB) __builtin_amdgcn_s_setprio(0);
         if (ILV && more) issue(st_i, ch_i, ks, KS);   // this slice's LDS-DMA issues under the MFMAs just queued
       }
@@ -370,132 +409,207 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(ADesc ad, const char
       sc = sc + 1 == NSTAGE ? 0 : sc + 1;
     }
 
-    // ---- epilogue.  Every wave is done with the stage consumed last (raw barrier: the DMAs of the next tile stay in
-    // flight); that stage is the transpose buffer, and the next DMA into it is issued behind the next tile's first
-    // barrier, which every wave reaches only after its own LDS reads below have completed.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const int se = sc == 0 ? NSTAGE - 1 : sc - 1;
-    float* ebuf = reinterpret_cast<float*>(smem + se * STAGE_BYTES) + wid * SLAB * ESTR;
+    // ---- bias as one more K-step (fast path):  D[n][m] += sum_c bsum[c][n] * sel[c][m], sel[c][m] = (row m belongs to
+    // bias2 row b2r0 + c).  Each value is split into a storage-type head and tail (k = 2c, 2c + 1) so the bf16
+    // instantiation adds the bias to ~2^-17 relative; for fp32 the tail is zero and the product is exact.
+    if (fast && (ep.bias || ep.bias2)) {
+      Frag<T> fbias[TN], fsel[TM];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        fbias[j].zero();
+        if (lh == 0) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const float hi = Elem<T>::cvt(bsum[j][c]);
+            fbias[j].set(2 * c, hi);
+            fbias[j].set(2 * c + 1, bsum[j][c] - hi);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        fsel[i].zero();
+        int m = row0 + 32 * i + lr;
+        if (m >= M) m = M - 1;
+        const int c = m / b2div - b2r0;
+        if (lh == 0) {
+          fsel[i].set(0, c == 0 ? 1.f : 0.f);
+          fsel[i].set(1, c == 0 ? 1.f : 0.f);
+          fsel[i].set(2, c == 1 ? 1.f : 0.f);
+          fsel[i].set(3, c == 1 ? 1.f : 0.f);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma32(acc[i][j], fbias[j], fsel[i]);
+    }
+
+    // ---- epilogue from registers: lane = output row m, accumulator register = column (see "epilogue geometry") ----
     T* out = reinterpret_cast<T*>(ep.out) + (long)bz * ep.bso;
     const T* res = ep.residual ? reinterpret_cast<const T*>(ep.residual) + (long)bz * ep.bsr : nullptr;
-    const bool geglu = ep.act == 1;
-    const float* zero = reinterpret_cast<const float*>(g_zero_page);
+    if (fast) {
+      constexpr int OV = ESZ == 2 ? 1 : 2;       // 16-byte vectors per octet as stored
 #pragma unroll
-    for (int sb = 0; sb < NSLAB; ++sb) {
-      const int i = sb / (32 / SLAB), half = sb % (32 / SLAB);
+      for (int i = 0; i < TM; ++i) {
+        int m = row0 + 32 * i + lr;              // the row this lane holds in the accumulator layout
+        asm volatile("" : "+v"(m));              // keeps the address arithmetic below out of the main loop's live ranges
+        const bool mok = m < M;
+        const bool scaled = ep.row_scale != nullptr || ep.alpha != 1.f;   // uniform
+        const float rs = (ep.row_scale && mok ? ep.row_scale[m] : 1.f) * ep.alpha;
+        // residual of this row block: prefetched (or loaded here) in the store layout, transposed back to "lane = row"
+        u32x4 rv[OV][SN];
+        if (res) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+          for (int sidx = 0; sidx < SN; ++sidx) {
+            const int ms = row0 + 32 * i + srow + sidx, ns = col0 + scol;
+            const bool inb = ms < M && ns < N;
+            if (ESZ == 2) {
+              rv[0][sidx] = res_pf ? rres[RES_PF ? i : 0][RES_PF ? sidx : 0]
+                                   : (inb ? *reinterpret_cast<const u32x4*>(res + (long)ms * ep.ldr + ns) : (u32x4)(0u));
+            } else {
+              const u32x4* rp = reinterpret_cast<const u32x4*>(res + (long)ms * ep.ldr + ns);
+              rv[0][sidx] = inb ? rp[0] : (u32x4)(0u);
+              rv[OV - 1][sidx] = inb ? rp[1] : (u32x4)(0u);
+            }
+          }
 #pragma unroll
-        for (int r = 0; r < SLAB / 2; ++r) {
-          const int reg = SLAB == 32 ? r : half * 8 + r;
-          const int lrow = SLAB == 32 ? acc_row(reg, lane) : (r & 3) + 8 * (r >> 2) + 4 * lh;
-          ebuf[lrow * ESTR + j * 32 + lr] = acc[i][j][reg];
+          for (int q = 0; q < OV; ++q) quad_transpose<SN>(rv[q], lane);
         }
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int nvec = geglu ? SLAB * (VPR / 2) : SLAB * VPR;
+        u32x4 pk[OV][SN];                        // finished octets, slot k = 2 j + g2
 #pragma unroll
-      for (int t = 0; t < ENV; ++t) {
-        const int v = lane + 64 * t;
-        if (v >= nvec) continue;
-        int rr, hcol, ncol;      // row in the slab, column of the (h) vector inside the wave tile, global column
-        long ocol;
-        if (geglu) {             // columns [0,32) of every 64 = h, [32,64) = gate of the same 32 output channels
-          const int per = VPR / 2;
-          rr = v / per;
-          const int g = v - rr * per;
-          const int blk = g >> 2, c8 = (g & 3) * 8;
-          hcol = blk * 64 + c8;
-          ncol = col0 + hcol;
-          ocol = (long)((col0 + blk * 64) >> 1) + c8;
-        } else {
-          rr = v / VPR;
-          hcol = (v - rr * VPR) * 8;
-          ncol = col0 + hcol;
-          ocol = ncol;
-        }
-        const int m = row0 + sb * SLAB + rr;
-        if (m >= M || ncol >= N) continue;
-        const float* hp = ebuf + rr * ESTR + hcol;
-        float o8[8];
-        {
-          const f32x4 x0 = *reinterpret_cast<const f32x4*>(hp), x1 = *reinterpret_cast<const f32x4*>(hp + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { o8[e] = x0[e]; o8[4 + e] = x1[e]; }
-        }
-        if (ep.fast) {
-          // branch-free vector path: absent operands read a zero page
-          const float* bp = ep.bias ? ep.bias + ncol : zero;
-          const f32x4 b0 = BIAS_PF ? bvec[BIAS_PF ? t : 0][0] : *reinterpret_cast<const f32x4*>(bp);
-          const f32x4 b1 = BIAS_PF ? bvec[BIAS_PF ? t : 0][1] : *reinterpret_cast<const f32x4*>(bp + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { o8[e] += b0[e]; o8[4 + e] += b1[e]; }
+        for (int j = 0; j < TN; ++j) {
+          if (geglu && (j & 1)) continue;          // gate tiles are consumed with their h tile
+          f32x16 v = acc[i][j];
           if (geglu) {
-            const float* gp = ep.bias ? ep.bias + ncol + 32 : zero;
-            const f32x4 g0 = BIAS_PF ? gvec[BIAS_PF ? t : 0][0] : *reinterpret_cast<const f32x4*>(gp);
-            const f32x4 g1 = BIAS_PF ? gvec[BIAS_PF ? t : 0][1] : *reinterpret_cast<const f32x4*>(gp + 4);
-            const f32x4 y0 = *reinterpret_cast<const f32x4*>(hp + 32), y1 = *reinterpret_cast<const f32x4*>(hp + 36);
+            // packed weights: tile j = 32 h channels, tile j + 1 = their 32 gates, same lane and register
+            const f32x16 gt = acc[i][(j + 1) < TN ? j + 1 : j];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              o8[e] *= gelu_erf_f(y0[e] + g0[e]);
-              o8[4 + e] *= gelu_erf_f(y1[e] + g1[e]);
+            for (int r = 0; r < 16; r += 2) {
+              const f32x2 gl = gelu_erf_f2((f32x2){gt[r], gt[r + 1]});
+              v[r] *= gl[0];
+              v[r + 1] *= gl[1];
             }
           } else {
-            const float* b2p = ep.bias2 ? ep.bias2 + (long)(m / ep.bias2_rows) * N + ncol : zero;
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(b2p), c1 = *reinterpret_cast<const f32x4*>(b2p + 4);
-            const float rs = (ep.row_scale ? ep.row_scale[m] : 1.f) * ep.alpha;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { o8[e] += c0[e]; o8[4 + e] += c1[e]; }
             if (ep.act == 2) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) o8[e] = silu_f(o8[e]);
+              for (int r = 0; r < 16; ++r) v[r] = silu_f(v[r]);
             } else if (ep.act == 3) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) o8[e] = fmaxf(o8[e], 0.f);
+              for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] *= rs;
+            if (scaled) v *= rs;
           }
-          T* op = out + (long)m * ep.ldo + ocol;
-          if (ESZ == 2) {
-            union { u32x4 u; bf16_t e[8]; } rv;
-            if (res_pf) rv.u = rres[RES_PF ? sb : 0][RES_PF ? t : 0];
-            else rv.u = *reinterpret_cast<const u32x4*>(res ? reinterpret_cast<const char*>(res + (long)m * ep.ldr + ocol)
-                                                            : reinterpret_cast<const char*>(zero));
-            union { bf16_t e[8]; u32x4 u; } pk;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pk.e[e] = f32_to_bf16(o8[e] + bf16_to_f32(rv.e[e]));
-            *reinterpret_cast<u32x4*>(op) = pk.u;
-          } else {
-            const float* rp = res ? reinterpret_cast<const float*>(res) + (long)m * ep.ldr + ocol : zero;
-            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
-            *reinterpret_cast<f32x4*>(op) = (f32x4){o8[0] + r0[0], o8[1] + r0[1], o8[2] + r0[2], o8[3] + r0[3]};
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(op) + 4) =
-                (f32x4){o8[4] + r1[0], o8[5] + r1[1], o8[6] + r1[2], o8[7] + r1[3]};
+          for (int g2 = 0; g2 < 2; ++g2) {
+            const int k = 2 * j + g2;
+            float o8[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // a: n = 16 g2 + e (+4 in the upper lane half), b: n = 16 g2 + 8 + e (+4);  a.hi <-> b.lo
+              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * g2 + e]),
+                                                               __float_as_uint(v[8 * g2 + 4 + e]), false, false);
+              o8[e] = __uint_as_float(sw[0]);
+              o8[4 + e] = __uint_as_float(sw[1]);
+            }
+            if (ESZ == 2) {
+              if (res) {
+                union { u32x4 u; bf16_t e[8]; } r8;
+                r8.u = rv[0][k];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] += bf16_to_f32(r8.e[e]);
+              }
+              union { bf16_t e[8]; u32x4 u; } p8;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) p8.e[e] = f32_to_bf16(o8[e]);
+              pk[0][k] = p8.u;
+            } else {
+              union { f32x4 f; u32x4 u; } c0, c1;
+              c0.f = (f32x4){o8[0], o8[1], o8[2], o8[3]};
+              c1.f = (f32x4){o8[4], o8[5], o8[6], o8[7]};
+              if (res) {
+                union { u32x4 u; f32x4 f; } r0, r1;
+                r0.u = rv[0][k];
+                r1.u = rv[OV - 1][k];
+                c0.f += r0.f;
+                c1.f += r1.f;
+              }
+              pk[0][k] = c0.u;
+              pk[OV - 1][k] = c1.u;
+            }
+          }
+        }
+        // ---- to the store layout and out
+        T* ob = out + (long)(row0 + 32 * i) * ep.ldo;
+        if (!geglu) {
+#pragma unroll
+          for (int q = 0; q < OV; ++q) quad_transpose<SN>(pk[q], lane);
+#pragma unroll
+          for (int sidx = 0; sidx < SN; ++sidx) {
+            const int ms = row0 + 32 * i + srow + sidx, ns = col0 + scol;
+            if (ms >= M || ns >= N) continue;
+            u32x4* op = reinterpret_cast<u32x4*>(ob + (long)(srow + sidx) * ep.ldo + ns);
+#pragma unroll
+            for (int q = 0; q < OV; ++q) op[q] = pk[q][sidx];
           }
         } else {
-          // generic scalar path (ragged N or unaligned rows)
-          for (int e = 0; e < 8 && ncol + e < N; ++e) {
-            float x = o8[e];
-            if (ep.bias) x += ep.bias[ncol + e];
+          // GEGLU: every even tile j yields 32 output columns = 2 octets per row -> 2 x 2 transposes
+#pragma unroll
+          for (int j = 0; j < TN; j += 2) {
+            const int gr = lr & 1, grow = lr & ~1;
+#pragma unroll
+            for (int q = 0; q < OV; ++q) {
+              u32x4 t2[2] = {pk[q][2 * j], pk[q][2 * j + 1]};
+              quad_transpose<2>(t2, lane);
+              pk[q][2 * j] = t2[0];
+              pk[q][2 * j + 1] = t2[1];
+            }
+#pragma unroll
+            for (int sidx = 0; sidx < 2; ++sidx) {
+              const int ms = row0 + 32 * i + grow + sidx;
+              const int ns = col0 + 32 * j + 16 * gr + 8 * lh;          // column in the accumulator's N space
+              if (ms >= M || ns >= N) continue;
+              const long ocol = (long)((col0 + 32 * j) >> 1) + 16 * gr + 8 * lh;
+              u32x4* op = reinterpret_cast<u32x4*>(ob + (long)(grow + sidx) * ep.ldo + ocol);
+#pragma unroll
+              for (int q = 0; q < OV; ++q) op[q] = pk[q][2 * j + sidx];
+            }
+          }
+        }
+      }
+    } else {
+      // generic scalar path (ragged N, unaligned rows, bias2 blocks shorter than a tile): element by element
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = row0 + 32 * i + lr;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (geglu && (j & 1)) continue;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int nl = acc_row(r, lane);
+            const int ncol = col0 + 32 * j + nl;
+            if (ncol >= N) continue;
+            float x = acc[i][j][r];
+            if (ep.bias) x += ep.bias[ncol];
+            long ocol = ncol;
             if (geglu) {
-              float gte = hp[32 + e];
-              if (ep.bias) gte += ep.bias[ncol + 32 + e];
+              float gte = acc[i][(j + 1) < TN ? j + 1 : j][r];
+              if (ep.bias) gte += ep.bias[ncol + 32];
               x *= gelu_erf_f(gte);
+              ocol = (long)((col0 + 32 * j) >> 1) + nl;
             } else {
-              if (ep.bias2) x += ep.bias2[(long)(m / ep.bias2_rows) * N + ncol + e];
+              if (ep.bias2) x += ep.bias2[(long)(m / ep.bias2_rows) * N + ncol];
               if (ep.act == 2) x = silu_f(x);
               if (ep.act == 3) x = fmaxf(x, 0.f);
               x *= (ep.row_scale ? ep.row_scale[m] : 1.f) * ep.alpha;
             }
-            if (res) x += Elem<T>::ld(res + (long)m * ep.ldr + ocol + e);
-            Elem<T>::st(out + (long)m * ep.ldo + ocol + e, x);
+            if (res) x += Elem<T>::ld(res + (long)m * ep.ldr + ocol);
+            Elem<T>::st(out + (long)m * ep.ldo + ocol, x);
           }
         }
       }
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
 }
@@ -553,7 +667,7 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     else if (M >= 131072 && N >= 640) cfg = 6;
     else cfg = 3;
   }
-  if (geglu && (cfg == 3 || cfg == 4 || cfg == 5 || cfg >= 8)) cfg = 1;
+  if (geglu && (cfg == 3 || cfg == 4 || cfg == 5 || cfg == 8)) cfg = 1;
   switch (cfg) {
     case 1: return launch_cfg<T, MODE, 128, 128, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
     case 2: return launch_cfg<T, MODE, 128, 128, 2, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
@@ -562,14 +676,15 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     case 5: return launch_cfg<T, MODE, 64, 64, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
     case 6: return launch_cfg<T, MODE, 256, 128, 4, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
     case 7: return launch_cfg<T, MODE, 256, 128, 4, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
-    default: return launch_cfg<T, MODE, 256, 64, 4, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
+    case 8: return launch_cfg<T, MODE, 256, 64, 4, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
+    default: return launch_cfg<T, MODE, 128, 128, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
   }
 }
 
 int epi_fast(const Epi& ep, int N, int n_out, int esz) {
   auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   bool ok = N % 8 == 0 && n_out % 8 == 0 && al16(ep.out) && (ep.ldo * esz) % 16 == 0 && (ep.bso * esz) % 16 == 0;
-  ok = ok && al16(ep.bias) && al16(ep.bias2);
+  ok = ok && (ep.bias2 == nullptr || ep.bias2_rows >= 256);   // a tile (<= 256 rows) touches at most two bias2 rows
   if (ep.residual) ok = ok && al16(ep.residual) && (ep.ldr * esz) % 16 == 0 && (ep.bsr * esz) % 16 == 0;
   return ok ? 1 : 0;
 }
