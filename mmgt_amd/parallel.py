@@ -68,12 +68,12 @@ def gather_frames(frames: torch.Tensor, dst: int = 0) -> Optional[List[torch.Ten
     return [b[:n].view(tuple(int(x) for x in s[:ndim])) for b, n, s in zip(bufs, numels, shapes)]
 
 
-def allgather_window_predictions(pred: torch.Tensor) -> List[torch.Tensor]:
+def allgather_window_predictions(pred: torch.Tensor, group=None) -> List[torch.Tensor]:
     """Window-parallel long video: ranks own disjoint windows of one DDIM step and exchange their
     predictions; every rank then applies the identical overlap-average + CFG + DDIM update."""
-    world = dist.get_world_size()
+    world = dist.get_world_size(group)
     out = [torch.empty_like(pred) for _ in range(world)]
-    dist.all_gather(out, pred.contiguous())
+    dist.all_gather(out, pred.contiguous(), group=group)
     return out
 
 

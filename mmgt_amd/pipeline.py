@@ -16,7 +16,7 @@ from typing import Callable, List, Optional, Union
 import numpy as np
 import torch
 
-from . import hip
+from . import hip, parallel
 from .context import get_context_scheduler
 
 
@@ -71,12 +71,23 @@ class Pose2VideoPipeline:
         latents = latents.to(device=device, dtype=torch.float32)
         return (latents * self.scheduler.init_noise_sigma).contiguous()
 
-    def decode_latents(self, latents):
-        """pipeline_pose2vid_long.py:112-125: frame-by-frame VAE decode of z / 0.18215, (x/2+0.5).clamp(0,1), fp32 CPU."""
+    def decode_latents(self, latents, window_group=None):
+        """pipeline_pose2vid_long.py:112-125: frame-by-frame VAE decode of z / 0.18215, (x/2+0.5).clamp(0,1), fp32 CPU.
+        With a window_group the frames (independent units) are dealt in contiguous runs to the ranks and all-gathered, so
+        every rank returns the whole video ("VAE decode sharded by frame")."""
         if self.vae is None:
             raise RuntimeError("decode_latents needs a VAE (pass decode=False to get latents)")
-        video = self.vae.decode_video(latents)               # (b, 3, f, H, W) fp32 in [0, 1] on the GPU
-        return video.cpu().float().numpy()
+        if window_group is None:
+            video = self.vae.decode_video(latents)           # (b, 3, f, H, W) fp32 in [0, 1] on the GPU
+            return video.cpu().float().numpy()
+        group = None if window_group is True else window_group
+        world, rank = parallel.dist.get_world_size(group), parallel.dist.get_rank(group)
+        f = latents.shape[2]
+        per = (f + world - 1) // world                       # equal runs (the last ranks repeat the final frame as padding)
+        idx = torch.arange(rank * per, (rank + 1) * per, device=latents.device).clamp_(max=f - 1)
+        part = self.vae.decode_video(latents[:, :, idx])
+        parts = parallel.allgather_window_predictions(part, group)
+        return torch.cat(parts, dim=2)[:, :, :f].cpu().float().numpy()
 
     def interpolate_latents(self, latents, interpolation_factor, device=None):
         """pipeline_pose2vid_long.py:292-335 (no-op below factor 2)."""
@@ -102,8 +113,15 @@ class Pose2VideoPipeline:
     # --------------------------------------------------------------------------------------------- the hot loop
     def denoise(self, latents, timesteps, encoder_hidden_states, pose_fea, audio_tensor_pre, full_masks, face_masks,
                 lip_masks, guidance_scale, motion_scale, context_frames, context_stride, context_overlap,
-                context_schedule="uniform", num_inference_steps=None, callback=None, callback_steps=1):
-        """pipeline_pose2vid_long.py:494-643.  latents (1, C, L, h, w) fp32 on the GPU; returns the final latents."""
+                context_schedule="uniform", num_inference_steps=None, callback=None, callback_steps=1,
+                window_group=None):
+        """pipeline_pose2vid_long.py:494-643.  latents (1, C, L, h, w) fp32 on the GPU; returns the final latents.
+
+        window_group: a torch.distributed process group (or True for the default group) turns on window-parallel sampling of
+        ONE long video: the windows of a DDIM step are dealt round-robin to the ranks, each round
+        ends in one all-gather of the per-window predictions (RCCL over xGMI on the GPUs, 1.6 MB per rank), and every rank
+        then accumulates ALL windows in the reference's window order and applies the identical overlap-average + CFG + DDIM
+        update -- so the latents stay bit-identical on every rank and to the single-process run, with no other exchange."""
         video_length = latents.shape[2]
         dev = latents.device
         sched = get_context_scheduler(context_schedule)
@@ -125,13 +143,29 @@ class Pose2VideoPipeline:
         for i, t in enumerate(timesteps):
             pred_sum = torch.zeros((2,) + tuple(latents.shape[1:]), device=dev, dtype=torch.float32)
             counter = torch.zeros((video_length,), device=dev, dtype=torch.float32)
-            for c_long, c_idx, cd in zip(win_long, win_idx, cond):
-                latent_in = self.scheduler.scale_model_input(latents[:, :, c_long].repeat(2, 1, 1, 1, 1), t)
-                pred = self.denoising_unet.denoise_window(
+            def run_window(w):
+                cd = cond[w]
+                latent_in = self.scheduler.scale_model_input(latents[:, :, win_long[w]].repeat(2, 1, 1, 1, 1), t)
+                return self.denoising_unet.denoise_window(
                     latent_in, t, encoder_hidden_states=encoder_hidden_states, audio_embedding=cd["audio"],
                     pose_cond_fea=cd["pose"], full_mask=cd["full"], face_mask=cd["face"], body_mask=cd["lips"],
                     motion_scale=motion_scale)
-                hip.accumulate_window(pred, pred_sum, counter, c_idx, C)
+
+            if window_group is None:
+                for w in range(len(windows)):
+                    hip.accumulate_window(run_window(w), pred_sum, counter, win_idx[w], C)
+            else:
+                group = None if window_group is True else window_group
+                world, rank = parallel.dist.get_world_size(group), parallel.dist.get_rank(group)
+                pred_shape = (2, C, len(windows[0])) + tuple(latents.shape[3:])
+                for w0 in range(0, len(windows), world):
+                    mine = w0 + rank
+                    pred = run_window(mine) if mine < len(windows) else \
+                        torch.zeros(pred_shape, device=dev, dtype=torch.float32)     # idle rank in the last round
+                    preds = parallel.allgather_window_predictions(pred.float(), group)
+                    for r in range(world):
+                        if w0 + r < len(windows):
+                            hip.accumulate_window(preds[r], pred_sum, counter, win_idx[w0 + r], C)
             sa_t, sb_t, sa_p, sb_p = self.scheduler.step_coefficients(t)
             latents = hip.cfg_ddim_step(pred_sum, counter, latents, float(guidance_scale), sa_t, sb_t, sa_p, sb_p)
             if callback is not None and i % callback_steps == 0:
@@ -206,14 +240,15 @@ class Pose2VideoPipeline:
         # ---- denoising loop ---------------------------------------------------------------------------------
         latents = self.denoise(latents, timesteps, encoder_hidden_states, pose_fea, audio_pre, full_masks, face_masks,
                                lip_masks, guidance_scale, motion_scale, context_frames, context_stride, context_overlap,
-                               context_schedule, num_inference_steps, callback, callback_steps)
+                               context_schedule, num_inference_steps, callback, callback_steps,
+                               window_group=kwargs.get("window_group"))
         unet.clear_banks()                                                                # :645-646
 
         if interpolation_factor > 0:
             latents = self.interpolate_latents(latents, interpolation_factor, dev)
         if not kwargs.get("decode", True):
             return Pose2VideoPipelineOutput(videos=latents) if return_dict else latents
-        images = self.decode_latents(latents)
+        images = self.decode_latents(latents, kwargs.get("window_group"))
         if output_type == "tensor":
             images = torch.from_numpy(images)
         if not return_dict:

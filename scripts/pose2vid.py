@@ -41,6 +41,9 @@ def parse_args():
     p.add_argument("--synthetic", action="store_true")
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-decode", action="store_true")
+    p.add_argument("--window-parallel", action="store_true",
+                   help="one long video over all ranks of a torch.distributed.run launch: the windows of every DDIM step are "
+                        "dealt to the ranks, one RCCL all-gather per round (SURVEY 8e, config 5)")
     return p.parse_args()
 
 
@@ -70,14 +73,21 @@ def main():
     a = parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("pose2vid needs an MI355X (the product has no CPU path)")
-    dev = torch.device("cuda:0")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    rank = 0
+    if a.window_parallel:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)        # RANK / WORLD_SIZE / MASTER_* from torch.distributed.run
+        rank = dist.get_rank()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     if not a.synthetic:
         raise SystemExit("non-synthetic runs need the reference's checkpoints and PyAV/cv2 video decoding, which this "
                          "build does not include; see INTEGRATION.md for wiring mmgt_amd into the reference's own script")
     from mmgt_amd.synthetic import hash_uniform, synth_masks
     t0 = time.time()
-    pipe = build_synthetic(dev, dtype)
+    pipe = build_synthetic(dev, dtype)                   # same hash-seeded weights on every rank
     t_build = time.time() - t0
     lat = a.H // 8
     gen = torch.manual_seed(a.seed)                           # :171
@@ -89,9 +99,14 @@ def main():
     t0 = time.time()
     out = pipe(None, pose, audio, full, face, lips, a.W, a.H, a.L, a.steps, a.cfg, generator=gen,
                motion_scale=[1.0, 1.0, 2.0], context_frames=a.num_c, clip_image_embeds=hash_uniform("p2v.clip", (1, 768), 1.0),
-               ref_image_latents=hash_uniform("p2v.reflat", (1, 4, lat, a.W // 8), 1.0), decode=not a.no_decode)
+               ref_image_latents=hash_uniform("p2v.reflat", (1, 4, lat, a.W // 8), 1.0), decode=not a.no_decode,
+               window_group=True if a.window_parallel else None)
     torch.cuda.synchronize()
     dt = time.time() - t0
+    if a.window_parallel:
+        dist.destroy_process_group()
+        if rank != 0:                                         # every rank holds the same video; rank 0 writes it
+            return
     v = out.videos
     os.makedirs(a.out_dir, exist_ok=True)
     path = os.path.join(a.out_dir, f"pose2vid_synth_{a.W}x{a.H}x{a.L}.pt")

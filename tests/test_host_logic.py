@@ -188,6 +188,78 @@ def test_clip_parallel_plumbing_world_size_2():
     assert res[0][2] == [0, 2, 4] and res[1][2] == [1, 3]
 
 
+class _FakeWindowUNet:
+    """Test double for the window-parallel host logic only (the HIP UNet has no CPU path): a deterministic, window- and
+    conditioning-dependent function of its inputs."""
+    device = torch.device("cpu")
+
+    def denoise_window(self, latent_in, t, encoder_hidden_states, audio_embedding, pose_cond_fea, full_mask, face_mask,
+                       body_mask, motion_scale):
+        a = audio_embedding.float().mean(dim=(2, 3)).view(2, 1, -1, 1, 1)
+        return (latent_in * (0.9 - 1e-4 * float(t)) + 0.1 * a + 0.01 * full_mask[0].float().mean()).float()
+
+
+def _install_cpu_doubles(monkeypatch_target):
+    """CPU restatements of the two elementwise HIP ops the loop calls (pipeline_pose2vid_long.py:621-635), for this test."""
+    def accumulate_window(pred, pred_sum, counter, idx, C):
+        pred_sum[:, :, idx.long()] += pred
+        counter[idx.long()] += 1
+
+    def cfg_ddim_step(pred_sum, counter, latents, g, sa_t, sb_t, sa_p, sb_p):
+        avg = pred_sum / counter.view(1, 1, -1, 1, 1)
+        v = avg[0:1] + g * (avg[1:2] - avg[0:1])
+        x0 = sa_t * latents - sb_t * v
+        eps = sa_t * v + sb_t * latents
+        return sa_p * x0 + sb_p * eps
+    monkeypatch_target.accumulate_window = accumulate_window
+    monkeypatch_target.cfg_ddim_step = cfg_ddim_step
+
+
+def _window_parallel_run(window_group):
+    from mmgt_amd import pipeline as PL
+    _install_cpu_doubles(PL.hip)
+    sched = DDIMScheduler()
+    sched.set_timesteps(4)
+    pipe = PL.Pose2VideoPipeline(vae=None, image_encoder=None, reference_unet=None, denoising_unet=_FakeWindowUNet(),
+                                 pose_guider=None, scheduler=sched)
+    g = torch.Generator().manual_seed(7)
+    L, hw = 40, 4
+    lat = torch.randn(1, 4, L, hw, hw, generator=g)
+    audio = torch.randn(2, L, 3, 5, generator=g)
+    masks = [torch.rand(2 * L, hw * hw, generator=g)]
+    return pipe.denoise(lat, sched.timesteps, torch.zeros(2, 1, 8), None, audio, masks, masks, masks, 3.5, None,
+                        context_frames=12, context_stride=1, context_overlap=4, num_inference_steps=4,
+                        window_group=window_group)
+
+
+def _wp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        q.put((rank, _window_parallel_run(True).numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_window_parallel_denoise_world_size_2_is_bit_identical():
+    """40 frames / context 12 / overlap 4 = 5 windows over 2 ranks (3 rounds, rank 1 idle in the last):
+    both ranks end with the same latents, equal bit for bit to the single-process loop."""
+    import torch.multiprocessing as mp
+    want = _window_parallel_run(None).numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_wp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0], want) and np.array_equal(res[1], want)
+
+
 # ------------------------------------------------------------------------------------------------ conditioning layout
 def test_process_audio_emb_matches_reference_loop():
     from mmgt_amd.conditioning import process_audio_emb

@@ -94,3 +94,25 @@ def test_pipeline_bf16_runs_and_stays_close(weights):
     d = (got - want).abs()
     print("bf16 pipeline final latents: max|d|", d.max().item(), "mean|d|", d.mean().item(), "mean|x|", want.abs().mean().item())
     assert torch.isfinite(got).all() and d.mean() < 3e-2 and d.max() < 0.3
+
+
+def test_window_parallel_group_path_equals_serial_loop(weights):
+    """SURVEY 8e config 5 on the device: the window-parallel branch (RCCL all-gather per round; here a 1-rank group, the
+    multi-rank dealing is covered by the gloo test) leaves the latents bit-identical to the serial window loop."""
+    import os
+    import torch.distributed as dist
+    sds, _ = weights
+    inp = _inputs(14, 8)
+    pipe = _build(sds, torch.bfloat16)
+    kw = dict(motion_scale=[1.0, 1.0, 2.0], context_frames=8, context_overlap=2, latents=inp["latents"],
+              clip_image_embeds=inp["clip"], ref_image_latents=inp["ref_lat"])
+    serial = pipe(None, inp["pose"], inp["audio"], inp["full"], inp["face"], inp["lips"], 64, 64, 14, 2, 3.5, **kw).videos
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        par = pipe(None, inp["pose"], inp["audio"], inp["full"], inp["face"], inp["lips"], 64, 64, 14, 2, 3.5,
+                   window_group=True, **kw).videos
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(serial, par)
