@@ -10,6 +10,9 @@
 #include "common.h"
 #include "mmgt_hip.h"
 
+// Experiment knobs (mmgt_tune "attn_stag_shift" / "attn_stag_sleep"): start-up stagger of the workgroups that share a CU.
+int g_attn_stag_shift = 8, g_attn_stag_sleep = 0;
+
 namespace {
 
 struct AttnParams {
@@ -21,12 +24,15 @@ struct AttnParams {
   int nq, nk;
   int nqb, npairs, heads;
   float scale_log2e;
+  int stag_shift, stag_sleep;
 };
 
-constexpr int KT = 64;  // keys per LDS tile
-
-template <typename T, int HD, int NW, bool VT>
+// KT = keys per LDS tile: 64, or 32 for the short key sets (temporal attention over <= 32 frames, the 32 audio tokens),
+// where a 64-key tile would spend half its MFMAs, exponentials and LDS on masked keys.
+template <typename T, int HD, int NW, bool VT, int KT>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_kernel(AttnParams p) {
+  constexpr int NSUB = KT / 32;                 // 32-key score sub-tiles per LDS tile
+  static_assert(KT == 32 || KT == 64, "KT");
   constexpr int ESZ = sizeof(T);
   constexpr int VEC = 16 / ESZ;                 // elements per 16-byte vector
   constexpr int HDK = (HD + 15) / 16 * 16;      // QK^T reduction length (zero padded)
@@ -37,12 +43,29 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
   constexpr int RSV = VT ? (KT * ESZ + (ESZ == 2 ? 8 : 16)) : (HDV * ESZ + 16);
   constexpr int VROWS = VT ? HDV : KT;
   constexpr int NT = NW * 64;
-  __shared__ __attribute__((aligned(16))) char smem[KT * RSK + VROWS * RSV];
-  char* lK = smem;
-  char* lV = smem + KT * RSK;
+  // The kernel is VALU-bound at head_dim 40, so two per-score VALU operations ride in the MFMAs' zero padding instead:
+  //  MFOLD: spare reduction slots of the score product (hd 40 -> 48) carry -M: Q'[q][HD..HD+1] = -(M_hi, M_lo) against
+  //         K[key][HD..HD+1] = 1, so the MFMA starts from a literal-zero accumulator (no per-element v_mov of -M);
+  //  LSUM:  a spare row of V^T (hd 40 -> 64, 80 -> 96) is all ones, so row HD of O^T accumulates the softmax denominator
+  //         (of the probabilities as rounded for the P.V product) -- no per-element add.
+  constexpr bool MFOLD = HDK - HD >= 2;
+  constexpr bool LSUM = HDV > HD;
+  // NBUF = 2 double-buffers the staged tiles (tile t+1 is written into the other buffer at the END of tile t's work, so
+  // one barrier per tile both publishes it and retires the buffer it replaces).  Measured on MI355X: no gain over the
+  // single buffer with two barriers (hd 40: 2816 vs 2812 us, hd 80: 290 vs 279 us) at twice the LDS, so it stays off.
+  constexpr int TILE_BYTES = KT * RSK + VROWS * RSV;
+  constexpr int NBUF = 1;
+  __shared__ __attribute__((aligned(16))) char smem[NBUF * TILE_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
+  // The workgroups resident on one CU run the same program on tiles of the same length: started together they stay in
+  // lockstep (every SIMD's waves are in their MFMA phase together, then in their softmax phase together).  A start-up
+  // delay of a third of a tile per co-resident workgroup lets one wave's MFMAs run under another's VALU work.
+  if (NW >= 4 && p.stag_sleep > 0) {
+    const int ph = (int)((blockIdx.x >> p.stag_shift) % 3u);
+    for (int i = 0; i < ph * p.stag_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+  }
   // XCD-aware mapping (1-D grid): workgroup ids are dealt round-robin over the 8 XCDs, so id = slot * 8 + xcd.  All query
   // blocks of one (batch, head) pair are placed on ONE XCD (pair = xcd + 8 * (slot / nqb)): their K/V tiles are then
   // re-read from that XCD's L2 instead of crossing the fabric once per query block.
@@ -111,7 +134,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
   constexpr int KVEC = PF ? (KT * NVK + NT - 1) / NT : 1;
   constexpr int VVEC = PF ? (VR * NVV + NT - 1) / NT : 1;
   u32x4 rk[KVEC], rv[VVEC];
-  for (int i = tid * 16; i < KT * RSK + VROWS * RSV; i += NT * 16) *reinterpret_cast<u32x4*>(smem + i) = (u32x4)(0u);
+  for (int i = tid * 16; i < NBUF * TILE_BYTES; i += NT * 16) *reinterpret_cast<u32x4*>(smem + i) = (u32x4)(0u);
+  if (MFOLD || LSUM) {
+    __syncthreads();   // the padding constants below overwrite zeros written by other threads
+    for (int r = tid; r < NBUF * KT; r += NT) {
+      char* bK = smem + (r / KT) * TILE_BYTES;
+      char* bV = bK + KT * RSK;
+      const int rr = r % KT;
+      if (MFOLD) {
+        Elem<T>::st(reinterpret_cast<T*>(bK + rr * RSK) + HD, 1.f);
+        Elem<T>::st(reinterpret_cast<T*>(bK + rr * RSK) + HD + 1, 1.f);
+      }
+      if (LSUM) {
+        if (VT) Elem<T>::st(reinterpret_cast<T*>(bV + HD * RSV) + rr, 1.f);
+        else Elem<T>::st(reinterpret_cast<T*>(bV + rr * RSV) + HD, 1.f);
+      }
+    }
+  }
 
   struct TileSrc { const T *kb, *vb; long kts, vts; int nks, kt; };
   auto tile_src = [&](int it) {
@@ -150,11 +189,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
       return *reinterpret_cast<const u32x4*>(t.vb + (long)key * t.vts + (long)head * HD + vc * VEC);
     }
   };
-  auto store_k = [&](int idx, u32x4 v) {
+  auto store_k = [&](char* lK, int idx, u32x4 v) {
     const int row = idx / NVK, vc = idx - row * NVK;
     *reinterpret_cast<u32x4*>(lK + row * RSK + vc * 16) = v;
   };
-  auto store_v = [&](int idx, u32x4 v) {
+  auto store_v = [&](char* lV, int idx, u32x4 v) {
     const int row = idx / NVV, vc = idx - row * NVV;
     if (VT && ESZ == 2) {  // 136-byte rows: two 8-byte stores keep natural alignment
       u32x2* dst = reinterpret_cast<u32x2*>(lV + row * RSV + vc * 16);
@@ -215,41 +254,50 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
       }
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int buf) {
+    char* bK = smem + buf * TILE_BYTES;
+    char* bV = bK + KT * RSK;
 #pragma unroll
     for (int i = 0; i < KVEC; ++i) {
       const int idx = tid + i * NT;
-      if ((i + 1) * NT <= KT * NVK || idx < KT * NVK) store_k(idx, rk[i]);
+      if ((i + 1) * NT <= KT * NVK || idx < KT * NVK) store_k(bK, idx, rk[i]);
     }
 #pragma unroll
     for (int i = 0; i < VVEC; ++i) {
       const int idx = tid + i * NT;
-      if ((i + 1) * NT <= VR * NVV || idx < VR * NVV) store_v(idx, rv[i]);
+      if ((i + 1) * NT <= VR * NVV || idx < VR * NVV) store_v(bV, idx, rv[i]);
     }
   };
   // single-wave variant (temporal / tiny sequences): straight global -> LDS staging, rolled loops, no prefetch registers
   auto stage_direct = [&](int it) {
     const TileSrc t = tile_src(it);
-    for (int idx = tid; idx < KT * NVK; idx += NT) store_k(idx, load_k(t, idx));
-    for (int idx = tid; idx < VR * NVV; idx += NT) store_v(idx, load_v(t, idx, false));
+    for (int idx = tid; idx < KT * NVK; idx += NT) store_k(smem, idx, load_k(t, idx));
+    for (int idx = tid; idx < VR * NVV; idx += NT) store_v(smem + KT * RSK, idx, load_v(t, idx, false));
   };
 
   if (PF) prefetch(0);
+  if (NBUF == 2) commit(0);
   for (int it = 0; it < ntiles; ++it) {
     const bool s1 = it >= nt0;
     const int nks = s1 ? p.nk2 : p.nk;
     const int kt = (s1 ? it - nt0 : it) * KT;
-    __syncthreads();     // every wave has finished reading the previous tile
-    if (PF) commit();
-    else stage_direct(it);
-    __syncthreads();
+    const char* lK = smem + (NBUF == 2 ? (it & 1) * TILE_BYTES : 0);
+    const char* lV = lK + KT * RSK;
+    if (NBUF == 2) {
+      __syncthreads();   // tile `it` is visible, and every wave has left the buffer tile it + 1 will replace
+    } else {
+      __syncthreads();   // every wave has finished reading the previous tile
+      if (PF) commit(0);
+      else stage_direct(it);
+      __syncthreads();
+    }
     if (PF && it + 1 < ntiles) prefetch(it + 1);
 
     // ---- S^T - M = K . Q'^T - M for the two 32-key sub-tiles ----
-    f32x16 s[2];
+    f32x16 s[NSUB];
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      s[sub] = (f32x16)(-m_run);
+    for (int sub = 0; sub < NSUB; ++sub) {
+      s[sub] = MFOLD ? (f32x16)(0.f) : (f32x16)(-m_run);
       const char* kp = lK + (sub * 32 + lr) * RSK + lh * 8 * ESZ;
 #pragma unroll
       for (int ks = 0; ks < KSQ; ++ks) {
@@ -260,40 +308,50 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
     }
     if (kt + KT > nks) {   // ragged last tile only: mask the keys past the end
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub)
+      for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (kt + sub * 32 + acc_row(r, lane) >= nks) s[sub][r] = -1e30f;
     }
-    float mt = fmaxf(s[0][0], s[1][0]);
+    float mt = fmaxf(s[0][0], s[NSUB - 1][0]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(s[0][r], s[1][r]));
+    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(s[0][r], s[NSUB - 1][r]));
     mt = fmaxf(mt, __shfl_xor(mt, 32));
     if (it == 0 || __any(mt > 0.f)) {
       // the first tile fixes M at the tile maximum (either sign); later tiles only ever raise it
-      const float delta = it == 0 ? mt : fmaxf(mt, 0.f);
+      float delta = it == 0 ? mt : fmaxf(mt, 0.f);
+      if (MFOLD) {
+        // the reference the MFMA subtracts is M_hi + M_lo in the storage type: move M to the nearest such value
+        const float m_new = m_run + delta;
+        const float hi = Elem<T>::cvt(m_new), lo = Elem<T>::cvt(m_new - hi);
+        delta = (hi + lo) - m_run;
+        if (lh == 1) {   // lanes holding d = HD .. HD + 7 of the last K-step
+          qf[KSQ - 1].set(0, -hi);
+          qf[KSQ - 1].set(1, -lo);
+        }
+      }
       const float alpha = __builtin_amdgcn_exp2f(-delta);
       m_run += delta;
-      l_run *= alpha;
+      if (!LSUM) l_run *= alpha;
 #pragma unroll
       for (int i = 0; i < DT; ++i) o[i] *= alpha;
 #pragma unroll
-      for (int sub = 0; sub < 2; ++sub) s[sub] -= delta;
+      for (int sub = 0; sub < NSUB; ++sub) s[sub] -= delta;
     }
     float ls = 0.f;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+    for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pv = __builtin_amdgcn_exp2f(s[sub][r]);
         s[sub][r] = pv;
-        ls += pv;
+        if (!LSUM) ls += pv;
       }
-    l_run += ls;
+    if (!LSUM) l_run += ls;
 
     // ---- O^T += V^T . P^T ----
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+    for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         Frag<T> pf;
@@ -333,10 +391,18 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
           mma32(o[dt], vf, pf);
         }
       }
+    if (NBUF == 2 && it + 1 < ntiles) commit((it + 1) & 1);
   }
 
   // ---- normalise and store: lane (q, half) owns d = 32 dt + 8 g + 4 half + (0..3) ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  float l_tot;
+  if (LSUM) {   // row HD of O^T: accumulator register and lane half that hold it
+    constexpr int R = HD % 32, REG = (R & 3) + 4 * (R >> 3), LHS = (R >> 2) & 1;
+    const float mine = o[HD / 32][REG], other = __shfl_xor(mine, 32);
+    l_tot = lh == LHS ? mine : other;
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32);
+  }
   const float inv = 1.f / l_tot;
   const int qi = q0 + lr;
   if (qi < p.nq) {
@@ -368,16 +434,19 @@ int launch_hd(AttnParams p, int batch, int heads, int vt, hipStream_t s) {
   // Short sequences (temporal attention, <= 32 frames) use one wave per workgroup; spatial sequences four.
   p.heads = heads;
   p.npairs = batch * heads;
+  const bool short_keys = !vt && p.nk <= 32 && p.nk2 <= 32;   // every key segment fits one 32-key tile
   if (p.nq <= 32) {
     p.nqb = 1;
     dim3 grid(batch * heads);
-    if (vt) hipLaunchKernelGGL((attn_kernel<T, HD, 1, true>), grid, dim3(64), 0, s, p);
-    else hipLaunchKernelGGL((attn_kernel<T, HD, 1, false>), grid, dim3(64), 0, s, p);
+    if (vt) hipLaunchKernelGGL((attn_kernel<T, HD, 1, true, 64>), grid, dim3(64), 0, s, p);
+    else if (short_keys) hipLaunchKernelGGL((attn_kernel<T, HD, 1, false, 32>), grid, dim3(64), 0, s, p);
+    else hipLaunchKernelGGL((attn_kernel<T, HD, 1, false, 64>), grid, dim3(64), 0, s, p);
   } else {
     p.nqb = (p.nq + 127) / 128;
     dim3 grid((unsigned)((long)p.nqb * batch * heads));
-    if (vt) hipLaunchKernelGGL((attn_kernel<T, HD, 4, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attn_kernel<T, HD, 4, false>), grid, dim3(256), 0, s, p);
+    if (vt) hipLaunchKernelGGL((attn_kernel<T, HD, 4, true, 64>), grid, dim3(256), 0, s, p);
+    else if (short_keys) hipLaunchKernelGGL((attn_kernel<T, HD, 4, false, 32>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attn_kernel<T, HD, 4, false, 64>), grid, dim3(256), 0, s, p);
   }
   MMGT_LAUNCH_CHECK();
   return 0;
@@ -422,6 +491,8 @@ extern "C" int mmgt_attention(const void* q, long q_bs0, long q_bs1, long q_ts, 
   p.bdiv = bdiv; p.k2_bdiv = k2 ? k2_bdiv : 1; p.nk2 = k2 ? nk2 : 0; p.seg2_first_batch = seg2_first_batch;
   p.nq = nq; p.nk = nk;
   p.scale_log2e = scale * 1.4426950408889634f;
+  p.stag_shift = g_attn_stag_shift;
+  p.stag_sleep = g_attn_stag_sleep;
   hipStream_t s = (hipStream_t)stream;
   return dtype == MMGT_BF16 ? launch_t<bf16_t>(p, batch, heads, hd, v_transposed, s)
                             : launch_t<float>(p, batch, heads, hd, v_transposed, s);

@@ -21,21 +21,27 @@
 //  * XCD-aware tile order (n fastest inside an XCD's contiguous run) so the tiles sharing an A row panel hit one L2.
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "mmgt_hip.h"
 
 // Main-loop variant (A/B-able by building a second library with -DMMGT_GEMM_VARIANT=n, tools/ab_gemm.py):
 //   bit 0: fragments of K-step ks+1 are read while the MFMAs of K-step ks run (register double buffering) + s_setprio
 //   bit 1: dense 8-wave tiles spread the next chunk's LDS-DMA issue between the MFMA groups instead of one burst
+//   bit 2: the per-chunk barrier sits inside the chunk's MFMA work and the next chunk's first fragments are read early
+//          (applied to the 320-column tiles, whose 2-deep ring depends on it; bit 3 forces it on every tile for A/B runs)
 #ifndef MMGT_GEMM_VARIANT
-#define MMGT_GEMM_VARIANT 3
+#define MMGT_GEMM_VARIANT 7
 #endif
 
 namespace {
 
-constexpr int ROWB = 128;  // bytes of K per tile row per chunk
 constexpr bool V_FRAGDB = (MMGT_GEMM_VARIANT & 1) != 0;
 constexpr bool V_ILV = (MMGT_GEMM_VARIANT & 2) != 0;
+constexpr bool V_LATE = (MMGT_GEMM_VARIANT & 4) != 0;
+constexpr bool V_LATE_ALL = (MMGT_GEMM_VARIANT & 8) != 0;
+constexpr bool V_NODMA = (MMGT_GEMM_VARIANT & 16) != 0;   // timing diagnostic only (wrong results): no LDS-DMA after the ring fill
 
 __device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
 
@@ -122,7 +128,7 @@ __device__ __forceinline__ void quad_transpose(u32x4 (&x)[S], int lane) {
 // already in flight, and the epilogue of tile t (which borrows the ring stage consumed last) runs with them landing
 // and its stores draining under the next main loop.  Measured before this: a 256 x 128 tile paid about 7 us of launch +
 // first-load latency + store drain per tile, as much as a K = 640 main loop.
-template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE>
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE, int ROWB>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN / WN / 32) <= 2) ? 3 : 2) void gemm_kernel(ADesc ad, const char* __restrict__ W, long bsw, Epi ep, int M, int N,
                                                    int K, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -132,9 +138,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int NW = WM * WN;
-  constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;   // 8-row LDS-DMA groups per wave for A and B
-  static_assert((NW == 4 || NW == 8) && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && BM % (8 * NW) == 0 &&
-                    BN % (8 * NW) == 0, "tile");
+  // ROWB = bytes of K per tile row per chunk (128, or 64 for the 256 x 256 tile whose 4-deep ring would not fit otherwise).
+  // One LDS-DMA wave instruction fills 1 KiB = RPD consecutive rows of CPR 16-byte chunks.
+  constexpr int CPR = ROWB / 16, RPD = 1024 / ROWB;
+  constexpr int GA = BM / RPD / NW, GB = BN / RPD / NW;   // LDS-DMA groups per wave for A and B
+  static_assert(ROWB == 128 || ROWB == 64, "ROWB");
+  static_assert((NW == 4 || NW == 8) && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && BM % (RPD * NW) == 0 &&
+                    BN % (RPD * NW) == 0 && KS >= 1, "tile");
+  // XOR swizzle of the 16-byte chunk index by the row: the sixteen lanes of every ds_read_b128 service group (rows r, r+12,
+  // r+20.. of one chunk column) must hit sixteen distinct 16-byte slots of the 256-byte bank period = 2 rows of 128 B or
+  // 4 rows of 64 B.
+  auto swz = [](int row) { return ROWB == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
 
   const int nwg = tiles_m * tiles_n;
   const int bz = blockIdx.z;
@@ -152,7 +166,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   };
 
   // ---- LDS-DMA source addressing: wave `wid` fills 8-row groups g = wid * GA + i; lane -> (row l>>3, slot l&7) ----
-  const int srow = lane >> 3, spos = lane & 7;
+  const int srow = lane / CPR, spos = lane % CPR;
   const T* a0 = reinterpret_cast<const T*>(ad.src0) + (long)bz * ad.bs0;
   const T* a1 = ad.src1 ? reinterpret_cast<const T*>(ad.src1) + (long)bz * ad.bs1 : nullptr;
   const T* wbase = reinterpret_cast<const T*>(W) + (long)bz * bsw;
@@ -168,8 +182,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   auto setup = [&](int tm, int tn) {   // operand addresses of tile (tm, tn), the tile the DMA stream is in
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
-      const int row = (wid * GA + i) * 8 + srow;
-      const int chunk = spos ^ ((row >> 1) & 7);
+      const int row = (wid * GA + i) * RPD + srow;
+      const int chunk = spos ^ swz(row);
       int m = tm * BM + row;
       if (m >= M) m = M - 1;
       if (MODE == 0) {
@@ -185,8 +199,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
     }
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
-      const int row = (wid * GB + i) * 8 + srow;
-      const int chunk = spos ^ ((row >> 1) & 7);
+      const int row = (wid * GB + i) * RPD + srow;
+      const int chunk = spos ^ swz(row);
       int n = tn * BN + row;
       if (n >= N) n = N - 1;
       wptr[i] = reinterpret_cast<const char*>(wbase + (long)n * K) + chunk * 16;
@@ -199,6 +213,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   // global_load_lds costs as many issue cycles as the chunk's 16 MFMAs).  `prep` resolves the per-lane source pointers
   // of the A operand once per chunk (conv: tap / channel decomposition + padding test), `issue` only launches DMAs.
   const char* asrc[GA];
+  bool dma_on = true;
   auto prep = [&](int ch) {
     if (MODE == 0) {
       const long kb = (long)ch * ROWB;   // byte offset along K
@@ -231,6 +246,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
     }
   };
   auto issue = [&](int stage, int ch, int part, int nparts) {  // chunk `ch` of the DMA-side tile -> LDS stage `stage`
+    if (V_NODMA && !dma_on) return;
     char* st = smem + stage * STAGE_BYTES;
     const long kb = (long)ch * ROWB;
 #pragma unroll
@@ -254,8 +270,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   // (quad_transpose): store s of lane (r, h) then covers row S * (lane >> 2 or 1) + s, columns of octet slot r, and one
   // instruction writes 64 / S rows of S * 32 contiguous bytes (full 128-byte lines for a 64-column wave tile).  No LDS
   // round trip, no barrier: waves drift into the next tile's chunks independently.
-  static_assert(TN <= 2, "epilogue: wave tiles wider than 64 columns are not laid out");
-  constexpr bool RES_PF = ESZ == 2 && TM * TN <= 4;   // wide wave tiles have no registers to spare for it
+  static_assert(TN <= 6, "epilogue: column groups of two 32-column tiles, at most three of them");
+  constexpr bool RES_PF = ESZ == 2 && TM * TN <= 4 && TN <= 2;   // wide wave tiles have no registers to spare for it
   // ---- the chunk stream of this workgroup: tiles vt = blockIdx.x + k * gridDim.x, nchunks chunks each ----
   const int nchunks = K / BK;
   const int G = gridDim.x;
@@ -270,6 +286,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   }
   auto advance_dma = [&]() {   // bookkeeping after chunk (vt_i, ich) has been issued
     ++gi;
+    if (V_NODMA && gi >= NSTAGE) dma_on = false;
     sl = sl + 1 == NSTAGE ? 0 : sl + 1;
     if (++ich == nchunks) {
       ich = 0;
@@ -281,10 +298,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
       }
     }
   };
+  // LATE (see the main loop): the ring runs one chunk fuller, the stage of chunk c is refilled inside chunk c's own work
+  constexpr bool LATE = V_LATE && (BN == 320 || V_LATE_ALL) && KS >= 2 && KS % 2 == 0;
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
+  for (int s = 0; s < NSTAGE - (LATE ? 0 : 1); ++s)
     if (gi < total) { prep(ich); issue(sl, ich, 0, 1); advance_dma(); }
+  // at most `younger` whole chunks of LDS-DMA (GA + GB ops per wave each) may stay in flight; vmcnt retires in order, so
+  // allowing fewer than are really younger only waits longer
+  auto wait_chunks = [&](int younger) {
+    if (younger <= 0) wait_vmcnt<0>();
+    else if (younger == 1) wait_vmcnt<(GA + GB)>();
+    else if (younger == 2 || NSTAGE <= 3) wait_vmcnt<2 * (GA + GB)>();
+    else wait_vmcnt<3 * (GA + GB)>();
+  };
 
+  if (LATE) {
+    wait_chunks(gi - 1);
+    __builtin_amdgcn_s_barrier();
+  }
   for (int vt = blockIdx.x; vt < nwg; vt += G) {
     int tm, tn;
     decode(vt, tm, tn);
@@ -295,6 +326,41 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16)(0.f);
+
+    // fragments of one K-step: lane (row lr [+32 i], k-half lh) reads its 8 consecutive k values from stage `st`
+    auto load_frags = [&](const char* st, int ks, Frag<T>* pa, Frag<T>* pb) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int r = arow + 32 * i;
+        const int sw = swz(r);
+        if (ESZ == 2) {
+          frag_load(pa[i], reinterpret_cast<const T*>(st + r * ROWB + (((2 * ks + lh) ^ sw) << 4)));
+        } else {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * ROWB + (((4 * ks + 2 * lh) ^ sw) << 4));
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * ROWB + (((4 * ks + 2 * lh + 1) ^ sw) << 4));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { pa[i].set(j, lo[j]); pa[i].set(4 + j, hi[j]); }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int r = brow + 32 * j;
+        const int sw = swz(r);
+        const char* sb = st + A_BYTES;
+        if (ESZ == 2) {
+          frag_load(pb[j], reinterpret_cast<const T*>(sb + r * ROWB + (((2 * ks + lh) ^ sw) << 4)));
+        } else {
+          const f32x4 lo = *reinterpret_cast<const f32x4*>(sb + r * ROWB + (((4 * ks + 2 * lh) ^ sw) << 4));
+          const f32x4 hi = *reinterpret_cast<const f32x4*>(sb + r * ROWB + (((4 * ks + 2 * lh + 1) ^ sw) << 4));
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) { pb[j].set(jj, lo[jj]); pb[j].set(4 + jj, hi[jj]); }
+        }
+      }
+    };
+    Frag<T> fa[2][TM], fb[2][TN];
+    // LATE: the tile's first chunk was waited for and published by the previous chunk's barrier (or the one in front of
+    // the tile loop), before this tile's epilogue-operand loads and the previous tile's stores entered the vmcnt queue
+    if (LATE) load_frags(smem + sc * STAGE_BYTES, 0, fa[0], fb[0]);
 
     // ---- epilogue operands requested before the main loop, so their latency hides under it:
     //  * residual (bf16 fast path): the lane's 16-byte vectors in the octet layout of the epilogue (measured, earlier
@@ -308,7 +374,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
     // Store-layout coordinates of this lane (non-GEGLU: S = 2 TN slots per row block; see "epilogue geometry"):
     // vector s of row block i is row 32 i + S * (lr / S) + s, columns 32 * (r >> 1) + 16 * (r & 1) + 8 h with r = lr % S
     // (for S = 2: 16 r + 8 h).
-    constexpr int SN = 2 * TN;
+    constexpr int SN = TN <= 2 ? 2 * TN : 2;   // residual prefetch exists for narrow wave tiles only (one column group)
     const int sr = lr & (SN - 1), srow = lr & ~(SN - 1);
     const int scol = (SN == 4 ? 32 * (sr >> 1) + 16 * (sr & 1) : 16 * sr) + 8 * lh;
     u32x4 rres[RES_PF ? TM : 1][RES_PF ? SN : 1];
@@ -340,12 +406,64 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
       bsum[j][1] = b + ((ok && ep.bias2 && b2two) ? ep.bias2[(long)(b2r0 + 1) * N + n] : 0.f);
     }
 
+    if (LATE) {
+      // One barrier per chunk, placed INSIDE the chunk's MFMA work (after K-step KS-2 has been queued) instead of in
+      // front of it: by then every read of this chunk has returned, so the barrier both frees its stage for the next
+      // LDS-DMA and publishes the next chunk, whose first fragments are then read under the last K-step's MFMAs.  The
+      // matrix pipe no longer idles through barrier skew + LDS read latency at every chunk start.
+      // The refill of the freed stage is issued in KS slices (V_ILV): one right after the barrier, the others behind the
+      // following MFMA groups (across the chunk boundary), so no wave pays a burst of LDS-DMA issue slots at once.
+      constexpr bool ILVL = V_ILV;
+      bool pendf = false;
+      int pst = 0, pch = 0;
+      for (int ch = 0; ch < nchunks; ++ch, ++gc) {
+        const bool last = ch == nchunks - 1;
+        const char* st = smem + sc * STAGE_BYTES;
+        const int nsc = sc + 1 == NSTAGE ? 0 : sc + 1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          if (ks + 1 < KS) load_frags(st, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mma32(acc[i][j], fb[ks & 1][j], fa[ks & 1][i]);   // D[n][m]
+          __builtin_amdgcn_s_setprio(0);
+          if (ks == KS - 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of the chunk have all returned
+            if (gc + 1 < total) wait_chunks(gi - gc - 2);         // this wave's share of chunk gc + 1 has landed
+            __builtin_amdgcn_s_barrier();
+            if (!last) load_frags(smem + nsc * STAGE_BYTES, 0, fa[0], fb[0]);
+            if (gi < total) {                                     // refill the stage just freed
+              prep(ich);
+              if (ILVL) {
+                pendf = true; pst = sc; pch = ich;
+                issue(pst, pch, 0, KS);
+                if (KS == 1) { advance_dma(); pendf = false; }
+              } else {
+                issue(sc, ich, 0, 1);
+                advance_dma();
+              }
+            }
+          } else if (ILVL && pendf) {
+            constexpr int KSm = KS > 0 ? KS : 1;
+            const int part = (ks + 2) % KSm;
+            issue(pst, pch, part, KS);
+            if (part == KS - 1) { advance_dma(); pendf = false; }
+          }
+        }
+        sc = nsc;
+      }
+      if (ILVL && pendf) {   // tile end: slices 0 (barrier) and 1 (last K-step) are out, the rest goes now
+#pragma unroll
+        for (int part = 2; part < KS; ++part) issue(pst, pch, part, KS);
+        advance_dma();
+        pendf = false;
+      }
+    } else {
     for (int ch = 0; ch < nchunks; ++ch, ++gc) {
       // chunk gc must have landed; up to NSTAGE-2 younger chunks may stay in flight (GA + GB LDS-DMA ops per wave each)
-      const int younger = total - 1 - gc;
-      if (NSTAGE == 2 || younger < 1) wait_vmcnt<0>();
-      else if (NSTAGE == 3 || younger < 2) wait_vmcnt<(GA + GB)>();
-      else wait_vmcnt<2 * (GA + GB)>();
+      wait_chunks(gi - gc - 1);
       __builtin_amdgcn_s_barrier();
       // Spreading the DMA issue between MFMA groups pays for the dense 8-wave tiles (+7% at 8192^3); for the conv gather
       // and the 4-wave tiles the burst right after the barrier measured faster.
@@ -359,44 +477,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
 
       const char* st = smem + sc * STAGE_BYTES;
       // fragments of K-step ks+1 are read from LDS while the MFMAs of K-step ks run (register double buffering)
-      Frag<T> fa[2][TM], fb[2][TN];
-      auto load_frags = [&](int ks, Frag<T>* pa, Frag<T>* pb) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int r = arow + 32 * i;
-          const int sw = (r >> 1) & 7;
-          if (ESZ == 2) {
-            frag_load(pa[i], reinterpret_cast<const T*>(st + r * ROWB + (((2 * ks + lh) ^ sw) << 4)));
-          } else {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(st + r * ROWB + (((4 * ks + 2 * lh) ^ sw) << 4));
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(st + r * ROWB + (((4 * ks + 2 * lh + 1) ^ sw) << 4));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { pa[i].set(j, lo[j]); pa[i].set(4 + j, hi[j]); }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int r = brow + 32 * j;
-          const int sw = (r >> 1) & 7;
-          const char* sb = st + A_BYTES;
-          if (ESZ == 2) {
-            frag_load(pb[j], reinterpret_cast<const T*>(sb + r * ROWB + (((2 * ks + lh) ^ sw) << 4)));
-          } else {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(sb + r * ROWB + (((4 * ks + 2 * lh) ^ sw) << 4));
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(sb + r * ROWB + (((4 * ks + 2 * lh + 1) ^ sw) << 4));
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) { pb[j].set(jj, lo[jj]); pb[j].set(4 + jj, hi[jj]); }
-          }
-        }
-      };
-      if (V_FRAGDB) load_frags(0, fa[0], fb[0]);
+      if (V_FRAGDB) load_frags(st, 0, fa[0], fb[0]);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (V_FRAGDB) {
-          if (ks + 1 < KS) load_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+          if (ks + 1 < KS) load_frags(st, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
           __builtin_amdgcn_s_setprio(1);
         } else {
-          load_frags(ks, fa[ks & 1], fb[ks & 1]);
+          load_frags(st, ks, fa[ks & 1], fb[ks & 1]);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -407,6 +495,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
       }
       if (more) advance_dma();
       sc = sc + 1 == NSTAGE ? 0 : sc + 1;
+    }
     }
 
     // ---- bias as one more K-step (fast path):  D[n][m] += sum_c bsum[c][n] * sel[c][m], sel[c][m] = (row m belongs to
@@ -457,125 +546,135 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
         const bool mok = m < M;
         const bool scaled = ep.row_scale != nullptr || ep.alpha != 1.f;   // uniform
         const float rs = (ep.row_scale && mok ? ep.row_scale[m] : 1.f) * ep.alpha;
-        // residual of this row block: prefetched (or loaded here) in the store layout, transposed back to "lane = row"
-        u32x4 rv[OV][SN];
-        if (res) {
-#pragma unroll
-          for (int sidx = 0; sidx < SN; ++sidx) {
-            const int ms = row0 + 32 * i + srow + sidx, ns = col0 + scol;
-            const bool inb = ms < M && ns < N;
-            if (ESZ == 2) {
-              rv[0][sidx] = res_pf ? rres[RES_PF ? i : 0][RES_PF ? sidx : 0]
-                                   : (inb ? *reinterpret_cast<const u32x4*>(res + (long)ms * ep.ldr + ns) : (u32x4)(0u));
-            } else {
-              const u32x4* rp = reinterpret_cast<const u32x4*>(res + (long)ms * ep.ldr + ns);
-              rv[0][sidx] = inb ? rp[0] : (u32x4)(0u);
-              rv[OV - 1][sidx] = inb ? rp[1] : (u32x4)(0u);
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < OV; ++q) quad_transpose<SN>(rv[q], lane);
-        }
-        u32x4 pk[OV][SN];                        // finished octets, slot k = 2 j + g2
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if (geglu && (j & 1)) continue;          // gate tiles are consumed with their h tile
-          f32x16 v = acc[i][j];
-          if (geglu) {
-            // packed weights: tile j = 32 h channels, tile j + 1 = their 32 gates, same lane and register
-            const f32x16 gt = acc[i][(j + 1) < TN ? j + 1 : j];
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-              const f32x2 gl = gelu_erf_f2((f32x2){gt[r], gt[r + 1]});
-              v[r] *= gl[0];
-              v[r + 1] *= gl[1];
-            }
-          } else {
-            if (ep.act == 2) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) v[r] = silu_f(v[r]);
-            } else if (ep.act == 3) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (scaled) v *= rs;
-          }
-#pragma unroll
-          for (int g2 = 0; g2 < 2; ++g2) {
-            const int k = 2 * j + g2;
-            float o8[8];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              // a: n = 16 g2 + e (+4 in the upper lane half), b: n = 16 g2 + 8 + e (+4);  a.hi <-> b.lo
-              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * g2 + e]),
-                                                               __float_as_uint(v[8 * g2 + 4 + e]), false, false);
-              o8[e] = __uint_as_float(sw[0]);
-              o8[4 + e] = __uint_as_float(sw[1]);
-            }
-            if (ESZ == 2) {
-              if (res) {
-                union { u32x4 u; bf16_t e[8]; } r8;
-                r8.u = rv[0][k];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o8[e] += bf16_to_f32(r8.e[e]);
-              }
-              union { bf16_t e[8]; u32x4 u; } p8;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) p8.e[e] = f32_to_bf16(o8[e]);
-              pk[0][k] = p8.u;
-            } else {
-              union { f32x4 f; u32x4 u; } c0, c1;
-              c0.f = (f32x4){o8[0], o8[1], o8[2], o8[3]};
-              c1.f = (f32x4){o8[4], o8[5], o8[6], o8[7]};
-              if (res) {
-                union { u32x4 u; f32x4 f; } r0, r1;
-                r0.u = rv[0][k];
-                r1.u = rv[OV - 1][k];
-                c0.f += r0.f;
-                c1.f += r1.f;
-              }
-              pk[0][k] = c0.u;
-              pk[OV - 1][k] = c1.u;
-            }
-          }
-        }
-        // ---- to the store layout and out
         T* ob = out + (long)(row0 + 32 * i) * ep.ldo;
-        if (!geglu) {
+        // One column group = GN (1 or 2) adjacent 32-column accumulator tiles starting at tile JG: SNg = 2 GN octet slots
+        // per row, transposed across the DPP quad into the store layout (see "epilogue geometry").
+        auto group = [&](auto JGc, auto GNc) {
+          constexpr int JG = decltype(JGc)::value, GN = decltype(GNc)::value, SNg = 2 * GN;
+          const int srg = lr & (SNg - 1), srowg = lr & ~(SNg - 1);
+          const int scolg = 32 * JG + (SNg == 4 ? 32 * (srg >> 1) + 16 * (srg & 1) : 16 * srg) + 8 * lh;
+          // residual of this row block: prefetched (or loaded here) in the store layout, transposed back to "lane = row"
+          u32x4 rv[OV][SNg];
+          if (res) {
 #pragma unroll
-          for (int q = 0; q < OV; ++q) quad_transpose<SN>(pk[q], lane);
+            for (int sidx = 0; sidx < SNg; ++sidx) {
+              const int ms = row0 + 32 * i + srowg + sidx, ns = col0 + scolg;
+              const bool inb = ms < M && ns < N;
+              if (ESZ == 2) {
+                rv[0][sidx] = res_pf ? rres[RES_PF ? i : 0][RES_PF ? sidx : 0]
+                                     : (inb ? *reinterpret_cast<const u32x4*>(res + (long)ms * ep.ldr + ns) : (u32x4)(0u));
+              } else {
+                const u32x4* rp = reinterpret_cast<const u32x4*>(res + (long)ms * ep.ldr + ns);
+                rv[0][sidx] = inb ? rp[0] : (u32x4)(0u);
+                rv[OV - 1][sidx] = inb ? rp[1] : (u32x4)(0u);
+              }
+            }
 #pragma unroll
-          for (int sidx = 0; sidx < SN; ++sidx) {
-            const int ms = row0 + 32 * i + srow + sidx, ns = col0 + scol;
-            if (ms >= M || ns >= N) continue;
-            u32x4* op = reinterpret_cast<u32x4*>(ob + (long)(srow + sidx) * ep.ldo + ns);
-#pragma unroll
-            for (int q = 0; q < OV; ++q) op[q] = pk[q][sidx];
+            for (int q = 0; q < OV; ++q) quad_transpose<SNg>(rv[q], lane);
           }
-        } else {
-          // GEGLU: every even tile j yields 32 output columns = 2 octets per row -> 2 x 2 transposes
+          u32x4 pk[OV][SNg];                       // finished octets, slot k = 2 jj + g2
 #pragma unroll
-          for (int j = 0; j < TN; j += 2) {
+          for (int jj = 0; jj < GN; ++jj) {
+            constexpr int JLAST = TN - 1;
+            const int j = JG + jj;
+            if (geglu && (j & 1)) continue;          // gate tiles are consumed with their h tile
+            f32x16 v = acc[i][j];
+            if (geglu) {
+              // packed weights: tile j = 32 h channels, tile j + 1 = their 32 gates, same lane and register
+              const f32x16 gt = acc[i][j < JLAST ? j + 1 : j];
+#pragma unroll
+              for (int r = 0; r < 16; r += 2) {
+                const f32x2 gl = gelu_erf_f2((f32x2){gt[r], gt[r + 1]});
+                v[r] *= gl[0];
+                v[r + 1] *= gl[1];
+              }
+            } else {
+              if (ep.act == 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = silu_f(v[r]);
+              } else if (ep.act == 3) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+              }
+              if (scaled) v *= rs;
+            }
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+              const int k = 2 * jj + g2;
+              float o8[8];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                // a: n = 16 g2 + e (+4 in the upper lane half), b: n = 16 g2 + 8 + e (+4);  a.hi <-> b.lo
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * g2 + e]),
+                                                                 __float_as_uint(v[8 * g2 + 4 + e]), false, false);
+                o8[e] = __uint_as_float(sw[0]);
+                o8[4 + e] = __uint_as_float(sw[1]);
+              }
+              if (ESZ == 2) {
+                if (res) {
+                  union { u32x4 u; bf16_t e[8]; } r8;
+                  r8.u = rv[0][k];
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) o8[e] += bf16_to_f32(r8.e[e]);
+                }
+                union { bf16_t e[8]; u32x4 u; } p8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) p8.e[e] = f32_to_bf16(o8[e]);
+                pk[0][k] = p8.u;
+              } else {
+                union { f32x4 f; u32x4 u; } c0, c1;
+                c0.f = (f32x4){o8[0], o8[1], o8[2], o8[3]};
+                c1.f = (f32x4){o8[4], o8[5], o8[6], o8[7]};
+                if (res) {
+                  union { u32x4 u; f32x4 f; } r0, r1;
+                  r0.u = rv[0][k];
+                  r1.u = rv[OV - 1][k];
+                  c0.f += r0.f;
+                  c1.f += r1.f;
+                }
+                pk[0][k] = c0.u;
+                pk[OV - 1][k] = c1.u;
+              }
+            }
+          }
+          // ---- to the store layout and out
+          if (!geglu) {
+#pragma unroll
+            for (int q = 0; q < OV; ++q) quad_transpose<SNg>(pk[q], lane);
+#pragma unroll
+            for (int sidx = 0; sidx < SNg; ++sidx) {
+              const int ms = row0 + 32 * i + srowg + sidx, ns = col0 + scolg;
+              if (ms >= M || ns >= N) continue;
+              u32x4* op = reinterpret_cast<u32x4*>(ob + (long)(srowg + sidx) * ep.ldo + ns);
+#pragma unroll
+              for (int q = 0; q < OV; ++q) op[q] = pk[q][sidx];
+            }
+          } else if (GN == 2) {
+            // GEGLU: the (h, gate) tile pair yields 32 output columns = 2 octets per row -> one 2 x 2 transpose
             const int gr = lr & 1, grow = lr & ~1;
 #pragma unroll
             for (int q = 0; q < OV; ++q) {
-              u32x4 t2[2] = {pk[q][2 * j], pk[q][2 * j + 1]};
+              u32x4 t2[2] = {pk[q][0], pk[q][1]};
               quad_transpose<2>(t2, lane);
-              pk[q][2 * j] = t2[0];
-              pk[q][2 * j + 1] = t2[1];
+              pk[q][0] = t2[0];
+              pk[q][1] = t2[1];
             }
 #pragma unroll
             for (int sidx = 0; sidx < 2; ++sidx) {
               const int ms = row0 + 32 * i + grow + sidx;
-              const int ns = col0 + 32 * j + 16 * gr + 8 * lh;          // column in the accumulator's N space
+              const int ns = col0 + 32 * JG + 16 * gr + 8 * lh;          // column in the accumulator's N space
               if (ms >= M || ns >= N) continue;
-              const long ocol = (long)((col0 + 32 * j) >> 1) + 16 * gr + 8 * lh;
+              const long ocol = (long)((col0 + 32 * JG) >> 1) + 16 * gr + 8 * lh;
               u32x4* op = reinterpret_cast<u32x4*>(ob + (long)(grow + sidx) * ep.ldo + ocol);
 #pragma unroll
-              for (int q = 0; q < OV; ++q) op[q] = pk[q][2 * j + sidx];
+              for (int q = 0; q < OV; ++q) op[q] = pk[q][sidx];
             }
           }
-        }
+        };
+        using std::integral_constant;
+        group(integral_constant<int, 0>{}, integral_constant<int, (TN >= 2 ? 2 : 1)>{});
+        if constexpr (TN > 2) group(integral_constant<int, 2>{}, integral_constant<int, (TN >= 4 ? 2 : 1)>{});
+        if constexpr (TN > 4) group(integral_constant<int, 4>{}, integral_constant<int, (TN >= 6 ? 2 : 1)>{});
       }
     } else {
       // generic scalar path (ragged N, unaligned rows, bias2 blocks shorter than a tile): element by element
@@ -614,11 +713,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   }
 }
 
-template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE>
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE, int ROWB = 128>
 int launch_cfg(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = (size_t)NSTAGE * (BM + BN) * ROWB;
-  auto kern = gemm_kernel<T, MODE, BM, BN, WM, WN, NSTAGE>;
+  auto kern = gemm_kernel<T, MODE, BM, BN, WM, WN, NSTAGE, ROWB>;
   static int resident = 0;   // workgroups of this instantiation the whole device holds at once
   if (!resident) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -646,7 +745,7 @@ int launch_cfg(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, i
   return 0;
 }
 
-int g_gemm_cfg = 0;   // 0 = heuristic; 1..5 force a tile configuration (mmgt_tune("gemm_cfg", v), benchmarking only)
+int g_gemm_cfg = 0;   // 0 = heuristic; 1, 3, 6, 9, 12 force a tile configuration (mmgt_tune("gemm_cfg", v), benchmarking only)
 
 template <typename T, int MODE>
 int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
@@ -661,24 +760,37 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     //   cfg 3 (128x64, 3 workgroups / CU)       short reductions, narrow outputs, grids that would not fill the chip.
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
     const long tiles256 = (long)((M + 255) / 256) * ((N + 127) / 128) * batch;
-    if (MODE == 1) cfg = tiles128 < 512 ? 3 : 1;
+    //   cfg 12 (128x320, 8 waves, barrier inside the chunk) outputs whose width is a multiple of 320 on the two large levels:
+    //          the im2col gather / A panel is staged once per 320 columns instead of once per 128 (conv -10..-24%).
+    if (MODE == 1) cfg = (N % 320 == 0 && M >= 49152) ? 12 : tiles128 < 512 ? 3 : 1;
     else if (geglu) cfg = tiles256 >= 256 ? 6 : 1;
+    else if (N == 320 && M >= 49152) cfg = 12;
     else if (K >= 1280) cfg = tiles256 >= 256 ? 6 : 3;
     else if (M >= 131072 && N >= 640) cfg = 6;
     else cfg = 3;
   }
-  if (geglu && (cfg == 3 || cfg == 4 || cfg == 5 || cfg == 8)) cfg = 1;
+  if (geglu && (cfg == 3 || cfg == 12)) cfg = 1;   // GEGLU pairs need 64-column wave tiles
+#ifdef MMGT_GEMM_AB   // A/B builds (make ab) instantiate only the production tiles: seconds instead of minutes
   switch (cfg) {
-    case 1: return launch_cfg<T, MODE, 128, 128, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
-    case 2: return launch_cfg<T, MODE, 128, 128, 2, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
     case 3: return launch_cfg<T, MODE, 128, 64, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
-    case 4: return launch_cfg<T, MODE, 128, 64, 2, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
-    case 5: return launch_cfg<T, MODE, 64, 64, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
     case 6: return launch_cfg<T, MODE, 256, 128, 4, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
-    case 7: return launch_cfg<T, MODE, 256, 128, 4, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
-    case 8: return launch_cfg<T, MODE, 256, 64, 4, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
+    case 12: return launch_cfg<T, MODE, 128, 320, 4, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
     default: return launch_cfg<T, MODE, 128, 128, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
   }
+#else
+  // Tiles measured and dropped (tools/ab_gemm.py, one process, one device): 128x128 / 128x64 with a 3-deep ring, 64x64,
+  // 256x128 with a 2-deep ring, 256x64, 256x256 with a 3-deep ring of 64-byte rows, 256x320 on 8 waves (accumulators +
+  // double-buffered fragments spill inside the main loop) and 256x256 / 256x320 on 4 waves (one wave per SIMD, 512
+  // registers: +4% at 8192^3, -9% on the 16x16 convs, 2-3x slower wherever the spilling epilogue matters).
+  switch (cfg) {
+    case 1: return launch_cfg<T, MODE, 128, 128, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
+    case 3: return launch_cfg<T, MODE, 128, 64, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
+    case 6: return launch_cfg<T, MODE, 256, 128, 4, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
+    case 9: return launch_cfg<T, MODE, 256, 256, 2, 4, 4, 64>(ad, W, bsw, ep, M, N, K, batch, s);
+    case 12: return launch_cfg<T, MODE, 128, 320, 4, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
+    default: return launch_cfg<T, MODE, 128, 128, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
+  }
+#endif
 }
 
 int epi_fast(const Epi& ep, int N, int n_out, int esz) {
@@ -700,8 +812,12 @@ int check_common(int dtype, int M, int N, int K, int act) {
 
 }  // namespace
 
+extern int g_attn_stag_shift, g_attn_stag_sleep;   // attention.hip
+
 extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return 0; }
+  if (key && !strcmp(key, "attn_stag_shift")) { g_attn_stag_shift = value; return 0; }
+  if (key && !strcmp(key, "attn_stag_sleep")) { g_attn_stag_sleep = value; return 0; }
   mmgt_set_error("tune: unknown key");
   return 1;
 }

@@ -93,6 +93,41 @@ def test_gemm_batched_vt(dt):
     assert out[:, :, ntok:].abs().max() == 0
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("cfg", [1, 3, 6, 9, 12])
+def test_gemm_and_conv_forced_tile_configs(dt, cfg):
+    """Every tile configuration the heuristic can pick (128x128, 128x64, 256x128, 256x256 with 64-byte LDS rows, and the
+    320-column tiles with the barrier inside the chunk) against fp64 torch math, incl. ragged M/N, two bias2 rows per
+    tile, residual, a two-source strided conv and persistent workgroups that walk several tiles."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_conv3x3
+    try:
+        hip.tune("gemm_cfg", cfg)
+        for M, N, K in [(700, 640, 192), (1300, 320, 1280), (515, 968, 64)]:
+            a = rnd("a", (M, K), 1.0, dt)
+            w = rnd("w", (N, K), 1.0 / math.sqrt(K), dt)
+            bias = rnd("b", (N,), 0.5)
+            res = rnd("r", (M, N), 1.0, dt)
+            b2 = rnd("b2", ((M + 299) // 300, N), 0.5)
+            out = hip.gemm(a, w, bias, residual=res, bias2=b2, bias2_rows=300)
+            ref = ref_gemm(a, w) + bias.double() + b2.double().repeat_interleave(300, 0)[:M] + res.double()
+            torch.testing.assert_close(out.double(), ref, **tol(dt))
+        x0 = rnd("x0", (5, 64, 12, 12), 1.0, dt)
+        x1 = rnd("x1", (5, 128, 12, 12), 1.0, dt)
+        w = rnd("wc", (320, 192, 3, 3), 1.0 / math.sqrt(9 * 192), dt)
+        b = rnd("bc", (320,), 0.5)
+        ref = F.conv2d(torch.cat([x0, x1], 1).double(), w.double(), b.double(), stride=2, padding=1)
+        out = hip.conv3x3(_nhwc(x0), pack_conv3x3(w), b, x1=_nhwc(x1), stride=2)
+        torch.testing.assert_close(out.double(), _nhwc(ref), **tol(dt))
+        big = rnd("xb", (16, 64, 32, 32), 1.0, dt)                 # 16384 output pixels: several tiles per workgroup
+        wb = rnd("wb", (640, 64, 3, 3), 1.0 / math.sqrt(9 * 64), dt)
+        refb = F.conv2d(big.double(), wb.double(), None, padding=1)
+        outb = hip.conv3x3(_nhwc(big), pack_conv3x3(wb), None)
+        torch.testing.assert_close(outb.double(), _nhwc(refb), **tol(dt))
+    finally:
+        hip.tune("gemm_cfg", 0)
+
+
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 

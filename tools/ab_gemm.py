@@ -56,7 +56,8 @@ def run(cases, cfgs, rounds=5):
 def gemm_case(M, N, K):
     def make():
         a, w = rnd(M, K), rnd(N, K, s=1 / math.sqrt(K))
-        o = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+        o = torch.zeros((M, N), device=dev, dtype=torch.bfloat16)
+        o._is_out = True
         call = lambda L, st: L.mmgt_gemm(a.data_ptr(), K, w.data_ptr(), None, None, 0, None, 1.0, None, 0, o.data_ptr(), N,
                                          M, N, K, 0, 1, 0, 0, 0, 0, 1, st)
         return call, 2 * M * N * K
@@ -70,7 +71,8 @@ def gemm_epi_case(M, N, K, act=0):
         no = N // 2 if act == 1 else N
         b = torch.rand(N, device=dev) - 0.5
         r = None if act == 1 else rnd(M, no)
-        o = torch.empty((M, no), device=dev, dtype=torch.bfloat16)
+        o = torch.zeros((M, no), device=dev, dtype=torch.bfloat16)
+        o._is_out = True
         call = lambda L, st: L.mmgt_gemm(a.data_ptr(), K, w.data_ptr(), b.data_ptr(), None, 0, None, 1.0,
                                          r.data_ptr() if r is not None else None, no, o.data_ptr(), no, M, N, K, act, 1, 0,
                                          0, 0, 0, 1, st)
@@ -81,7 +83,8 @@ def gemm_epi_case(M, N, K, act=0):
 def conv_case(nb, h, cin, cout):
     def make():
         x, w = rnd(nb, h, h, cin), rnd(cout, 3, 3, cin, s=1 / math.sqrt(9 * cin))
-        o = torch.empty((nb, h, h, cout), device=dev, dtype=torch.bfloat16)
+        o = torch.zeros((nb, h, h, cout), device=dev, dtype=torch.bfloat16)
+        o._is_out = True
         call = lambda L, st: L.mmgt_conv3x3_nhwc(x.data_ptr(), cin, None, 0, nb, h, h, 1, 0, w.data_ptr(), None, None, 0, None,
                                                  o.data_ptr(), cout, 0, 1, st)
         return call, 2 * nb * h * h * cout * 9 * cin
@@ -91,6 +94,31 @@ def conv_case(nb, h, cin, cout):
 if __name__ == "__main__":
     cfgs = [int(c) for c in os.environ.get("CFGS", "1,6").split(",")]
     print("libs:", list(libs))
+    # every variant must reproduce the current library (NODMA timing diagnostics, variants with bit 3, are skipped)
+    st0 = torch.cuda.current_stream().cuda_stream
+    for desc, make in [gemm_epi_case(1000, 320, 320), gemm_epi_case(2304, 640, 1280), gemm_epi_case(4096, 2560, 320, 1),
+                       conv_case(3, 16, 192, 320), gemm_case(777, 1280, 2560)]:
+        for cfg in cfgs:
+            outs = {}
+            for lname, L in libs.items():
+                if lname.startswith("_v") and int(lname[2:]) & 8:
+                    continue
+                torch.manual_seed(1)
+                calls, _ = make()
+                L.mmgt_tune(b"gemm_cfg", cfg)
+                calls(L, st0)
+                torch.cuda.synchronize()
+                outs[lname] = calls.__closure__
+            ref = None
+            for lname, cl in outs.items():
+                o = [c.cell_contents for c in cl if torch.is_tensor(c.cell_contents)]
+                o = [t for t in o if getattr(t, "_is_out", False)][0].float()
+                if ref is None:
+                    ref = o
+                else:
+                    d = (o - ref).abs().max().item()
+                    print(f"check {desc} cfg{cfg} {lname}: max|d| vs cur = {d:.3e}")
+                    assert d == 0.0, "variant differs from the current library"
     if os.environ.get("EPI"):
         run([gemm_epi_case(196608, 320, 320), gemm_epi_case(196608, 2560, 320, 1), gemm_epi_case(196608, 320, 1280),
              gemm_epi_case(49152, 640, 640), gemm_epi_case(49152, 5120, 640, 1), gemm_case(196608, 960, 320),
