@@ -64,6 +64,8 @@ int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C1, const fl
 
 /* LayerNorm over the last dimension of a (rows, C) token matrix, optional additive table pe[(row / pe_div) % pe_mod][C]
  * applied AFTER the affine transform (the temporal positional encoding enters q, k and v: motion_module.py:359-366).
+ * With pe == NULL and pe_mod > 1, `beta` is itself a [pe_mod][C] table indexed the same way (the host folds
+ * beta + pe once per model: one vector load per row less, 2x on the L0 temporal norms).
  * Replaces: nn.LayerNorm at attention.py:392-396,450-454,465,677-681,712-716,769; motion_module.py:244,256;
  * mutual_self_attention.py:122,195-199,210; audio_proj.py:119. */
 int mmgt_layernorm(const void* x, long ldx, const float* gamma, const float* beta, float eps, const float* pe, int pe_div,

@@ -10,9 +10,6 @@
 #include "common.h"
 #include "mmgt_hip.h"
 
-// Experiment knobs (mmgt_tune "attn_stag_shift" / "attn_stag_sleep"): start-up stagger of the workgroups that share a CU.
-int g_attn_stag_shift = 8, g_attn_stag_sleep = 0;
-
 namespace {
 
 struct AttnParams {
@@ -24,7 +21,6 @@ struct AttnParams {
   int nq, nk;
   int nqb, npairs, heads;
   float scale_log2e;
-  int stag_shift, stag_sleep;
 };
 
 // KT = keys per LDS tile: 64, or 32 for the short key sets (temporal attention over <= 32 frames, the 32 audio tokens),
@@ -59,13 +55,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  // The workgroups resident on one CU run the same program on tiles of the same length: started together they stay in
-  // lockstep (every SIMD's waves are in their MFMA phase together, then in their softmax phase together).  A start-up
-  // delay of a third of a tile per co-resident workgroup lets one wave's MFMAs run under another's VALU work.
-  if (NW >= 4 && p.stag_sleep > 0) {
-    const int ph = (int)((blockIdx.x >> p.stag_shift) % 3u);
-    for (int i = 0; i < ph * p.stag_sleep; ++i) __builtin_amdgcn_s_sleep(1);
-  }
+  // (Measured and rejected: a start-up stagger of the co-resident workgroups by fractions of a tile -- s_sleep of
+  // 128..1536 cycles keyed on several workgroup-id bit fields -- changed nothing, 2445 +- 10 us at hd 40: the resident
+  // workgroups are not in lockstep.)
   // XCD-aware mapping (1-D grid): workgroup ids are dealt round-robin over the 8 XCDs, so id = slot * 8 + xcd.  All query
   // blocks of one (batch, head) pair are placed on ONE XCD (pair = xcd + 8 * (slot / nqb)): their K/V tiles are then
   // re-read from that XCD's L2 instead of crossing the fabric once per query block.
@@ -491,8 +483,6 @@ extern "C" int mmgt_attention(const void* q, long q_bs0, long q_bs1, long q_ts, 
   p.bdiv = bdiv; p.k2_bdiv = k2 ? k2_bdiv : 1; p.nk2 = k2 ? nk2 : 0; p.seg2_first_batch = seg2_first_batch;
   p.nq = nq; p.nk = nk;
   p.scale_log2e = scale * 1.4426950408889634f;
-  p.stag_shift = g_attn_stag_shift;
-  p.stag_sleep = g_attn_stag_sleep;
   hipStream_t s = (hipStream_t)stream;
   return dtype == MMGT_BF16 ? launch_t<bf16_t>(p, batch, heads, hd, v_transposed, s)
                             : launch_t<float>(p, batch, heads, hd, v_transposed, s);

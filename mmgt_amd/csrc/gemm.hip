@@ -812,12 +812,8 @@ int check_common(int dtype, int M, int N, int K, int act) {
 
 }  // namespace
 
-extern int g_attn_stag_shift, g_attn_stag_sleep;   // attention.hip
-
 extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return 0; }
-  if (key && !strcmp(key, "attn_stag_shift")) { g_attn_stag_shift = value; return 0; }
-  if (key && !strcmp(key, "attn_stag_sleep")) { g_attn_stag_sleep = value; return 0; }
   mmgt_set_error("tune: unknown key");
   return 1;
 }

@@ -199,6 +199,8 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long l
   const float rstd = rsqrtf(sq / (float)C + eps);
   if (!ok) return;
   const float* perow = pe ? pe + (long)((row / pe_div) % pe_mod) * C : nullptr;
+  // pe == nullptr with pe_mod > 1: beta is a [pe_mod][C] table (beta + pe folded once by the host), one vector load less
+  if (!pe && pe_mod > 1) beta += (long)((row / pe_div) % pe_mod) * C;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
     if (i < vpl) {
@@ -262,7 +264,7 @@ extern "C" int mmgt_layernorm(const void* x, long ldx, const float* gamma, const
   const int vec = dtype == MMGT_BF16 ? 8 : 4;
   MMGT_CHECK(C > 0 && C % vec == 0 && ldx % vec == 0 && ldo % vec == 0, "layernorm: unsupported C=%d", C);
   MMGT_CHECK(rows > 0, "layernorm: no rows");
-  MMGT_CHECK(!pe || (pe_div > 0 && pe_mod > 0), "layernorm: bad pe_div/pe_mod");
+  MMGT_CHECK(pe_div > 0 && pe_mod > 0, "layernorm: bad pe_div/pe_mod");
   MMGT_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
                  ((uintptr_t)beta % 16) == 0, "layernorm: pointers must be 16-byte aligned");
   const int nvec = C / vec;

@@ -193,10 +193,15 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x1=None, out=None):
 
 
 def layernorm(x, gamma, beta, eps=1e-5, pe=None, pe_div=1, pe_mod=1, out=None):
-    """x (rows, C) -> LayerNorm over C (+ pe[(row // pe_div) % pe_mod] added after the affine)."""
+    """x (rows, C) -> LayerNorm over C (+ pe[(row // pe_div) % pe_mod] added after the affine).  With pe=None and
+    pe_mod > 1, `beta` is a (>= pe_mod, C) table of beta + pe rows indexed the same way."""
     _dev(x, gamma, beta, pe)
     assert x.dim() == 2 and x.stride(1) == 1
     rows, C = x.shape
+    if pe is None and pe_mod > 1:
+        assert beta.dim() == 2 and beta.shape[0] >= pe_mod and beta.shape[1] == C and beta.is_contiguous()
+    else:
+        assert beta.numel() == C
     if out is None:
         out = torch.empty((rows, C), device=x.device, dtype=x.dtype)
     _check(lib().mmgt_layernorm(_ptr(x), x.stride(0), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), eps,

@@ -110,6 +110,17 @@ class Pose2VideoPipeline:
         new[:, :, idx] = v1
         return new
 
+    def _pose_window(self, pose_fea, c):
+        """Pose features of one window for both CFG rows (pipeline_pose2vid_long.py:576-580), converted ONCE to the
+        operator's channels-last layout and dtype: they are step-invariant, so the per-step forward takes them as is."""
+        if pose_fea is None:
+            return None
+        unet = self.denoising_unet
+        p5 = pose_fea[:, :, c].repeat(2, 1, 1, 1, 1).to(torch.float32).contiguous()
+        if not p5.is_cuda or not hasattr(unet, "boc"):
+            return p5
+        return hip.ncfhw_to_nhwc(p5, p5.shape[1], unet.dtype)
+
     # --------------------------------------------------------------------------------------------- the hot loop
     def denoise(self, latents, timesteps, encoder_hidden_states, pose_fea, audio_tensor_pre, full_masks, face_masks,
                 lip_masks, guidance_scale, motion_scale, context_frames, context_stride, context_overlap,
@@ -134,7 +145,7 @@ class Pose2VideoPipeline:
         cond = []
         for c in win_long:
             cond.append(dict(
-                pose=pose_fea[:, :, c].repeat(2, 1, 1, 1, 1).contiguous() if pose_fea is not None else None,
+                pose=self._pose_window(pose_fea, c),
                 audio=audio_tensor_pre[:, c].contiguous(),
                 full=[t.view(2, video_length, -1)[:, c].reshape(-1, t.shape[-1]).contiguous() for t in full_masks],
                 face=[t.view(2, video_length, -1)[:, c].reshape(-1, t.shape[-1]).contiguous() for t in face_masks],

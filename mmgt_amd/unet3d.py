@@ -108,6 +108,7 @@ class UNet3DConditionModel:
         self._banks: Dict[str, tuple] = {}
         self.bank_fp16_roundtrip = dtype == torch.float32   # reference stores banks as fp16 (mutual_self_attention.py:340)
         self._loaded = False
+        self._ehs_cache = None
 
     # ------------------------------------------------------------------------------------------ reference-style API
     @classmethod
@@ -205,6 +206,7 @@ class UNet3DConditionModel:
             raise RuntimeError("partial load_state_dict on an already packed model is not supported: pass every key")
         self._pack(sd)
         self._loaded = True
+        self._ehs_cache = None
         self._banks = {}
         return missing, unexpected
 
@@ -334,6 +336,10 @@ class UNet3DConditionModel:
                 if has(a + ".pos_encoder.pe"):
                     w[a + ".pe"] = self._f(sd[a + ".pos_encoder.pe"][0])
                 norm(f"{t}.norms.{i}")
+                if (a + ".pe") in w and (f"{t}.norms.{i}.b") in w:
+                    # LayerNorm bias + positional encoding as one (max_len, C) table (motion_module.py:359-366 adds pe
+                    # right after the norm): the kernel then reads gamma and one table row instead of gamma, beta and pe
+                    w[f"{t}.norms.{i}.bpe"] = (w[f"{t}.norms.{i}.b"][None, :] + w[a + ".pe"]).contiguous()
             norm(t + ".ff_norm")
             ff(t + ".ff")
 
@@ -451,17 +457,29 @@ class UNet3DConditionModel:
                                  frames=frames)
         if ehs.shape[1] == 1:
             # one key: softmax == 1, attn2 output is the per-CFG-row constant to_out(to_v(e))
-            e = ehs.reshape(ehs.shape[0], -1).to(self._dtype).contiguous()
-            cvec = hip.gemm(hip.gemm(e, self.w[t + ".attn2.v.w"]), self.w[t + ".attn2.o.w"], self.w[t + ".attn2.o.bias"])
+            cvec = self._clip_vector(t, ehs)
             rows = nb // ehs.shape[0] * n if ehs.shape[0] != nb else n
             hid = hip.gemm(o, self.w[t + ".attn1.o.w"], self.w[t + ".attn1.o.bias"], residual=hid,
-                           bias2=cvec.float(), bias2_rows=rows)
+                           bias2=cvec, bias2_rows=rows)
         else:
             hid = hip.gemm(o, self.w[t + ".attn1.o.w"], self.w[t + ".attn1.o.bias"], residual=hid)
             hid = self._cross_attention(t, hid, ehs, nb, n, inner)
         hid = self._ff(t + ".ff", self._ln(t + ".norm3", hid), hid)
         out = hip.gemm(hid, self.w[p + ".proj_out.w"], self.w[p + ".proj_out.bias"], residual=x.view(m, c))
         return out.view(nb, h, ww, c)
+
+    def _clip_vector(self, t, ehs):
+        """to_out(to_v(e)) of the one-token CLIP cross-attention, per CFG row, fp32.  It depends on the weights and on
+        `encoder_hidden_states` only, which the sampler passes unchanged at every step: cached while the caller keeps
+        handing in the same (unmodified) tensor object -- the reference held here keeps its storage from being reused."""
+        c = self._ehs_cache
+        if c is None or c[0] is not ehs or c[1] != ehs._version:
+            c = self._ehs_cache = (ehs, ehs._version, {})
+        if t not in c[2]:
+            e = ehs.reshape(ehs.shape[0], -1).to(self._dtype).contiguous()
+            c[2][t] = hip.gemm(hip.gemm(e, self.w[t + ".attn2.v.w"]), self.w[t + ".attn2.o.w"],
+                               self.w[t + ".attn2.o.bias"]).float()
+        return c[2][t]
 
     def _cross_attention(self, t, hid, ehs, nb, n, inner):
         """General attn2 (more than one context token): attention.py:448-462."""
@@ -529,7 +547,7 @@ class UNet3DConditionModel:
         hid = self._lin(q + ".proj_in", xn.view(m, c))
         for i in range(2):
             a = f"{t}.attention_blocks.{i}"
-            nrm = self._ln(f"{t}.norms.{i}", hid, pe=self.w[a + ".pe"], pe_div=n, pe_mod=frames)
+            nrm = hip.layernorm(hid, self.w[f"{t}.norms.{i}.g"], self.w[f"{t}.norms.{i}.bpe"], 1e-5, pe_div=n, pe_mod=frames)
             qkv = hip.gemm(nrm, self.w[a + ".qkv.w"])
             o = torch.empty((m, c), device=self._device, dtype=self._dtype)
             st = (frames * n * 3 * c, 3 * c, n * 3 * c)

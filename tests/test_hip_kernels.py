@@ -200,6 +200,9 @@ def test_layernorm(dt, C):
     idx = (torch.arange(rows, device=dev()) // 5) % 6
     torch.testing.assert_close(hip.layernorm(x, g, b, pe=pe, pe_div=5, pe_mod=6).double(), ref + pe.double()[idx],
                                **tol(dt))
+    # the folded form the motion modules use: beta is the (pe_mod, C) table beta + pe
+    table = (b[None, :] + pe).contiguous()
+    torch.testing.assert_close(hip.layernorm(x, g, table, pe_div=5, pe_mod=6).double(), ref + pe.double()[idx], **tol(dt))
 
 
 def _ref_attn(q, k, v, scale):
