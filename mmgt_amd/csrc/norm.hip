@@ -240,8 +240,12 @@ extern "C" int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C
   dim3 grid(chunks, NB);
   hipStream_t s = (hipStream_t)stream;
   const int nvec = C / vec;
-  int lpr = 64;
-  if (nvec <= 32) { lpr = 8; while (lpr < nvec) lpr <<= 1; }
+  // lanes per pixel row: the fewest of 8 / 16 / 32 / 64 whose lanes x MAXS vectors tile the row exactly, so that every lane
+  // streams a vector in every load instruction: C = 320 -> 8 lanes x 5 vectors (8 rows per wave instruction), 640 -> 16,
+  // 1280 -> 32, 2560 -> 64 (with 64 lanes per row the 40 vectors of a 320-channel row left 24 lanes idle).
+  const int maxs = GN_MAXC / (vec * 64);
+  int lpr = 8;
+  while (lpr < 64 && (lpr * maxs < nvec || nvec % lpr != 0)) lpr <<= 1;   // ragged rows (C = 960, 1920) measured faster at 64
   if (dtype == MMGT_BF16) {
     hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x0, C0, (const bf16_t*)x1, C1,
                        workspace, HW, G, chunks, lpr);
