@@ -94,8 +94,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
       if (d < HD) frag_load(qf[ks], qrow + d);
       else qf[ks].zero();
       // fold softmax scale * log2(e) into Q once: the MFMA then yields scores directly in the exp2 domain
+      {
+        float q8[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qf[ks].set(j, frag_get(qf[ks], j) * p.scale_log2e);
+        for (int j = 0; j < 8; ++j) q8[j] = frag_get(qf[ks], j) * p.scale_log2e;
+        frag_set8(qf[ks], q8);
+      }
     }
   }
 
@@ -308,7 +312,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
     float mt = fmaxf(s[0][0], s[NSUB - 1][0]);
 #pragma unroll
     for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(s[0][r], s[NSUB - 1][r]));
-    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    {
+      // the other lane half's maximum by v_permlane32_swap (a VALU move): __shfl_xor(mt, 32) is a ds_bpermute, an LDS
+      // round trip in the middle of the tile's critical path.  swap(a, b) exchanges a's upper half with b's lower half,
+      // so with a == b one result holds the own value and the other the partner's, in either lane half.
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
+      mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
     if (it == 0 || __any(mt > 0.f)) {
       // the first tile fixes M at the tile maximum (either sign); later tiles only ever raise it
       float delta = it == 0 ? mt : fmaxf(mt, 0.f);
@@ -347,8 +357,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         Frag<T> pf;
+        {
+          float p8[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf.set(j, s[sub][8 * s2 + j]);
+          for (int j = 0; j < 8; ++j) p8[j] = s[sub][8 * s2 + j];
+          frag_set8(pf, p8);
+        }
         // element j of this lane <-> key  sub*32 + 16*s2 + 8*(j>>2) + 4*lh + (j&3)
         const int kbase = sub * 32 + 16 * s2 + 4 * lh;
 #pragma unroll

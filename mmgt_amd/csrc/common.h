@@ -73,6 +73,24 @@ __device__ __forceinline__ void frag_load(Frag<float>& f, const float* p) {
   for (int j = 0; j < 4; ++j) { f.v[j] = lo[j]; f.v[4 + j] = hi[j]; }
 }
 
+// Fill a fragment from eight fp32 values.  bf16: four v_cvt_pk_bf16_f32 (RNE) -- element-wise set() costs a convert plus
+// two or three pack instructions per value, which made the P^T fragments the largest VALU item of the attention loop.
+typedef __attribute__((ext_vector_type(2))) float f32x2_;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  bf16x2_ r = __builtin_convertvector((f32x2_){a, b}, bf16x2_);
+  return *reinterpret_cast<unsigned*>(&r);
+}
+__device__ __forceinline__ void frag_set8(Frag<bf16_t>& f, const float (&v)[8]) {
+  union { u32x4 u; s16x8 s; } cv;
+  cv.u = (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+  f.v = cv.s;
+}
+__device__ __forceinline__ void frag_set8(Frag<float>& f, const float (&v)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = v[j];
+}
+
 __device__ __forceinline__ float frag_get(const Frag<bf16_t>& f, int j) { return bf16_to_f32((bf16_t)f.v[j]); }
 __device__ __forceinline__ float frag_get(const Frag<float>& f, int j) { return f.v[j]; }
 
