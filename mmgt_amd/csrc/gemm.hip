@@ -8,16 +8,18 @@
 // view is (ky, kx, cin) with cin fastest, matching weights pre-packed as [Cout][3][3][Cin].
 //
 // Structure (one template over storage type, A view and tile shape):
-//  * BM x BN tile per 256-thread workgroup (4 waves), K chunks of 128 bytes per row (64 bf16 / 32 fp32).
-//  * Both operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging registers): LDS rows are exactly
-//    128 B and lane-linear per wave instruction, so bank conflicts are removed by an XOR swizzle of the 16-byte chunk
-//    index applied on the per-lane SOURCE address and again on the fragment read (chunk ^ ((row >> 1) & 7): the sixteen
-//    lanes of every ds_read_b128 group hit sixteen distinct 16-byte slots).  Conv zero padding = the lane's source is a
-//    zero page.
+//  * BM x BN tile per workgroup of 4 or 8 waves, K chunks of 128 bytes per row (64 bf16 / 32 fp32).
+//  * Both operands go global -> LDS by LDS-DMA through buffer resources (buffer_load_dwordx4 ... offen lds: an SGPR
+//    descriptor, one 32-bit VGPR offset per lane and an SGPR offset along K; no staging registers, no per-chunk vector
+//    address arithmetic -- against global_load_lds with 64-bit per-lane addresses this measured -8..-18% on every shape).
+//    LDS rows are exactly 128 B and lane-linear per wave instruction, so bank conflicts are removed by an XOR swizzle of
+//    the 16-byte chunk index applied on the per-lane SOURCE offset and again on the fragment read
+//    (chunk ^ ((row >> 1) & 7): the sixteen lanes of every ds_read_b128 group hit sixteen distinct 16-byte slots).
+//    Conv zero padding = an out-of-range buffer offset, which the hardware reads as zero.
 //  * NSTAGE-deep LDS ring, one raw s_barrier per chunk, counted s_waitcnt vmcnt so NSTAGE-2 chunks stay in flight
-//    across the barrier.
-//  * Epilogue through LDS: accumulators are transposed to row-major so that every lane loads/stores 8 consecutive
-//    columns (16 B bf16): bias, per-batch bias, SiLU / GEGLU, row scale, alpha, residual, store.
+//    across the barrier; persistent grid whose chunk stream keeps rolling across tile boundaries.
+//  * Epilogue from registers (MFMA operands swapped, permlane32 / DPP quad transposes) so that every lane loads/stores 8
+//    consecutive columns (16 B bf16): bias, per-batch bias, SiLU / GEGLU, row scale, alpha, residual, store.
 //  * XCD-aware tile order (n fastest inside an XCD's contiguous run) so the tiles sharing an A row panel hit one L2.
 #include <string.h>
 
@@ -43,8 +45,6 @@ constexpr bool V_LATE = (MMGT_GEMM_VARIANT & 4) != 0;
 constexpr bool V_LATE_ALL = (MMGT_GEMM_VARIANT & 8) != 0;
 constexpr bool V_NODMA = (MMGT_GEMM_VARIANT & 16) != 0;   // timing diagnostic only (wrong results): no LDS-DMA after the ring fill
 
-__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];
-
 struct ADesc {
   const char* src0;
   const char* src1;
@@ -68,9 +68,16 @@ struct Epi {
   int fast;                // 1: N % 8 == 0 and every row / pointer 16-byte aligned -> vectorised epilogue
 };
 
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+// LDS-DMA through a buffer resource (buffer_load_dwordx4 ... offen lds): SGPR descriptor + one 32-bit VGPR offset per lane
+// + an SGPR offset for the position along K, instead of a 64-bit VGPR address per lane -- half the address registers, no
+// per-chunk vector address arithmetic, and out-of-range offsets READ AS ZERO, which is the conv's zero padding.
+// Operands are described as raw buffers of 2 GiB (the host checks the sizes); POISON is any offset beyond that.
+constexpr unsigned DMA_RANGE = 0x80000000u, DMA_POISON = 0xC0000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)DMA_RANGE, 0x00020000);
+}
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, void* lds_dst) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, (int)voff, soff, 0, 0);
 }
 
 template <int N>
@@ -171,14 +178,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   const T* a1 = ad.src1 ? reinterpret_cast<const T*>(ad.src1) + (long)bz * ad.bs1 : nullptr;
   const T* wbase = reinterpret_cast<const T*>(W) + (long)bz * bsw;
 
-  const char* aptr[GA];      // dense: pointer to (row, swizzled chunk) at k = 0
+  const __amdgpu_buffer_rsrc_t rA0 = dma_rsrc(a0), rA1 = dma_rsrc(a1 ? a1 : a0), rW = dma_rsrc(wbase);
+  unsigned aoff[GA];         // byte offset of (row, swizzled chunk) at k = 0 (dense) / of the current tap's pixel (conv)
   int cn[GA], coy[GA], cox[GA], achunk[GA];
-  const char* wptr[GB];
+  unsigned woff[GB];
   // Chunks are prepared strictly in order, so the conv view keeps a running position (tap, channel): inside one tap and
   // one source tensor consecutive chunks are 128 B apart, and the (ky, kx) / padding / pixel address arithmetic is redone
   // only when the tap or the source changes (every Cin / 64 chunks instead of every chunk).
   int p_tap = 0, p_c = 0;
-  unsigned okbits = 0;
+  int a_soff = 0;            // scalar byte offset of the chunk being issued, along K (dense) / inside the tap (conv)
+  bool a_second = false;     // conv: the chunk comes from the second source tensor
   auto setup = [&](int tm, int tn) {   // operand addresses of tile (tm, tn), the tile the DMA stream is in
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
       int m = tm * BM + row;
       if (m >= M) m = M - 1;
       if (MODE == 0) {
-        aptr[i] = reinterpret_cast<const char*>(a0 + (long)m * ad.ld0) + chunk * 16;
+        aoff[i] = (unsigned)((long)m * ad.ld0 * ESZ) + chunk * 16;
       } else {
         const int hw = ad.OH * ad.OW;
         cn[i] = m / hw;
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
       const int chunk = spos ^ swz(row);
       int n = tn * BN + row;
       if (n >= N) n = N - 1;
-      wptr[i] = reinterpret_cast<const char*>(wbase + (long)n * K) + chunk * 16;
+      woff[i] = (unsigned)((long)n * K * ESZ) + chunk * 16;
     }
     p_tap = 0;
     p_c = 0;
@@ -212,34 +221,29 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   // LDS-DMA ops of one chunk are issued in slices spread between the MFMA groups of the previous chunk (a burst of 8
   // global_load_lds costs as many issue cycles as the chunk's 16 MFMAs).  `prep` resolves the per-lane source pointers
   // of the A operand once per chunk (conv: tap / channel decomposition + padding test), `issue` only launches DMAs.
-  const char* asrc[GA];
   bool dma_on = true;
   auto prep = [&](int ch) {
     if (MODE == 0) {
-      const long kb = (long)ch * ROWB;   // byte offset along K
-#pragma unroll
-      for (int i = 0; i < GA; ++i) asrc[i] = aptr[i] + kb;
+      a_soff = ch * ROWB;   // byte offset along K
     } else {
       const int cin = ad.C0 + ad.C1;
       if (p_c == 0 || p_c == ad.C0) {
         const int ky = p_tap / 3, kx = p_tap - ky * 3;
         const int vh = ad.up ? ad.IH * 2 : ad.IH, vw = ad.up ? ad.IW * 2 : ad.IW;
         const bool second = p_c >= ad.C0 && ad.C1 > 0;
-        const T* base = second ? a1 : a0;
         const long cpp = second ? ad.C1 : ad.C0;
-        okbits = 0;
+        a_second = second;
+        a_soff = 0;
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
           const int iy = coy[i] * ad.stride + ky - 1, ix = cox[i] * ad.stride + kx - 1;
           const bool ok = iy >= 0 && iy < vh && ix >= 0 && ix < vw;
           const int sy = ad.up ? iy >> 1 : iy, sx = ad.up ? ix >> 1 : ix;
-          const char* p = reinterpret_cast<const char*>(base + (((long)cn[i] * ad.IH + sy) * ad.IW + sx) * cpp) + achunk[i];
-          asrc[i] = ok ? p : reinterpret_cast<const char*>(g_zero_page) + spos * 16;
-          okbits |= ok ? (1u << i) : 0u;
+          const unsigned off = (unsigned)((((long)cn[i] * ad.IH + sy) * ad.IW + sx) * cpp * ESZ) + achunk[i];
+          aoff[i] = ok ? off : DMA_POISON;   // padding: an out-of-range offset reads as zero
         }
       } else {
-#pragma unroll
-        for (int i = 0; i < GA; ++i) asrc[i] += (okbits >> i & 1u) ? ROWB : 0;
+        a_soff += ROWB;
       }
       p_c += BK;
       if (p_c == cin) { p_c = 0; ++p_tap; }
@@ -248,13 +252,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   auto issue = [&](int stage, int ch, int part, int nparts) {  // chunk `ch` of the DMA-side tile -> LDS stage `stage`
     if (V_NODMA && !dma_on) return;
     char* st = smem + stage * STAGE_BYTES;
-    const long kb = (long)ch * ROWB;
+    const __amdgpu_buffer_rsrc_t rA = (MODE == 1 && a_second) ? rA1 : rA0;
 #pragma unroll
     for (int i = 0; i < GA; ++i)
-      if (i % nparts == part) glds16(asrc[i], st + (wid * GA + i) * 1024);
+      if (i % nparts == part) blds16(rA, aoff[i], a_soff, st + (wid * GA + i) * 1024);
 #pragma unroll
     for (int i = 0; i < GB; ++i)
-      if (i % nparts == part) glds16(wptr[i] + kb, st + A_BYTES + (wid * GB + i) * 1024);
+      if (i % nparts == part) blds16(rW, woff[i], ch * ROWB, st + A_BYTES + (wid * GB + i) * 1024);
   };
 
   // fragment read addressing: row r of the tile, 16-byte chunk c  ->  r * 128 + ((c ^ ((r >> 1) & 7)) * 16)
@@ -749,25 +753,22 @@ int g_gemm_cfg = 0;   // 0 = heuristic; 1, 3, 6, 9, 12 force a tile configuratio
 
 template <typename T, int MODE>
 int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
-  // Tile choice: 128 x 128 with a 3-deep ring for compute-bound shapes; for short reductions (the HBM-bound L0/L1
-  // projections) smaller tiles with several resident workgroups per CU keep more loads in flight.
   const bool geglu = ep.act == 1;
   int cfg = g_gemm_cfg;
   if (cfg == 0) {
-    // Measured on MI355X with tools/ab_gemm.py / tools/bench_kernels.py (one process, one device):
-    //   cfg 6 (256x128, 8 waves, 3-deep ring)  long reductions, GEGLU, and the widest L0 projections;
-    //   cfg 1 (128x128, 2 workgroups / CU)      the conv gather;
-    //   cfg 3 (128x64, 3 workgroups / CU)       short reductions, narrow outputs, grids that would not fill the chip.
+    // Measured on MI355X with tools/ab_gemm.py / tools/bench_kernels.py (one process, one device; re-swept after the
+    // LDS-DMA moved to buffer addressing, which made 128x128 the better small tile for every dense shape):
+    //   cfg 6  (256x128, 8 waves, 3-deep ring)    long reductions, GEGLU, and the widest L0 projections;
+    //   cfg 1  (128x128, 2 workgroups / CU)       every other dense shape, and the conv gather on the small levels;
+    //   cfg 12 (128x320, 8 waves, barrier inside the chunk)   conv outputs whose width is a multiple of 320 on the two
+    //          large levels: the im2col gather is staged once per 320 columns instead of once per 128 (-5..-20%);
+    //   cfg 3  (128x64, 3 workgroups / CU)        conv grids that would not fill the chip (the 8x8 level).
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
     const long tiles256 = (long)((M + 255) / 256) * ((N + 127) / 128) * batch;
-    //   cfg 12 (128x320, 8 waves, barrier inside the chunk) outputs whose width is a multiple of 320 on the two large levels:
-    //          the im2col gather / A panel is staged once per 320 columns instead of once per 128 (conv -10..-24%).
     if (MODE == 1) cfg = (N % 320 == 0 && M >= 49152) ? 12 : tiles128 < 512 ? 3 : 1;
-    else if (geglu) cfg = tiles256 >= 256 ? 6 : 1;
-    else if (N == 320 && M >= 49152) cfg = 12;
-    else if (K >= 1280) cfg = tiles256 >= 256 ? 6 : 3;
+    else if (geglu || K >= 1280) cfg = tiles256 >= 256 ? 6 : 1;
     else if (M >= 131072 && N >= 640) cfg = 6;
-    else cfg = 3;
+    else cfg = 1;
   }
   if (geglu && (cfg == 3 || cfg == 12)) cfg = 1;   // GEGLU pairs need 64-column wave tiles
 #ifdef MMGT_GEMM_AB   // A/B builds (make ab) instantiate only the production tiles: seconds instead of minutes
@@ -830,6 +831,8 @@ extern "C" int mmgt_gemm(const void* A, long lda, const void* W, const float* bi
   MMGT_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && (lda * esz) % 16 == 0 && (bsA * esz) % 16 == 0 &&
                  (bsW * esz) % 16 == 0,
              "gemm: A/W must be 16-byte aligned with 16-byte aligned rows");
+  MMGT_CHECK((long)M * lda * esz < (1l << 31) && (long)N * K * esz < (1l << 31),
+             "gemm: an operand (per batch entry) exceeds the 2 GiB range of the 32-bit LDS-DMA offsets");
   ADesc ad{};
   ad.src0 = (const char*)A;
   ad.ld0 = lda;
@@ -859,6 +862,11 @@ extern "C" int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1,
   const int OH = (VH + 2 - 3) / stride + 1, OW = (VW + 2 - 3) / stride + 1;
   const long M = (long)NB * OH * OW;
   MMGT_CHECK(M < (1l << 31), "conv3x3: too many output pixels");
+  {
+    const long esz_ = dtype == MMGT_BF16 ? 2 : 4, px = (long)NB * IH * IW;
+    MMGT_CHECK(px * C0 * esz_ < (1l << 31) && px * C1 * esz_ < (1l << 31) && (long)Cout * 9 * (C0 + C1) * esz_ < (1l << 31),
+               "conv3x3: a tensor exceeds the 2 GiB range of the 32-bit LDS-DMA offsets (split the batch)");
+  }
   const int K = 9 * (C0 + C1);
   if (check_common(dtype, (int)M, Cout, K, act)) return 1;
   ADesc ad{};
