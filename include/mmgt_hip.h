@@ -46,6 +46,8 @@ int mmgt_gemm(const void* A, long lda, const void* W, const float* bias, const f
 /* 3x3 / pad 1 convolution on channels-last input as implicit GEMM.  x0 (NB,IH,IW,C0) and optional x1 (NB,IH,IW,C1) are
  * read as one (C0+C1)-channel tensor (the UNet skip concat, unet_3d_blocks.py:894,1057); `upsample` = the conv sees the
  * nearest-2x upsampled input (Upsample3D, resnet.py:70-88); stride 2 = Downsample3D (resnet.py:112-120).
+ * stride -2 = stride 2 with the padding on the high side only (diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)),
+ * the AutoencoderKL encoder's downsampler).
  * Wp: [Cout][3][3][C0+C1].  out (NB,OH,OW,Cout) = act(conv + bias + bias2[pixel / bias2_rows]) + residual.
  * Replaces: InflatedConv3d (src/models/resnet.py:9-17) in ResnetBlock3D.conv1/conv2 (resnet.py:223,240), conv_in /
  * conv_out (unet_3d.py:517,620), PoseGuider convs (pose_guider.py:47-57), AutoencoderKL decoder convs (diffusers). */

@@ -53,6 +53,7 @@ struct ADesc {
   int C0, C1;         // conv: channels of the two sources (Cin = C0 + C1)
   int IH, IW, OH, OW; // conv: stored input dims and output dims
   int stride, up;     // conv: stride; up = 1 -> the conv sees the nearest-2x upsampled input
+  int pad;            // conv: zero rows / columns in front (1; 0 for the VAE encoder's (0, 1) padded downsample)
 };
 
 struct Epi {
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
         a_soff = 0;
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
-          const int iy = coy[i] * ad.stride + ky - 1, ix = cox[i] * ad.stride + kx - 1;
+          const int iy = coy[i] * ad.stride + ky - ad.pad, ix = cox[i] * ad.stride + kx - ad.pad;
           const bool ok = iy >= 0 && iy < vh && ix >= 0 && ix < vw;
           const int sy = ad.up ? iy >> 1 : iy, sx = ad.up ? ix >> 1 : ix;
           const unsigned off = (unsigned)((((long)cn[i] * ad.IH + sy) * ad.IW + sx) * cpp * ESZ) + achunk[i];
@@ -851,6 +852,8 @@ extern "C" int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1,
                                  int upsample, const void* Wp, const float* bias, const float* bias2, int bias2_rows,
                                  const void* residual, void* out, int Cout, int act, int dtype, void* stream) {
   MMGT_CHECK(x0 && Wp && out, "conv3x3: null pointer");
+  int pad_lo = 1;
+  if (stride == -2) { stride = 2; pad_lo = 0; }   // diffusers Downsample2D(padding=0): F.pad(x, (0, 1, 0, 1)) + stride-2 conv
   MMGT_CHECK(stride == 1 || stride == 2, "conv3x3: stride %d", stride);
   MMGT_CHECK(!(upsample && stride != 1), "conv3x3: upsample requires stride 1");
   MMGT_CHECK(C0 % 64 == 0 && C1 % 64 == 0 && (x1 != nullptr) == (C1 > 0),
@@ -859,7 +862,7 @@ extern "C" int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1,
   MMGT_CHECK(((uintptr_t)x0 % 16) == 0 && ((uintptr_t)x1 % 16) == 0 && ((uintptr_t)Wp % 16) == 0,
              "conv3x3: pointers must be 16-byte aligned");
   const int VH = upsample ? IH * 2 : IH, VW = upsample ? IW * 2 : IW;
-  const int OH = (VH + 2 - 3) / stride + 1, OW = (VW + 2 - 3) / stride + 1;
+  const int OH = (VH + pad_lo + 1 - 3) / stride + 1, OW = (VW + pad_lo + 1 - 3) / stride + 1;
   const long M = (long)NB * OH * OW;
   MMGT_CHECK(M < (1l << 31), "conv3x3: too many output pixels");
   {
@@ -871,7 +874,7 @@ extern "C" int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1,
   if (check_common(dtype, (int)M, Cout, K, act)) return 1;
   ADesc ad{};
   ad.src0 = (const char*)x0; ad.src1 = (const char*)x1; ad.C0 = C0; ad.C1 = C1; ad.IH = IH; ad.IW = IW; ad.OH = OH;
-  ad.OW = OW; ad.stride = stride; ad.up = upsample;
+  ad.OW = OW; ad.stride = stride; ad.up = upsample; ad.pad = pad_lo;
   Epi ep{};
   ep.bias = bias; ep.bias2 = bias2; ep.bias2_rows = bias2_rows; ep.alpha = 1.f; ep.residual = (const char*)residual;
   ep.ldr = Cout; ep.out = (char*)out; ep.ldo = Cout; ep.act = act;

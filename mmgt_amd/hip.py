@@ -151,8 +151,9 @@ def gemm_batched(a, w, *, out):
 
 
 def conv3x3(x, wp, bias=None, *, stride=1, upsample=False, bias2=None, bias2_rows=0, residual=None, act=ACT_NONE,
-            x1=None, out=None):
-    """x (NB, H, W, C0) channels-last [+ x1 (NB, H, W, C1)], wp [Cout][3][3][C0+C1] -> (NB, OH, OW, Cout)."""
+            x1=None, out=None, pad_high_only=False):
+    """x (NB, H, W, C0) channels-last [+ x1 (NB, H, W, C1)], wp [Cout][3][3][C0+C1] -> (NB, OH, OW, Cout).
+    pad_high_only (stride 2 only): zero padding after the last row / column only (the VAE encoder's downsampler)."""
     _dev(x, wp, bias, bias2, residual, x1)
     assert x.dim() == 4 and x.is_contiguous() and wp.is_contiguous() and wp.dtype == x.dtype
     NB, IH, IW, C0 = x.shape
@@ -160,13 +161,17 @@ def conv3x3(x, wp, bias=None, *, stride=1, upsample=False, bias2=None, bias2_row
     cout = wp.shape[0]
     assert wp.numel() == cout * 9 * (C0 + C1)
     vh, vw = (IH * 2, IW * 2) if upsample else (IH, IW)
-    oh, ow = (vh - 1) // stride + 1, (vw - 1) // stride + 1
+    if pad_high_only:
+        assert stride == 2 and not upsample
+        oh, ow = (vh - 2) // 2 + 1, (vw - 2) // 2 + 1
+    else:
+        oh, ow = (vh - 1) // stride + 1, (vw - 1) // stride + 1
     if out is None:
         out = torch.empty((NB, oh, ow, cout), device=x.device, dtype=x.dtype)
     assert out.shape == (NB, oh, ow, cout) and out.is_contiguous()
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
-    _check(lib().mmgt_conv3x3_nhwc(_ptr(x), C0, _ptr(x1), C1, NB, IH, IW, stride, int(upsample), _ptr(wp),
+    _check(lib().mmgt_conv3x3_nhwc(_ptr(x), C0, _ptr(x1), C1, NB, IH, IW, -2 if pad_high_only else stride, int(upsample), _ptr(wp),
                                    _ptr(_f32(bias, "bias")), _ptr(_f32(bias2, "bias2")), bias2_rows, _ptr(residual),
                                    _ptr(out), cout, act, dtype_code(x.dtype), _stream()), "mmgt_conv3x3_nhwc")
     return out

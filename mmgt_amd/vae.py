@@ -1,4 +1,5 @@
-"""AutoencoderKL decoder (sd-vae-ft-mse) on MI355X: the `decode_latents` leg of the Stage-2 sampler.
+"""AutoencoderKL (sd-vae-ft-mse) on MI355X: the `decode_latents` leg of the Stage-2 sampler and the encoder that turns the
+reference image into `ref_image_latents` once per clip (pipeline_pose2vid_long.py:427-434).
 
 Mirrors what src/pipelines/pipeline_pose2vid_long.py:112-125 asks of diffusers' `AutoencoderKL.decode`, with the
 diffusers 0.24.0 state-dict key names so `sd-vae-ft-mse` checkpoints load by name.  All frames of a clip are decoded as
@@ -54,6 +55,48 @@ def vae_decoder_spec():
     return s
 
 
+_DOWN_CH = ((128, 128), (128, 256), (256, 512), (512, 512))   # (in, out) of encoder.down_blocks.0..3
+
+
+def vae_encoder_spec():
+    """diffusers 0.24.0 `AutoencoderKL` encoder + quant_conv key names (double_z: 8 moment channels)."""
+    s = OrderedDict()
+
+    def norm(p, c):
+        s[p + ".weight"] = (c,)
+        s[p + ".bias"] = (c,)
+
+    def conv(p, cin, cout, k=3):
+        s[p + ".weight"] = (cout, cin, k, k)
+        s[p + ".bias"] = (cout,)
+
+    def resnet(p, cin, cout):
+        norm(p + ".norm1", cin)
+        conv(p + ".conv1", cin, cout)
+        norm(p + ".norm2", cout)
+        conv(p + ".conv2", cout, cout)
+        if cin != cout:
+            conv(p + ".conv_shortcut", cin, cout, 1)
+
+    conv("encoder.conv_in", 3, 128)
+    for i, (cin, cout) in enumerate(_DOWN_CH):
+        for j in range(2):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+        if i != 3:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", cout, cout)
+    resnet("encoder.mid_block.resnets.0", 512, 512)
+    a = "encoder.mid_block.attentions.0"
+    norm(a + ".group_norm", 512)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        s[f"{a}.{n}.weight"] = (512, 512)
+        s[f"{a}.{n}.bias"] = (512,)
+    resnet("encoder.mid_block.resnets.1", 512, 512)
+    norm("encoder.conv_norm_out", 512)
+    conv("encoder.conv_out", 512, 8)
+    conv("quant_conv", 8, 8, 1)
+    return s
+
+
 class _Cfg:
     block_out_channels = (128, 256, 512, 512)
     scaling_factor = 0.18215
@@ -65,15 +108,18 @@ class DecoderOutput:
 
 
 class AutoencoderKL:
-    """Decoder half (the encoder is only used once per clip for the reference image: prologue)."""
+    """Decoder (every clip, all frames) and encoder (once per clip, the reference image: prologue).  The
+    encoder keys are optional in `load_state_dict`: without them `encode_mean` raises."""
     config = _Cfg()
 
     def __init__(self, device="cuda", dtype=torch.bfloat16):
         self._device, self._dtype = torch.device(device), dtype
         hip.dtype_code(dtype)
         self.spec = vae_decoder_spec()
+        self.encoder_spec = vae_encoder_spec()
         self.w = {}
         self._loaded = False
+        self._has_encoder = False
 
     @property
     def dtype(self):
@@ -97,10 +143,16 @@ class AutoencoderKL:
         if missing:
             raise RuntimeError(f"AutoencoderKL.load_state_dict: missing {len(missing)} decoder keys, e.g. {missing[:3]}")
         w = self.w
-        for k, shape in self.spec.items():
+        enc_present = [k for k in self.encoder_spec if k in sd]
+        if enc_present and len(enc_present) != len(self.encoder_spec):
+            raise RuntimeError(f"AutoencoderKL.load_state_dict: {len(self.encoder_spec) - len(enc_present)} encoder keys missing")
+        spec = OrderedDict(self.spec)
+        if enc_present:
+            spec.update(self.encoder_spec)
+        for k, shape in spec.items():
             if tuple(sd[k].shape) != tuple(shape):
                 raise RuntimeError(f"shape mismatch for {k}: {tuple(sd[k].shape)} vs {shape}")
-        for k in self.spec:
+        for k in spec:
             if not k.endswith(".weight"):
                 continue
             p = k[:-len(".weight")]
@@ -115,16 +167,17 @@ class AutoencoderKL:
                 m = wt.reshape(wt.shape[0], -1)
                 w[p + ".w"] = self._t(pad_rows(pad_cols(m, round_up(m.shape[1], 64)), round_up(m.shape[0], 64)))
                 w[p + ".bias"] = self._f(pad_rows(b, round_up(m.shape[0], 64)))
-        a = "decoder.mid_block.attentions.0"
         f32 = lambda t: t.to(torch.float32)
-        w[a + ".q.w"], w[a + ".q.bias"] = self._t(sd[a + ".to_q.weight"]), self._f(sd[a + ".to_q.bias"])
-        w[a + ".k.w"], w[a + ".k.bias"] = self._t(sd[a + ".to_k.weight"]), self._f(sd[a + ".to_k.bias"])
-        w[a + ".v.w"] = self._t(sd[a + ".to_v.weight"])
-        w[a + ".o.w"] = self._t(sd[a + ".to_out.0.weight"])
-        # softmax rows sum to 1, so P (V + 1 b_v^T) = P V + b_v^T: the value bias moves into the output bias
-        w[a + ".o.bias"] = self._f(f32(sd[a + ".to_out.0.weight"]) @ f32(sd[a + ".to_v.bias"]) + f32(sd[a + ".to_out.0.bias"]))
+        for a in ["decoder.mid_block.attentions.0"] + (["encoder.mid_block.attentions.0"] if enc_present else []):
+            w[a + ".q.w"], w[a + ".q.bias"] = self._t(sd[a + ".to_q.weight"]), self._f(sd[a + ".to_q.bias"])
+            w[a + ".k.w"], w[a + ".k.bias"] = self._t(sd[a + ".to_k.weight"]), self._f(sd[a + ".to_k.bias"])
+            w[a + ".v.w"] = self._t(sd[a + ".to_v.weight"])
+            w[a + ".o.w"] = self._t(sd[a + ".to_out.0.weight"])
+            # softmax rows sum to 1, so P (V + 1 b_v^T) = P V + b_v^T: the value bias moves into the output bias
+            w[a + ".o.bias"] = self._f(f32(sd[a + ".to_out.0.weight"]) @ f32(sd[a + ".to_v.bias"]) + f32(sd[a + ".to_out.0.bias"]))
         self._loaded = True
-        return [], [k for k in sd if k not in self.spec]
+        self._has_encoder = bool(enc_present)
+        return [], [k for k in sd if k not in spec]
 
     # ------------------------------------------------------------------------------------------------ blocks
     def _gn(self, p, x, silu):
@@ -141,8 +194,7 @@ class AutoencoderKL:
             res = res.view(nb, h, ww, -1)
         return hip.conv3x3(hdn, self.w[p + ".conv2.w"], self.w[p + ".conv2.bias"], residual=res)
 
-    def _mid_attention(self, x):
-        a = "decoder.mid_block.attentions.0"
+    def _mid_attention(self, x, a="decoder.mid_block.attentions.0"):
         nb, h, ww, c = x.shape
         n = h * ww
         t = self._gn(a + ".group_norm", x, False).view(nb * n, c)
@@ -178,6 +230,36 @@ class AutoencoderKL:
                 x = hip.conv3x3(x, self.w[p + ".w"], self.w[p + ".bias"], upsample=True)
         x = self._gn("decoder.conv_norm_out", x, True)
         return hip.conv3x3(x, self.w["decoder.conv_out.w"], self.w["decoder.conv_out.bias"])
+
+    def encode_nhwc(self, x):
+        """x: (nb, H, W, 64) channels-last image in [-1, 1] (3 valid channels) -> (nb, H/8, W/8, 64) moments (channels
+        0..3 = mean, 4..7 = logvar) after quant_conv.  diffusers 0.24.0 `Encoder.forward` + `quant_conv`."""
+        if not self._has_encoder:
+            raise RuntimeError("AutoencoderKL.encode: the encoder weights were not loaded")
+        x = hip.conv3x3(x, self.w["encoder.conv_in.w"], self.w["encoder.conv_in.bias"])
+        for i in range(4):
+            for j in range(2):
+                x = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}", x)
+            if i != 3:
+                p = f"encoder.down_blocks.{i}.downsamplers.0.conv"      # F.pad(x, (0, 1, 0, 1)) + stride-2 conv, padding 0
+                x = hip.conv3x3(x, self.w[p + ".w"], self.w[p + ".bias"], stride=2, pad_high_only=True)
+        x = self._resnet("encoder.mid_block.resnets.0", x)
+        x = self._mid_attention(x, "encoder.mid_block.attentions.0")
+        x = self._resnet("encoder.mid_block.resnets.1", x)
+        x = self._gn("encoder.conv_norm_out", x, True)
+        x = hip.conv3x3(x, self.w["encoder.conv_out.w"], self.w["encoder.conv_out.bias"])
+        nb, h, ww, _ = x.shape
+        return hip.gemm(x.view(nb * h * ww, 64), self.w["quant_conv.w"], self.w["quant_conv.bias"]).view(nb, h, ww, 64)
+
+    def encode_mean(self, x):
+        """`vae.encode(x).latent_dist.mean` (pipeline_pose2vid_long.py:427-434): x (n, 3, H, W) in [-1, 1] -> (n, 4, H/8, W/8)
+        fp32 on the GPU (the caller multiplies by 0.18215)."""
+        xx = x.to(self._device, torch.float32).contiguous()[:, :, None]                         # (n, 3, 1, H, W)
+        n = xx.shape[0]
+        img = hip.ncfhw_to_nhwc(xx.permute(2, 1, 0, 3, 4).contiguous(), 64, self._dtype)        # images as the f axis
+        mom = self.encode_nhwc(img)
+        out = hip.nhwc_to_ncfhw(mom, 1, 4)                                                       # (1, 4, n, h, w)
+        return out[0].permute(1, 0, 2, 3).contiguous()
 
     def decode(self, z):
         """diffusers-style: z (n, 4, h, w) -> DecoderOutput(sample (n, 3, 8h, 8w))."""

@@ -1,4 +1,4 @@
-"""ORACLE (test infrastructure): decoder of diffusers==0.24.0 `AutoencoderKL` (sd-vae-ft-mse layout) in plain torch fp32,
+"""ORACLE (test infrastructure): decoder and encoder of diffusers==0.24.0 `AutoencoderKL` (sd-vae-ft-mse layout) in plain torch fp32,
 with the diffusers state-dict key names.  diffusers is an un-vendored dependency of the reference
 (requirements.txt:36; call sites src/pipelines/pipeline_pose2vid_long.py:112-125,433) and the reference holds no test
 for it: PARITY UNPINNED — the structure is restated from the published architecture, anchored by analytic checks
@@ -51,6 +51,26 @@ def vae_decode(sd, z):
             x = _conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", x)
     x = F.silu(_gn(sd, "decoder.conv_norm_out", x))
     return _conv(sd, "decoder.conv_out", x)
+
+
+def vae_encode_mean(sd, x):
+    """AutoencoderKL.encode(x).latent_dist.mean for x (n, 3, H, W) in [-1, 1] -> (n, 4, H/8, W/8): diffusers 0.24.0
+    `Encoder` (DownEncoderBlock2D x4 with Downsample2D(padding=0) = F.pad (0,1,0,1) + stride-2 conv, UNetMidBlock2D with
+    one attention head, GroupNorm(32, eps 1e-6) + SiLU + conv_out to 8 moment channels), quant_conv, first half of the
+    moments.  Call site in the reference: pipeline_pose2vid_long.py:427-434."""
+    h = _conv(sd, "encoder.conv_in", x)
+    for i in range(4):
+        for j in range(2):
+            h = _resnet(sd, f"encoder.down_blocks.{i}.resnets.{j}", h)
+        if i != 3:
+            p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[p + ".weight"], sd[p + ".bias"], stride=2, padding=0)
+    h = _resnet(sd, "encoder.mid_block.resnets.0", h)
+    h = _attn(sd, "encoder.mid_block.attentions.0", h)
+    h = _resnet(sd, "encoder.mid_block.resnets.1", h)
+    h = _conv(sd, "encoder.conv_out", F.silu(_gn(sd, "encoder.conv_norm_out", h)))
+    moments = _conv(sd, "quant_conv", h, padding=0)
+    return moments[:, :4]
 
 
 def decode_latents(sd, latents):

@@ -55,7 +55,7 @@ def build_synthetic(dev, dtype):
     from mmgt_amd.synthetic import synth_state_dict
     from mmgt_amd.unet3d import UNet3DConditionModel
     from mmgt_amd.unet3d_spec import unet2d_reference_spec, unet3d_spec
-    from mmgt_amd.vae import AutoencoderKL, vae_decoder_spec
+    from mmgt_amd.vae import AutoencoderKL, vae_decoder_spec, vae_encoder_spec
     unet = UNet3DConditionModel(device=dev, dtype=dtype)
     unet.load_state_dict(synth_state_dict(unet3d_spec(), device=dev))
     unet.enable_gradient_checkpointing()                      # scripts/pose2vid.py:183-184
@@ -64,7 +64,9 @@ def build_synthetic(dev, dtype):
     pg = PoseGuider(320, block_out_channels=(16, 32, 96, 256), device=dev, dtype=dtype)   # :158
     pg.load_state_dict(synth_state_dict(pg.spec, prefix="pose_guider.", device=dev))
     vae = AutoencoderKL(device=dev, dtype=dtype)
-    vae.load_state_dict(synth_state_dict(vae_decoder_spec(), prefix="vae.", device=dev))
+    vae_spec = vae_decoder_spec()
+    vae_spec.update(vae_encoder_spec())                       # the encoder turns the reference image into ref_image_latents
+    vae.load_state_dict(synth_state_dict(vae_spec, prefix="vae.", device=dev))
     return Pose2VideoPipeline(vae=vae, image_encoder=None, reference_unet=ref, denoising_unet=unet, pose_guider=pg,
                               scheduler=DDIMScheduler())
 
@@ -95,11 +97,13 @@ def main():
     full = [1 + l for l in lips]                              # audio2vid convention (scripts/audio2vid.py:470-476)
     pose = hash_uniform("p2v.pose", (1, 3, a.L, a.H, a.W), 0.5) + 0.5
     audio = torch.zeros(1, a.L, 32, 768)                      # pose2vid runs with null audio (:279)
+    from PIL import Image
+    ref_img = Image.fromarray(((hash_uniform("p2v.ref", (a.H, a.W, 3), 0.5) + 0.5) * 255).clamp(0, 255).to(torch.uint8).numpy())
     torch.cuda.synchronize()
     t0 = time.time()
-    out = pipe(None, pose, audio, full, face, lips, a.W, a.H, a.L, a.steps, a.cfg, generator=gen,
+    out = pipe(ref_img, pose, audio, full, face, lips, a.W, a.H, a.L, a.steps, a.cfg, generator=gen,
                motion_scale=[1.0, 1.0, 2.0], context_frames=a.num_c, clip_image_embeds=hash_uniform("p2v.clip", (1, 768), 1.0),
-               ref_image_latents=hash_uniform("p2v.reflat", (1, 4, lat, a.W // 8), 1.0), decode=not a.no_decode,
+               decode=not a.no_decode,                         # ref_image_latents come from the VAE encoder (HIP)
                window_group=True if a.window_parallel else None)
     torch.cuda.synchronize()
     dt = time.time() - t0

@@ -7,9 +7,12 @@ from mmgt_amd.synthetic import hash_uniform, synth_state_dict
 from oracle import vae_ref
 
 
-def _sd(device="cpu"):
-    from mmgt_amd.vae import vae_decoder_spec
-    return synth_state_dict(vae_decoder_spec(), prefix="vae.", device=device)
+def _sd(device="cpu", encoder=False):
+    from mmgt_amd.vae import vae_decoder_spec, vae_encoder_spec
+    spec = vae_decoder_spec()
+    if encoder:
+        spec.update(vae_encoder_spec())
+    return synth_state_dict(spec, prefix="vae.", device=device)
 
 
 def test_oracle_vae_shapes_and_frame_independence():
@@ -62,3 +65,65 @@ def test_hip_vae_full_resolution_frame_is_finite():
     single = vae.decode_video(lat[:, :, 1:2].contiguous(), frames_per_batch=1)
     assert both.shape == (1, 3, 2, 512, 512) and torch.isfinite(both).all()
     torch.testing.assert_close(both[:, :, 1:2], single, rtol=0, atol=1e-6)
+
+
+def test_oracle_vae_encoder_known_answers():
+    """Shapes; the high-side-only padding of the downsamplers (an impulse in the LAST row/column reaches the output, one
+    in front of the FIRST does not exist); zero weights -> mean == quant_conv.bias[:4]."""
+    import torch.nn.functional as F
+    sd = _sd(encoder=True)
+    x = hash_uniform("vae.img", (2, 3, 32, 32), 1.0)
+    with torch.no_grad():
+        m = vae_ref.vae_encode_mean(sd, x)
+    assert m.shape == (2, 4, 4, 4) and torch.isfinite(m).all()
+    w = torch.zeros(1, 1, 3, 3)
+    w[0, 0, 0, 0] = 1.0                                               # tap (ky, kx) = (0, 0) picks in[2y][2x]
+    img = torch.arange(16.0).view(1, 1, 4, 4)
+    out = F.conv2d(F.pad(img, (0, 1, 0, 1)), w, stride=2)
+    torch.testing.assert_close(out, img[:, :, ::2, ::2])
+    sdz = {k: torch.zeros_like(v) for k, v in sd.items()}
+    sdz["quant_conv.bias"] = torch.arange(8.0)
+    with torch.no_grad():
+        mz = vae_ref.vae_encode_mean(sdz, x)
+    torch.testing.assert_close(mz, torch.arange(4.0).view(1, 4, 1, 1).expand_as(mz))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, dict(rtol=1e-3, atol=1e-4)), (torch.bfloat16, dict(rtol=0, atol=6e-2))])
+def test_hip_vae_encoder_matches_oracle(dtype, tol):
+    from mmgt_amd.vae import AutoencoderKL
+    sd = _sd(encoder=True)
+    x = hash_uniform("vae.img", (2, 3, 128, 64), 1.0)                 # non-square; 16 x 8 = 128 mid-block tokens
+    with torch.no_grad():
+        ref = vae_ref.vae_encode_mean(sd, x)
+    vae = AutoencoderKL(device="cuda:0", dtype=dtype)
+    vae.load_state_dict(sd)
+    out = vae.encode_mean(x.cuda()).cpu()
+    assert out.shape == ref.shape == (2, 4, 16, 8)
+    print(dtype, "max|d|", (out - ref).abs().max().item(), "mean|ref|", ref.abs().mean().item())
+    torch.testing.assert_close(out, ref, **tol)
+
+
+@pytest.mark.gpu
+def test_hip_conv_high_side_padding():
+    """The stride-2 conv with padding after the last row / column only, against F.pad + conv2d, odd and even sizes."""
+    import math
+    import torch.nn.functional as F
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_conv3x3
+    for hw in (8, 6, 10):
+        x = hash_uniform(f"dn.x{hw}", (3, 64, hw, hw + 2), 1.0)
+        w = hash_uniform("dn.w", (128, 64, 3, 3), 1.0 / math.sqrt(9 * 64))
+        b = hash_uniform("dn.b", (128,), 0.5)
+        ref = F.conv2d(F.pad(x.double(), (0, 1, 0, 1)), w.double(), b.double(), stride=2)
+        out = hip.conv3x3(x.permute(0, 2, 3, 1).contiguous().cuda(), pack_conv3x3(w).cuda(), b.cuda(), stride=2,
+                          pad_high_only=True)
+        torch.testing.assert_close(out.double().cpu(), ref.permute(0, 2, 3, 1), rtol=1e-3, atol=1e-4)
+
+
+def test_vae_without_encoder_weights_raises():
+    from mmgt_amd.vae import AutoencoderKL
+    vae = AutoencoderKL.__new__(AutoencoderKL)
+    vae._has_encoder = False
+    with pytest.raises(RuntimeError, match="encoder weights"):
+        vae.encode_nhwc(None)
