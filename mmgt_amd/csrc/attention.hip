@@ -25,7 +25,9 @@ struct AttnParams {
 
 // KT = keys per LDS tile: 64, or 32 for the short key sets (temporal attention over <= 32 frames, the 32 audio tokens),
 // where a 64-key tile would spend half its MFMAs, exponentials and LDS on masked keys.
-template <typename T, int HD, int NW, bool VT, int KT>
+// RG = false: every key segment is a whole number of KT-key tiles (all the UNet's spatial shapes): the ragged-tail staging
+// and masking code is not compiled in, so the hot loop has ONE staging path and no register shuffles where two would merge.
+template <typename T, int HD, int NW, bool VT, int KT, bool RG = true>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_kernel(AttnParams p) {
   constexpr int NSUB = KT / 32;                 // 32-key score sub-tiles per LDS tile
   static_assert(KT == 32 || KT == 64, "KT");
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
   auto prefetch = [&](int it) {
     const TileSrc t = tile_src(it);
     if (HD <= 80 && t.kt == 0) seg_init(t);
-    if (HD <= 80 && t.kt + KT <= t.nks) {      // wave-uniform: full tiles take the branch-free path
+    if (HD <= 80 && (!RG || t.kt + KT <= t.nks)) {      // wave-uniform: full tiles take the branch-free path
       const long kstep = (long)KT * t.kts, vstep = VT ? (long)KT : (long)KT * t.vts;
 #pragma unroll
       for (int i = 0; i < KVEC; ++i) {
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
 #pragma unroll
       for (int i = 0; i < VVEC; ++i) {
         const int idx = tid + i * NT;
-        if ((i + 1) * NT <= VR * NVV || idx < VR * NVV) rv[i] = load_v(t, idx, HD > 80 && t.kt + KT <= t.nks);
+        if ((i + 1) * NT <= VR * NVV || idx < VR * NVV) rv[i] = load_v(t, idx, HD > 80 && (!RG || t.kt + KT <= t.nks));
       }
     }
   };
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
         mma32(s[sub], kf, qf[ks]);
       }
     }
-    if (kt + KT > nks) {   // ragged last tile only: mask the keys past the end
+    if (RG && kt + KT > nks) {   // ragged last tile only: mask the keys past the end
 #pragma unroll
       for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
@@ -450,7 +452,9 @@ int launch_hd(AttnParams p, int batch, int heads, int vt, hipStream_t s) {
   } else {
     p.nqb = (p.nq + 127) / 128;
     dim3 grid((unsigned)((long)p.nqb * batch * heads));
-    if (vt) hipLaunchKernelGGL((attn_kernel<T, HD, 4, true, 64>), grid, dim3(256), 0, s, p);
+    const bool whole = p.nk % 64 == 0 && p.nk2 % 64 == 0;
+    if (vt && whole) hipLaunchKernelGGL((attn_kernel<T, HD, 4, true, 64, false>), grid, dim3(256), 0, s, p);
+    else if (vt) hipLaunchKernelGGL((attn_kernel<T, HD, 4, true, 64>), grid, dim3(256), 0, s, p);
     else if (short_keys) hipLaunchKernelGGL((attn_kernel<T, HD, 4, false, 32>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((attn_kernel<T, HD, 4, false, 64>), grid, dim3(256), 0, s, p);
   }
