@@ -293,15 +293,38 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
 
     // ---- S^T - M = K . Q'^T - M for the two 32-key sub-tiles ----
     f32x16 s[NSUB];
+    {
+      // all K fragments of the tile are requested before the first MFMA (where registers allow: hd <= 80), so the two
+      // score chains wait for LDS once instead of once per K-step
+      constexpr bool BATCH = HD <= 80;
+      Frag<T> kf[BATCH ? NSUB : 1][BATCH ? KSQ : 1];
+      if (BATCH) {
 #pragma unroll
-    for (int sub = 0; sub < NSUB; ++sub) {
-      s[sub] = MFOLD ? (f32x16)(0.f) : (f32x16)(-m_run);
-      const char* kp = lK + (sub * 32 + lr) * RSK + lh * 8 * ESZ;
+        for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
-      for (int ks = 0; ks < KSQ; ++ks) {
-        Frag<T> kf;
-        frag_load(kf, reinterpret_cast<const T*>(kp + ks * 16 * ESZ));
-        mma32(s[sub], kf, qf[ks]);
+          for (int ks = 0; ks < KSQ; ++ks)
+            frag_load(kf[BATCH ? sub : 0][BATCH ? ks : 0],
+                      reinterpret_cast<const T*>(lK + (sub * 32 + lr) * RSK + lh * 8 * ESZ + ks * 16 * ESZ));
+      }
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) s[sub] = MFOLD ? (f32x16)(0.f) : (f32x16)(-m_run);
+      // the two chains interleaved K-step by K-step: consecutive MFMAs are independent
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks)
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+          if (BATCH) {
+            mma32(s[sub], kf[BATCH ? sub : 0][BATCH ? ks : 0], qf[ks]);
+          } else {
+            Frag<T> k1;
+            frag_load(k1, reinterpret_cast<const T*>(lK + (sub * 32 + lr) * RSK + lh * 8 * ESZ + ks * 16 * ESZ));
+            mma32(s[sub], k1, qf[ks]);
+          }
+        }
+      if (BATCH && ESZ == 2) {
+        // keep the scheduler from re-serialising read -> wait -> MFMA pairs: all DS reads first, then the MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, NSUB * KSQ, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NSUB * KSQ, 0);
       }
     }
     if (RG && kt + KT > nks) {   // ragged last tile only: mask the keys past the end
@@ -311,9 +334,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
         for (int r = 0; r < 16; ++r)
           if (kt + sub * 32 + acc_row(r, lane) >= nks) s[sub][r] = -1e30f;
     }
-    float mt = fmaxf(s[0][0], s[NSUB - 1][0]);
+    // two independent v_max3 chains (running, s0[r], s1[r]): 16 instructions for the 32 scores instead of 24
+    float mt = fmaxf(s[0][0], s[NSUB - 1][0]), mt2 = fmaxf(s[0][1], s[NSUB - 1][1]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(s[0][r], s[NSUB - 1][r]));
+    for (int r = 2; r < 16; r += 2) {
+      mt = fmaxf(fmaxf(mt, s[0][r]), s[NSUB - 1][r]);
+      mt2 = fmaxf(fmaxf(mt2, s[0][r + 1]), s[NSUB - 1][r + 1]);
+    }
+    mt = fmaxf(mt, mt2);
     {
       // the other lane half's maximum by v_permlane32_swap (a VALU move): __shfl_xor(mt, 32) is a ds_bpermute, an LDS
       // round trip in the middle of the tile's critical path.  swap(a, b) exchanges a's upper half with b's lower half,
