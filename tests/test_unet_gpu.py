@@ -102,3 +102,22 @@ def test_unet_wider_geometry_fp32(full_sd):
     ref = _run_oracle(sd_cpu, case)
     out = _run_hip(sd_gpu, case, torch.float32)
     torch.testing.assert_close(out, ref, rtol=1e-3, atol=1e-4)
+
+
+def test_unet_full_resolution_512x512_six_frames(full_sd):
+    """BASELINE config-2 spatial size (512x512 px = 64x64 latent, 4096 tokens and 4096 bank keys at level 0) on 6 frames:
+    the shapes at which the production tile configurations are chosen (128x320 conv tile from 49152 output rows, 256x128
+    for the GEGLU / long-K GEMMs, 64-key attention tiles without ragged-tail code).  fp32-I/O mode against the CPU oracle
+    at the north-star tolerance, bf16 product mode against the same reference at the bf16 noise floor."""
+    sd_gpu, sd_cpu = full_sd
+    case = dict(gc.UNET_CASES["full_cfg1"], frames=6, latent=64, timestep=499)
+    ref = _run_oracle(sd_cpu, case)
+    out = _run_hip(sd_gpu, case, torch.float32)
+    d = (out - ref).abs()
+    print("512x512x6 fp32 mode: max|d|", d.max().item(), "mean|x|", ref.abs().mean().item())
+    torch.testing.assert_close(out, ref, rtol=1e-3, atol=1e-4)
+    out16 = _run_hip(sd_gpu, case, torch.bfloat16)
+    d16 = (out16 - ref).abs()
+    print("512x512x6 bf16 mode: max|d|", d16.max().item(), "mean|d|", d16.mean().item())
+    assert torch.isfinite(out16).all()
+    assert d16.max() <= 8e-2 and d16.mean() <= 8e-3
