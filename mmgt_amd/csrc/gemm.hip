@@ -304,7 +304,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
     }
   };
   // LATE (see the main loop): the ring runs one chunk fuller, the stage of chunk c is refilled inside chunk c's own work
-  constexpr bool LATE = V_LATE && (BN == 320 || V_LATE_ALL) && KS >= 2 && KS % 2 == 0;
+  constexpr bool LATE = V_LATE && (BN == 320 || (BM == 256 && BN == 256) || V_LATE_ALL) && KS >= 2 && KS % 2 == 0;
 #pragma unroll
   for (int s = 0; s < NSTAGE - (LATE ? 0 : 1); ++s)
     if (gi < total) { prep(ich); issue(sl, ich, 0, 1); advance_dma(); }
@@ -766,7 +766,12 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     //   cfg 3  (128x64, 3 workgroups / CU)        conv grids that would not fill the chip (the 8x8 level).
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
     const long tiles256 = (long)((M + 255) / 256) * ((N + 127) / 128) * batch;
-    if (MODE == 1) cfg = (N % 320 == 0 && M >= 49152) ? 12 : tiles128 < 512 ? 3 : 1;
+    //   cfg 9  (256x256, 8 waves, 2-deep ring, barrier inside the chunk)   long reductions whose grid still gives ~one tile
+    //          per CU: the 16x16-level convs (-6%) and the K = 5120 ff2 GEMM of that level (-5%).
+    const long tiles256sq = (long)((M + 255) / 256) * ((N + 255) / 256) * batch;
+    const bool big_ok = N % 256 == 0 && K >= 2560 && tiles256sq >= 192 && tiles256sq <= 512;
+    if (MODE == 1) cfg = (N % 320 == 0 && M >= 49152) ? 12 : big_ok ? 9 : tiles128 < 512 ? 3 : 1;
+    else if (!geglu && big_ok) cfg = 9;
     else if (geglu || K >= 1280) cfg = tiles256 >= 256 ? 6 : 1;
     else if (M >= 131072 && N >= 640) cfg = 6;
     else cfg = 1;
@@ -776,19 +781,20 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
   switch (cfg) {
     case 3: return launch_cfg<T, MODE, 128, 64, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
     case 6: return launch_cfg<T, MODE, 256, 128, 4, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
+    case 9: return launch_cfg<T, MODE, 256, 256, 2, 4, 2>(ad, W, bsw, ep, M, N, K, batch, s);
     case 12: return launch_cfg<T, MODE, 128, 320, 4, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
     default: return launch_cfg<T, MODE, 128, 128, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
   }
 #else
   // Tiles measured and dropped (tools/ab_gemm.py, one process, one device): 128x128 / 128x64 with a 3-deep ring, 64x64,
-  // 256x128 with a 2-deep ring, 256x64, 256x256 with a 3-deep ring of 64-byte rows, 256x320 on 8 waves (accumulators +
+  // 256x128 with a 2-deep ring, 256x64, 256x256 with a 3- or 4-deep ring of 64-byte rows, 256x320 on 8 waves (accumulators +
   // double-buffered fragments spill inside the main loop) and 256x256 / 256x320 on 4 waves (one wave per SIMD, 512
   // registers: +4% at 8192^3, -9% on the 16x16 convs, 2-3x slower wherever the spilling epilogue matters).
   switch (cfg) {
     case 1: return launch_cfg<T, MODE, 128, 128, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
     case 3: return launch_cfg<T, MODE, 128, 64, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
     case 6: return launch_cfg<T, MODE, 256, 128, 4, 2, 3>(ad, W, bsw, ep, M, N, K, batch, s);
-    case 9: return launch_cfg<T, MODE, 256, 256, 2, 4, 4, 64>(ad, W, bsw, ep, M, N, K, batch, s);
+    case 9: return launch_cfg<T, MODE, 256, 256, 2, 4, 2>(ad, W, bsw, ep, M, N, K, batch, s);
     case 12: return launch_cfg<T, MODE, 128, 320, 4, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
     default: return launch_cfg<T, MODE, 128, 128, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
   }
