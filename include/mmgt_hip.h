@@ -28,6 +28,7 @@ extern "C" {
 #define MMGT_ACT_GEGLU 1 /* weights packed per 64 rows as [32 h | 32 gate]; output has N/2 columns */
 #define MMGT_ACT_SILU 2
 #define MMGT_ACT_RELU 3
+#define MMGT_ACT_QUICK_GELU 4 /* x * sigmoid(1.702 x): the CLIP vision tower's MLP (transformers activations.py) */
 
 int mmgt_abi_version(void);
 const char* mmgt_last_error(void);

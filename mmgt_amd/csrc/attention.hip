@@ -1,6 +1,6 @@
 // Flash-style attention for the MMGT Stage-2 path (gfx950): spatial self-attention with the ReferenceNet feature bank as
 // a second key/value segment, MM-HAA audio cross-attention (32 keys) and temporal self-attention (<= 32 frames), all
-// with head_dim in {40, 80, 160}.
+// with head_dim in {40, 80, 160} (and 64 for the CLIP vision tower of the prologue).
 //
 // Structure per wave (32 queries): the score tile is computed TRANSPOSED, S^T[key][q] = K . Q^T, so a lane owns one
 // query column: the online-softmax max / sum are in-register reductions plus one exchange between the two lane halves,
@@ -494,9 +494,10 @@ template <typename T>
 int launch_t(const AttnParams& p, int batch, int heads, int hd, int vt, hipStream_t s) {
   switch (hd) {
     case 40: return launch_hd<T, 40>(p, batch, heads, vt, s);
+    case 64: return launch_hd<T, 64>(p, batch, heads, vt, s);   // CLIP vision tower
     case 80: return launch_hd<T, 80>(p, batch, heads, vt, s);
     case 160: return launch_hd<T, 160>(p, batch, heads, vt, s);
-    default: mmgt_set_error("attention: head_dim %d unsupported (40, 80, 160)", hd); return 1;
+    default: mmgt_set_error("attention: head_dim %d unsupported (40, 64, 80, 160)", hd); return 1;
   }
 }
 

@@ -97,6 +97,8 @@ __device__ __forceinline__ float frag_get(const Frag<float>& f, int j) { return 
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+// CLIP's activation (transformers `quick_gelu`): x * sigmoid(1.702 x)
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.f + __expf(-1.702f * x)); }
 // Exact-erf GELU, x * Phi(x), with erf from Abramowitz & Stegun 7.1.28:
 //   erf(z) = 1 - (1 + a1 z + a2 z^2 + ... + a6 z^6)^-16,  |error| <= 3e-7  (fp32 evaluation: |gelu error| < 1e-6)
 // i.e. six FMAs, four squarings and ONE reciprocal per value -- the libm erff costs ~4x more VALU issue slots, and

@@ -65,7 +65,7 @@ struct Epi {
   long ldr, ldo, bsr, bso; // strides in elements; bs* = grid.z strides
   int bias2_rows;
   float alpha;
-  int act;                 // 0 none, 1 GEGLU (packed weights, out has N/2 columns), 2 SiLU, 3 ReLU
+  int act;                 // 0 none, 1 GEGLU (packed weights, out has N/2 columns), 2 SiLU, 3 ReLU, 4 quick-GELU
   int fast;                // 1: N % 8 == 0 and every row / pointer 16-byte aligned -> vectorised epilogue
 };
 
@@ -600,6 +600,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
               } else if (ep.act == 3) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+              } else if (ep.act == 4) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = quick_gelu_f(v[r]);
               }
               if (scaled) v *= rs;
             }
@@ -707,6 +710,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
               if (ep.bias2) x += ep.bias2[(long)(m / ep.bias2_rows) * N + ncol];
               if (ep.act == 2) x = silu_f(x);
               if (ep.act == 3) x = fmaxf(x, 0.f);
+              if (ep.act == 4) x = quick_gelu_f(x);
               x *= (ep.row_scale ? ep.row_scale[m] : 1.f) * ep.alpha;
             }
             if (res) x += Elem<T>::ld(res + (long)m * ep.ldr + ocol);
@@ -813,7 +817,7 @@ int check_common(int dtype, int M, int N, int K, int act) {
   MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "gemm: bad dtype %d", dtype);
   MMGT_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
   MMGT_CHECK(K % 64 == 0, "gemm: K=%d must be a multiple of 64 (pad channels on the host)", K);
-  MMGT_CHECK(act >= 0 && act <= 3, "gemm: bad act %d", act);
+  MMGT_CHECK(act >= 0 && act <= 4, "gemm: bad act %d", act);
   MMGT_CHECK(act != 1 || N % 64 == 0, "gemm: GEGLU needs N %% 64 == 0 (N=%d)", N);
   return 0;
 }

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmgt_hip.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_RELU = 0, 1, 2, 3
+ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_RELU, ACT_QUICK_GELU = 0, 1, 2, 3, 4
 
 _lib = None
 

@@ -60,8 +60,8 @@ def synth_tensor(name: str, shape, device="cpu", dtype=torch.float32, zero_init_
     leaf = name.rsplit(".", 1)[-1]
     if leaf == "pe":
         return sinusoid_pe(shape[1], shape[2]).to(device=device, dtype=dtype)
-    is_norm = any(t in name for t in (".norm", "norm1", "norm2", "norm3", "ff_norm", "norms.", "conv_norm_out")) \
-        and len(shape) == 1
+    is_norm = any(t in name for t in (".norm", "norm1", "norm2", "norm3", "ff_norm", "norms.", "conv_norm_out", "layrnorm",
+                                      "layernorm")) and len(shape) == 1
     if is_norm:
         base = 1.0 if leaf == "weight" else 0.0
         amp = 0.1 if leaf == "weight" else 0.05

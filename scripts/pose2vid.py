@@ -48,6 +48,7 @@ def parse_args():
 
 
 def build_synthetic(dev, dtype):
+    from mmgt_amd.clip_vision import CLIPVisionModelWithProjection, clip_vision_spec
     from mmgt_amd.pipeline import Pose2VideoPipeline
     from mmgt_amd.reference_unet import UNet2DConditionModel
     from mmgt_amd.scheduler import DDIMScheduler
@@ -67,7 +68,9 @@ def build_synthetic(dev, dtype):
     vae_spec = vae_decoder_spec()
     vae_spec.update(vae_encoder_spec())                       # the encoder turns the reference image into ref_image_latents
     vae.load_state_dict(synth_state_dict(vae_spec, prefix="vae.", device=dev))
-    return Pose2VideoPipeline(vae=vae, image_encoder=None, reference_unet=ref, denoising_unet=unet, pose_guider=pg,
+    clip = CLIPVisionModelWithProjection(device=dev, dtype=dtype)     # ViT-L/14, the reference's image_encoder (:158-162)
+    clip.load_state_dict(synth_state_dict(clip_vision_spec(), prefix="clip.", device=dev))
+    return Pose2VideoPipeline(vae=vae, image_encoder=clip, reference_unet=ref, denoising_unet=unet, pose_guider=pg,
                               scheduler=DDIMScheduler())
 
 
@@ -102,8 +105,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.time()
     out = pipe(ref_img, pose, audio, full, face, lips, a.W, a.H, a.L, a.steps, a.cfg, generator=gen,
-               motion_scale=[1.0, 1.0, 2.0], context_frames=a.num_c, clip_image_embeds=hash_uniform("p2v.clip", (1, 768), 1.0),
-               decode=not a.no_decode,                         # ref_image_latents come from the VAE encoder (HIP)
+               motion_scale=[1.0, 1.0, 2.0], context_frames=a.num_c,
+               decode=not a.no_decode,                         # CLIP embedding and ref_image_latents: HIP encoders, from ref_img
                window_group=True if a.window_parallel else None)
     torch.cuda.synchronize()
     dt = time.time() - t0

@@ -108,3 +108,36 @@ def refnet_inputs(case, tag="rn"):
     lat = hash_uniform(tag + ".latents", (1, 4, h, h), 1.0).repeat(2, 1, 1, 1)      # same latents in both CFG rows
     ehs = torch.cat([torch.zeros(1, 1, cad), hash_uniform(tag + ".ehs", (1, 1, cad), 1.0)])
     return dict(latents=lat, ehs=ehs, timestep=torch.tensor(0))
+
+
+# ---- CLIP vision tower (the reference's image_encoder; transformers.CLIPVisionModelWithProjection) ----
+CLIP_CASES = {
+    # tiny: two layers, head_dim 64, 17 tokens (ragged against every tile size)
+    "tiny": dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, image_size=56,
+                 patch_size=14, projection_dim=64, batch=2),
+    # ViT-L/14 width and token count (sd-image-variations image_encoder), two of its 24 identical layers
+    "vitl_2layers": dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=2, num_attention_heads=16,
+                         image_size=224, patch_size=14, projection_dim=768, batch=1),
+}
+
+
+def clip_state_dict(case, device="cpu"):
+    """Hash-seeded weights for a CLIP vision case: generic rule of mmgt_amd.synthetic, LayerNorm gains around 1."""
+    import torch
+    from mmgt_amd.clip_vision import clip_vision_spec
+    from mmgt_amd.synthetic import hash_uniform, synth_state_dict
+    spec = clip_vision_spec(case["hidden_size"], case["intermediate_size"], case["num_hidden_layers"], case["image_size"],
+                            case["patch_size"], case["projection_dim"])
+    sd = synth_state_dict(spec, prefix="clip.", device=device)
+    for k in spec:
+        if "norm" in k and k.endswith(".weight"):
+            sd[k] = (1.0 + hash_uniform("clip." + k, spec[k], 0.1, device)).to(torch.float32)
+        if k.endswith("class_embedding") or k.endswith("position_embedding.weight"):
+            sd[k] = hash_uniform("clip." + k, spec[k], 0.5, device)
+    return sd
+
+
+def clip_pixels(case, device="cpu"):
+    from mmgt_amd.synthetic import hash_uniform
+    s = case["image_size"]
+    return hash_uniform("clip.pixels", (case["batch"], 3, s, s), 1.5, device)
