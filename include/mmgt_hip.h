@@ -44,6 +44,14 @@ int mmgt_gemm(const void* A, long lda, const void* W, const float* bias, const f
               const float* row_scale, float alpha, const void* residual, long ldr, void* out, long ldo, int M, int N,
               int K, int act, int batch, long bsA, long bsW, long bsR, long bsO, int dtype, void* stream);
 
+/* The same with a second bias added AFTER the row scale:  v = (acc + bias[n]) * row_scale[m] * alpha + bias_post[n] +
+ * residual[m][n].  Lets MM-HAA's  zero_conv_i(mask_i * to_out_i(a_i))  (attention.py:730-760: a 320x320 Linear, a per-token
+ * mask multiply and a 1x1 conv per branch) run as ONE GEMM per branch on the host-merged weight W_z W_o: bias = W_z b_o,
+ * row_scale = mask, alpha = motion_scale, bias_post = motion_scale * b_z. */
+int mmgt_gemm_post(const void* A, long lda, const void* W, const float* bias, const float* row_scale, float alpha,
+                   const float* bias_post, const void* residual, long ldr, void* out, long ldo, int M, int N, int K,
+                   int dtype, void* stream);
+
 /* 3x3 / pad 1 convolution on channels-last input as implicit GEMM.  x0 (NB,IH,IW,C0) and optional x1 (NB,IH,IW,C1) are
  * read as one (C0+C1)-channel tensor (the UNet skip concat, unet_3d_blocks.py:894,1057); `upsample` = the conv sees the
  * nearest-2x upsampled input (Upsample3D, resnet.py:70-88); stride 2 = Downsample3D (resnet.py:112-120).

@@ -60,6 +60,7 @@ struct Epi {
   const float* bias;       // [N]
   const float* bias2;      // [ceil(M / bias2_rows)][N]   (time-embedding add: one row per CFG batch entry)
   const float* row_scale;  // [M]                         (motion-mask multiply)
+  const float* bias_post;  // [N]  added AFTER the row scale / alpha (the zero-conv bias of a merged out-proj . zero-conv)
   const char* residual;    // T [M][ldr]
   char* out;               // T [M][ldo]
   long ldr, ldo, bsr, bso; // strides in elements; bs* = grid.z strides
@@ -136,7 +137,7 @@ __device__ __forceinline__ void quad_transpose(u32x4 (&x)[S], int lane) {
 // already in flight, and the epilogue of tile t (which borrows the ring stage consumed last) runs with them landing
 // and its stores draining under the next main loop.  Measured before this: a 256 x 128 tile paid about 7 us of launch +
 // first-load latency + store drain per tile, as much as a K = 640 main loop.
-template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE, int ROWB>
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE, int ROWB, bool POST>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN / WN / 32) <= 2) ? 3 : 2) void gemm_kernel(ADesc ad, const char* __restrict__ W, long bsw, Epi ep, int M, int N,
                                                    int K, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   // round trip, no barrier: waves drift into the next tile's chunks independently.
   static_assert(TN <= 6, "epilogue: column groups of two 32-column tiles, at most three of them");
   constexpr bool RES_PF = ESZ == 2 && TM * TN <= 4 && TN <= 2;   // wide wave tiles have no registers to spare for it
+  constexpr bool POST_OK = POST;   // the post-scale bias is a separate instantiation (it cost the others ~10% in registers)
   // ---- the chunk stream of this workgroup: tiles vt = blockIdx.x + k * gridDim.x, nchunks chunks each ----
   const int nchunks = K / BK;
   const int G = gridDim.x;
@@ -618,6 +620,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
                 o8[e] = __uint_as_float(sw[0]);
                 o8[4 + e] = __uint_as_float(sw[1]);
               }
+              if (POST_OK && ep.bias_post) {   // uniform; the lane's 8 consecutive columns of this octet
+                const float* pp = ep.bias_post + col0 + 32 * j + 16 * g2 + 8 * lh;
+                const bool cok = col0 + 32 * j + 16 * g2 + 8 * lh < N;
+                const f32x4 p0 = cok ? *reinterpret_cast<const f32x4*>(pp) : (f32x4)(0.f);
+                const f32x4 p1 = cok ? *reinterpret_cast<const f32x4*>(pp + 4) : (f32x4)(0.f);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { o8[e] += p0[e]; o8[4 + e] += p1[e]; }
+              }
               if (ESZ == 2) {
                 if (res) {
                   union { u32x4 u; bf16_t e[8]; } r8;
@@ -712,6 +722,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
               if (ep.act == 3) x = fmaxf(x, 0.f);
               if (ep.act == 4) x = quick_gelu_f(x);
               x *= (ep.row_scale ? ep.row_scale[m] : 1.f) * ep.alpha;
+              if (POST_OK && ep.bias_post) x += ep.bias_post[ncol];
             }
             if (res) x += Elem<T>::ld(res + (long)m * ep.ldr + ocol);
             Elem<T>::st(out + (long)m * ep.ldo + ocol, x);
@@ -722,11 +733,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   }
 }
 
-template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE, int ROWB = 128>
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE, int ROWB = 128, bool POST = false>
 int launch_cfg(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = (size_t)NSTAGE * (BM + BN) * ROWB;
-  auto kern = gemm_kernel<T, MODE, BM, BN, WM, WN, NSTAGE, ROWB>;
+  auto kern = gemm_kernel<T, MODE, BM, BN, WM, WN, NSTAGE, ROWB, POST>;
   static int resident = 0;   // workgroups of this instantiation the whole device holds at once
   if (!resident) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -771,16 +782,21 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
     const long tiles256 = (long)((M + 255) / 256) * ((N + 127) / 128) * batch;
     //   cfg 9  (256x256, 8 waves, 2-deep ring, barrier inside the chunk)   long reductions whose grid still gives ~one tile
-    //          per CU: the 16x16-level convs (-6%) and the K = 5120 ff2 GEMM of that level (-5%).
+    //          per CU: the 16x16-level convs (-6%).  (Dense launches stay off it: at 256 VGPRs its register allocation is
+    //          fragile -- an unrelated epilogue change moved spills into its dense main loop, 153 -> 210 us.)
     const long tiles256sq = (long)((M + 255) / 256) * ((N + 255) / 256) * batch;
     const bool big_ok = N % 256 == 0 && K >= 2560 && tiles256sq >= 192 && tiles256sq <= 512;
     if (MODE == 1) cfg = (N % 320 == 0 && M >= 49152) ? 12 : big_ok ? 9 : tiles128 < 512 ? 3 : 1;
-    else if (!geglu && big_ok) cfg = 9;
     else if (geglu || K >= 1280) cfg = tiles256 >= 256 ? 6 : 1;
     else if (M >= 131072 && N >= 640) cfg = 6;
     else cfg = 1;
   }
   if (geglu && (cfg == 3 || cfg == 12)) cfg = 1;   // GEGLU pairs need 64-column wave tiles
+  if (ep.bias_post) {   // mmgt_gemm_post: its own instantiation of the 128x128 tile
+    if (MODE == 0) return launch_cfg<T, 0, 128, 128, 2, 2, 2, 128, true>(ad, W, bsw, ep, M, N, K, batch, s);
+    mmgt_set_error("conv3x3: no post-scale bias");
+    return 1;
+  }
 #ifdef MMGT_GEMM_AB   // A/B builds (make ab) instantiate only the production tiles: seconds instead of minutes
   switch (cfg) {
     case 3: return launch_cfg<T, MODE, 128, 64, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
@@ -830,10 +846,10 @@ extern "C" int mmgt_tune(const char* key, int value) {
   return 1;
 }
 
-extern "C" int mmgt_gemm(const void* A, long lda, const void* W, const float* bias, const float* bias2, int bias2_rows,
-                         const float* row_scale, float alpha, const void* residual, long ldr, void* out, long ldo, int M,
-                         int N, int K, int act, int batch, long bsA, long bsW, long bsR, long bsO, int dtype,
-                         void* stream) {
+static int gemm_entry(const void* A, long lda, const void* W, const float* bias, const float* bias2, int bias2_rows,
+                      const float* row_scale, float alpha, const float* bias_post, const void* residual, long ldr, void* out,
+                      long ldo, int M, int N, int K, int act, int batch, long bsA, long bsW, long bsR, long bsO, int dtype,
+                      void* stream) {
   if (check_common(dtype, M, N, K, act)) return 1;
   MMGT_CHECK(A && W && out, "gemm: null pointer");
   MMGT_CHECK(lda >= K && batch >= 1, "gemm: lda %ld < K %d or batch %d < 1", lda, K, batch);
@@ -850,12 +866,29 @@ extern "C" int mmgt_gemm(const void* A, long lda, const void* W, const float* bi
   ad.bs0 = bsA;
   Epi ep{};
   ep.bias = bias; ep.bias2 = bias2; ep.bias2_rows = bias2_rows; ep.row_scale = row_scale; ep.alpha = alpha;
+  ep.bias_post = bias_post;
+  MMGT_CHECK(!bias_post || (act != 1 && ((uintptr_t)bias_post % 16) == 0), "gemm: bias_post needs a 16-byte aligned vector and no GEGLU");
   ep.residual = (const char*)residual; ep.ldr = ldr; ep.out = (char*)out; ep.ldo = ldo; ep.act = act;
   ep.bsr = bsR; ep.bso = bsO;
   ep.fast = epi_fast(ep, N, act == 1 ? N / 2 : N, esz);
   hipStream_t s = (hipStream_t)stream;
   return dtype == MMGT_BF16 ? launch<bf16_t, 0>(ad, W, bsW, ep, M, N, K, batch, s)
                             : launch<float, 0>(ad, W, bsW, ep, M, N, K, batch, s);
+}
+
+extern "C" int mmgt_gemm(const void* A, long lda, const void* W, const float* bias, const float* bias2, int bias2_rows,
+                         const float* row_scale, float alpha, const void* residual, long ldr, void* out, long ldo, int M,
+                         int N, int K, int act, int batch, long bsA, long bsW, long bsR, long bsO, int dtype,
+                         void* stream) {
+  return gemm_entry(A, lda, W, bias, bias2, bias2_rows, row_scale, alpha, nullptr, residual, ldr, out, ldo, M, N, K, act,
+                    batch, bsA, bsW, bsR, bsO, dtype, stream);
+}
+
+extern "C" int mmgt_gemm_post(const void* A, long lda, const void* W, const float* bias, const float* row_scale, float alpha,
+                              const float* bias_post, const void* residual, long ldr, void* out, long ldo, int M, int N,
+                              int K, int dtype, void* stream) {
+  return gemm_entry(A, lda, W, bias, nullptr, 0, row_scale, alpha, bias_post, residual, ldr, out, ldo, M, N, K, 0, 1, 0, 0, 0,
+                    0, dtype, stream);
 }
 
 extern "C" int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1, int NB, int IH, int IW, int stride,

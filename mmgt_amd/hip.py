@@ -24,6 +24,8 @@ _SIGS = {
     "mmgt_gemm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_long,
                           c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_int,
                           c_void_p]),
+    "mmgt_gemm_post": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_long, c_void_p,
+                               c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_conv3x3_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                   c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mmgt_groupnorm_chunks": (c_int, [c_int]),
@@ -123,6 +125,21 @@ def gemm(a, w, bias=None, *, out=None, residual=None, bias2=None, bias2_rows=0, 
                            bias2_rows, _ptr(_f32(row_scale, "row_scale")), alpha, _ptr(residual),
                            residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), M, N, K, act, 1,
                            0, 0, 0, 0, dtype_code(a.dtype), _stream()), "mmgt_gemm")
+    return out
+
+
+def gemm_post(a, w, bias, row_scale, alpha, bias_post, residual, out=None):
+    """out = (a @ w^T + bias) * row_scale[:, None] * alpha + bias_post + residual   (see mmgt_gemm_post)."""
+    _dev(a, w, bias, row_scale, bias_post, residual, out)
+    assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.is_contiguous() and a.dtype == w.dtype
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=a.dtype)
+    assert out.shape == (M, N) and residual.shape == (M, N) and residual.stride(1) == 1 and out.stride(1) == 1
+    _check(lib().mmgt_gemm_post(_ptr(a), a.stride(0), _ptr(w), _ptr(_f32(bias, "bias")), _ptr(_f32(row_scale, "row_scale")),
+                                alpha, _ptr(_f32(bias_post, "bias_post")), _ptr(residual), residual.stride(0), _ptr(out),
+                                out.stride(0), M, N, K, dtype_code(a.dtype), _stream()), "mmgt_gemm_post")
     return out
 
 

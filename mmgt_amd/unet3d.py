@@ -109,6 +109,7 @@ class UNet3DConditionModel:
         self.bank_fp16_roundtrip = dtype == torch.float32   # reference stores banks as fp16 (mutual_self_attention.py:340)
         self._loaded = False
         self._ehs_cache = None
+        self._zbias = {}
 
     # ------------------------------------------------------------------------------------------ reference-style API
     @classmethod
@@ -207,6 +208,7 @@ class UNet3DConditionModel:
         self._pack(sd)
         self._loaded = True
         self._ehs_cache = None
+        self._zbias = {}
         self._banks = {}
         return missing, unexpected
 
@@ -317,6 +319,14 @@ class UNet3DConditionModel:
             for i, z in enumerate(("zero_conv_full", "zero_conv_face", "zero_conv_lip")):
                 lin(f"{t}.attn2_{i}.to_out.0", f"{t}.o{i}")
                 lin(f"{t}.{z}", f"{t}.z{i}")
+                if has(f"{t}.attn2_{i}.to_out.0.weight") and has(f"{t}.{z}.weight"):
+                    # zero_conv_i(mask_i * to_out_i(a)) = mask_i * (a (Wz Wo)^T + Wz b_o) + b_z  (attention.py:730-760): the
+                    # per-token mask is a row scalar, so the 1x1 conv folds into the Linear -- one GEMM per branch
+                    wz = sd[f"{t}.{z}.weight"].to(torch.float32).reshape(sd[f"{t}.{z}.weight"].shape[0], -1)
+                    wo = sd[f"{t}.attn2_{i}.to_out.0.weight"].to(torch.float32)
+                    bo = sd[f"{t}.attn2_{i}.to_out.0.bias"].to(torch.float32)
+                    w[f"{t}.oz{i}.w"] = self._t(wz @ wo)
+                    w[f"{t}.oz{i}.bias"] = self._f(wz @ bo)
             ff(t + ".ff")
 
         self._motion = [k[: -len(".temporal_transformer.norm.weight")] for k in self.spec
@@ -523,10 +533,12 @@ class UNet3DConditionModel:
             mask = masks[i][depth].reshape(-1).to(device=self._device, dtype=torch.float32).contiguous()
             if mask.numel() != m:
                 raise RuntimeError(f"mask level {depth} has {mask.numel()} entries, block has {m} tokens")
-            br = hip.gemm(a3[:, i * inner:(i + 1) * inner], self.w[f"{t}.o{i}.w"], self.w[f"{t}.o{i}.bias"],
-                          row_scale=mask)
             s = 1.0 if motion_scale is None else float(motion_scale[i])
-            hid = hip.gemm(br, self.w[f"{t}.z{i}.w"], self.w[f"{t}.z{i}.bias"], alpha=s, residual=hid)
+            key = (f"{t}.z{i}", s)
+            if key not in self._zbias:
+                self._zbias[key] = (self.w[f"{t}.z{i}.bias"] * s).contiguous()
+            hid = hip.gemm_post(a3[:, i * inner:(i + 1) * inner], self.w[f"{t}.oz{i}.w"], self.w[f"{t}.oz{i}.bias"], mask, s,
+                                self._zbias[key], hid)
         hid = self._ff(t + ".ff", self._ln(t + ".norm3", hid), hid)
         out = hip.gemm(hid, self.w[p + ".proj_out.w"], self.w[p + ".proj_out.bias"], residual=x.view(m, c))
         return out.view(nb, h, ww, c)

@@ -53,6 +53,22 @@ def test_gemm_plain_and_epilogue(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (4100, 640, 640), (77, 1280, 1280)])
+def test_gemm_post_scale_bias(dt, M, N, K):
+    """mmgt_gemm_post: (a W^T + bias) * row_scale * alpha + bias_post + residual, on a strided A view (MM-HAA branch)."""
+    from mmgt_amd import hip
+    big = rnd("a3", (M, 3 * K), 1.0, dt)
+    a = big[:, K:2 * K]
+    w = rnd("w", (N, K), 1.0 / math.sqrt(K), dt)
+    b, bp = rnd("b", (N,), 0.5), rnd("bp", (N,), 0.5)
+    rs = rnd("rs", (M,), 1.0) + 1.0
+    res = rnd("r", (M, N), 1.0, dt)
+    out = hip.gemm_post(a, w, b, rs, 0.75, bp, res)
+    ref = (ref_gemm(a, w) + b.double()) * rs.double()[:, None] * 0.75 + bp.double() + res.double()
+    torch.testing.assert_close(out.double(), ref, **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DT)
 def test_gemm_strided_views(dt):
     from mmgt_amd import hip
     big = rnd("big", (100, 960), 1.0, dt)
