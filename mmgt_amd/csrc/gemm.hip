@@ -278,7 +278,10 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   // round trip, no barrier: waves drift into the next tile's chunks independently.
   static_assert(TN <= 6, "epilogue: column groups of two 32-column tiles, at most three of them");
   constexpr bool RES_PF = ESZ == 2 && TM * TN <= 4 && TN <= 2;   // wide wave tiles have no registers to spare for it
-  constexpr bool POST_OK = POST;   // the post-scale bias is a separate instantiation (it cost the others ~10% in registers)
+  // POST = the FULL epilogue: row scale / alpha / post-scale bias, SiLU / ReLU / quick-GELU, and the element-wise path for
+  // ragged or unaligned problems.  The common instantiations (POST = false) carry bias, per-batch bias, GEGLU and residual on
+  // the vectorised path only: every extra epilogue feature costs the hot kernels registers (the post-scale bias alone: 10%).
+  constexpr bool POST_OK = POST;
   // ---- the chunk stream of this workgroup: tiles vt = blockIdx.x + k * gridDim.x, nchunks chunks each ----
   const int nchunks = K / BK;
   const int G = gridDim.x;
@@ -551,8 +554,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
         int m = row0 + 32 * i + lr;              // the row this lane holds in the accumulator layout
         asm volatile("" : "+v"(m));              // keeps the address arithmetic below out of the main loop's live ranges
         const bool mok = m < M;
-        const bool scaled = ep.row_scale != nullptr || ep.alpha != 1.f;   // uniform
-        const float rs = (ep.row_scale && mok ? ep.row_scale[m] : 1.f) * ep.alpha;
+        const bool scaled = POST_OK && (ep.row_scale != nullptr || ep.alpha != 1.f);   // uniform
+        const float rs = POST_OK ? (ep.row_scale && mok ? ep.row_scale[m] : 1.f) * ep.alpha : 1.f;
         T* ob = out + (long)(row0 + 32 * i) * ep.ldo;
         // One column group = GN (1 or 2) adjacent 32-column accumulator tiles starting at tile JG: SNg = 2 GN octet slots
         // per row, transposed across the DPP quad into the store layout (see "epilogue geometry").
@@ -596,13 +599,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
                 v[r + 1] *= gl[1];
               }
             } else {
-              if (ep.act == 2) {
+              if (POST_OK && ep.act == 2) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = silu_f(v[r]);
-              } else if (ep.act == 3) {
+              } else if (POST_OK && ep.act == 3) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-              } else if (ep.act == 4) {
+              } else if (POST_OK && ep.act == 4) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = quick_gelu_f(v[r]);
               }
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
         if constexpr (TN > 2) group(integral_constant<int, 2>{}, integral_constant<int, (TN >= 4 ? 2 : 1)>{});
         if constexpr (TN > 4) group(integral_constant<int, 4>{}, integral_constant<int, (TN >= 6 ? 2 : 1)>{});
       }
-    } else {
+    } else if (POST_OK) {
       // generic scalar path (ragged N, unaligned rows, bias2 blocks shorter than a tile): element by element
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -792,11 +795,9 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     else cfg = 1;
   }
   if (geglu && (cfg == 3 || cfg == 12)) cfg = 1;   // GEGLU pairs need 64-column wave tiles
-  if (ep.bias_post) {   // mmgt_gemm_post: its own instantiation of the 128x128 tile
-    if (MODE == 0) return launch_cfg<T, 0, 128, 128, 2, 2, 2, 128, true>(ad, W, bsw, ep, M, N, K, batch, s);
-    mmgt_set_error("conv3x3: no post-scale bias");
-    return 1;
-  }
+  // anything beyond bias / per-batch bias / GEGLU / residual on the vectorised path runs the FULL instantiation (128x128 tile)
+  if (!ep.fast || ep.act >= 2 || ep.row_scale || ep.alpha != 1.f || ep.bias_post)
+    return launch_cfg<T, MODE, 128, 128, 2, 2, 2, 128, true>(ad, W, bsw, ep, M, N, K, batch, s);
 #ifdef MMGT_GEMM_AB   // A/B builds (make ab) instantiate only the production tiles: seconds instead of minutes
   switch (cfg) {
     case 3: return launch_cfg<T, MODE, 128, 64, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
