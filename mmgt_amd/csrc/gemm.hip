@@ -785,11 +785,15 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128) * batch;
     const long tiles256 = (long)((M + 255) / 256) * ((N + 127) / 128) * batch;
     //   cfg 9  (256x256, 8 waves, 2-deep ring, barrier inside the chunk)   long reductions whose grid still gives ~one tile
-    //          per CU: the 16x16-level convs (-6%).  (Dense launches stay off it: at 256 VGPRs its register allocation is
-    //          fragile -- an unrelated epilogue change moved spills into its dense main loop, 153 -> 210 us.)
+    //          per CU: the 16x16-level convs (-6%); dense shapes: below.
     const long tiles256sq = (long)((M + 255) / 256) * ((N + 255) / 256) * batch;
     const bool big_ok = N % 256 == 0 && K >= 2560 && tiles256sq >= 192 && tiles256sq <= 512;
+    // dense: the 256x256 tile wherever N fills its columns to within 7% (N = 960, 1280, 1920, 2560, 3840, 5120, 10240) and
+    // the grid still covers the chip -- with the slim common epilogue it no longer spills: GEGLU ff1 -11..-13%, q/k/v
+    // projections of the motion modules -13%, the N = 1280 family -5..-10%.
+    const bool sq_ok = ((N + 255) / 256) * 256l * 100 <= (long)N * 107 && tiles256sq >= 192;
     if (MODE == 1) cfg = (N % 320 == 0 && M >= 49152) ? 12 : big_ok ? 9 : tiles128 < 512 ? 3 : 1;
+    else if (sq_ok) cfg = 9;
     else if (geglu || K >= 1280) cfg = tiles256 >= 256 ? 6 : 1;
     else if (M >= 131072 && N >= 640) cfg = 6;
     else cfg = 1;
