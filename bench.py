@@ -73,7 +73,7 @@ def pmc_traffic():
     """HBM-side bytes per denoise step from the committed rocprofv3 PMC passes (profiles/r*/pmc_traffic*.json: FETCH_SIZE and
     WRITE_SIZE collected in separate runs of this same command, gfx950 FETCH_SIZE x2 correction applied)."""
     import glob
-    latest = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_s47.json")     # the passes that belong to the current build
+    latest = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_s55.json")     # the passes that belong to the current build
     files = [latest] if os.path.exists(latest) else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic*.json")))
     if not files:
         return None, None
