@@ -57,6 +57,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
+  // (Measured and rejected: software-pipelining the scores of tile t+1 under the softmax of tile t (K staged one tile ahead
+  // of V, correct on the first run) -- with hipcc's schedule 2985 us at two waves per SIMD, 10.6 ms at three (116 spilled
+  // VGPRs) against 2504 us for this loop at hd 40, 285 vs 262 us at hd 80; it needs a hand-placed instruction stream.)
   // (Measured and rejected: a start-up stagger of the co-resident workgroups by fractions of a tile -- s_sleep of
   // 128..1536 cycles keyed on several workgroup-id bit fields -- changed nothing, 2445 +- 10 us at hd 40: the resident
   // workgroups are not in lockstep.)
