@@ -137,7 +137,7 @@ __device__ __forceinline__ void quad_transpose(u32x4 (&x)[S], int lane) {
 // already in flight, and the epilogue of tile t (which borrows the ring stage consumed last) runs with them landing
 // and its stores draining under the next main loop.  Measured before this: a 256 x 128 tile paid about 7 us of launch +
 // first-load latency + store drain per tile, as much as a K = 640 main loop.
-template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE, int ROWB, bool POST>
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE, int ROWB, int EPI>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN / WN / 32) <= 2) ? 3 : 2) void gemm_kernel(ADesc ad, const char* __restrict__ W, long bsw, Epi ep, int M, int N,
                                                    int K, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -281,7 +281,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   // POST = the FULL epilogue: row scale / alpha / post-scale bias, SiLU / ReLU / quick-GELU, and the element-wise path for
   // ragged or unaligned problems.  The common instantiations (POST = false) carry bias, per-batch bias, GEGLU and residual on
   // the vectorised path only: every extra epilogue feature costs the hot kernels registers (the post-scale bias alone: 10%).
-  constexpr bool POST_OK = POST;
+  // EPI: 0 common, 1 + row scale / alpha / post-scale bias (vectorised path only: MM-HAA's merged branch GEMMs), 2 FULL.
+  constexpr bool POST_OK = EPI >= 1, FULL_OK = EPI >= 2;
   // ---- the chunk stream of this workgroup: tiles vt = blockIdx.x + k * gridDim.x, nchunks chunks each ----
   const int nchunks = K / BK;
   const int G = gridDim.x;
@@ -599,13 +600,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
                 v[r + 1] *= gl[1];
               }
             } else {
-              if (POST_OK && ep.act == 2) {
+              if (FULL_OK && ep.act == 2) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = silu_f(v[r]);
-              } else if (POST_OK && ep.act == 3) {
+              } else if (FULL_OK && ep.act == 3) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
-              } else if (POST_OK && ep.act == 4) {
+              } else if (FULL_OK && ep.act == 4) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = quick_gelu_f(v[r]);
               }
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
         if constexpr (TN > 2) group(integral_constant<int, 2>{}, integral_constant<int, (TN >= 4 ? 2 : 1)>{});
         if constexpr (TN > 4) group(integral_constant<int, 4>{}, integral_constant<int, (TN >= 6 ? 2 : 1)>{});
       }
-    } else if (POST_OK) {
+    } else if (FULL_OK) {
       // generic scalar path (ragged N, unaligned rows, bias2 blocks shorter than a tile): element by element
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -736,11 +737,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
   }
 }
 
-template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE, int ROWB = 128, bool POST = false>
+template <typename T, int MODE, int BM, int BN, int WM, int WN, int NSTAGE, int ROWB = 128, int EPI = 0>
 int launch_cfg(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = (size_t)NSTAGE * (BM + BN) * ROWB;
-  auto kern = gemm_kernel<T, MODE, BM, BN, WM, WN, NSTAGE, ROWB, POST>;
+  auto kern = gemm_kernel<T, MODE, BM, BN, WM, WN, NSTAGE, ROWB, EPI>;
   static int resident = 0;   // workgroups of this instantiation the whole device holds at once
   if (!resident) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -800,8 +801,11 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
   }
   if (geglu && (cfg == 3 || cfg == 12)) cfg = 1;   // GEGLU pairs need 64-column wave tiles
   // anything beyond bias / per-batch bias / GEGLU / residual on the vectorised path runs the FULL instantiation (128x128 tile)
-  if (!ep.fast || ep.act >= 2 || ep.row_scale || ep.alpha != 1.f || ep.bias_post)
-    return launch_cfg<T, MODE, 128, 128, 2, 2, 2, 128, true>(ad, W, bsw, ep, M, N, K, batch, s);
+  if (!ep.fast || ep.act >= 2) return launch_cfg<T, MODE, 128, 128, 2, 2, 2, 128, 2>(ad, W, bsw, ep, M, N, K, batch, s);
+  if (ep.row_scale || ep.alpha != 1.f || ep.bias_post) {
+    if (MODE == 0 && !geglu) return launch_cfg<T, 0, 128, 128, 2, 2, 2, 128, 1>(ad, W, bsw, ep, M, N, K, batch, s);
+    return launch_cfg<T, MODE, 128, 128, 2, 2, 2, 128, 2>(ad, W, bsw, ep, M, N, K, batch, s);
+  }
 #ifdef MMGT_GEMM_AB   // A/B builds (make ab) instantiate only the production tiles: seconds instead of minutes
   switch (cfg) {
     case 3: return launch_cfg<T, MODE, 128, 64, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);

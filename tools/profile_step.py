@@ -21,6 +21,9 @@ def key_of(name, args, kw):
         epi = ("geglu" if kw.get("act") == hip.ACT_GEGLU else "") + ("+res" if kw.get("residual") is not None else "") + \
               ("+b2" if kw.get("bias2") is not None else "") + ("+rs" if kw.get("row_scale") is not None else "")
         return f"gemm M={a.shape[0]} N={w.shape[0]} K={a.shape[1]} {epi}", 2 * a.shape[0] * w.shape[0] * a.shape[1]
+    if name == "gemm_post":
+        a, w = args[0], args[1]
+        return f"gemm_post M={a.shape[0]} N={w.shape[0]} K={a.shape[1]} +rs+post+res", 2 * a.shape[0] * w.shape[0] * a.shape[1]
     if name == "gemm_batched_wx":
         w, x = args[0], args[1]
         return f"gemm_wx B={x.shape[0]} R={w.shape[0]} ntok={x.shape[1]} K={x.shape[2]}", 2 * x.shape[0] * w.shape[0] * x.shape[1] * x.shape[2]
@@ -64,7 +67,7 @@ def wrap(name):
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    for n in ["gemm", "gemm_batched_wx", "gemm_batched", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
+    for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
               "ncfhw_to_nhwc", "nhwc_to_ncfhw", "timestep_features", "silu", "cfg_ddim_step", "accumulate_window"]:
         wrap(n)
     sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline"]
