@@ -7,30 +7,63 @@ reference-attention banks, then window accumulate + CFG combine + DDIM update.  
 All inputs are resident in HBM before the timed region.  N GPUs = N independent clips (clip-parallel, no collective in
 the loop), so `value` is the aggregate over ranks and scaling is "weak".
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--no-cpu-baseline] [--full-cpu-baseline] [--no-extras]
+
+With --gpus N > 1 and no RANK in the environment, bench.py starts `python -m torch.distributed.run --nproc-per-node N` on
+itself as a CHILD process (before anything touches the GPU) and exits with its return code; under torch.distributed.run it
+reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.
+
+Besides the contract's line (metric / value / roofline / cpu_baseline) rank 0 at N = 1 reports, timed OUTSIDE the step loop
+("exclude prologue + VAE, report them separately"): `vae_decode` (ms per 512x512 frame and its MFMA roofline
+fraction at 2.51 TFLOP per frame), `prologue_ms` (CLIP ViT-L/14 + VAE encode + ReferenceNet + PoseGuider + bank projection,
+once per clip), `max_abs_delta_vs_cpu` (bf16 HIP forward against the CPU fp32 oracle on the cpu_baseline's sample) and
+`roofline_kernels` (live HIP-event timings of the step's heaviest kernels at their in-step shapes).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_TFLOP_PER_STEP = 62.0      # SURVEY.md section 8d: minimal algorithmic FLOPs of one CFG denoise step at 512x512x24
 EXEC_TFLOP_PER_STEP = 71.6      # as executed by the reference's op graph (quoted alongside, never the numerator)
+VAE_TFLOP_PER_FRAME = 2.51      # SURVEY App. B-6
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 FRAMES, LATENT = 24, 64
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-cpu-baseline", action="store_true",
+                    help="time one FULL 24-frame CFG forward of the oracle on the host (minutes) instead of the 2-frame sample")
+    ap.add_argument("--no-extras", action="store_true", help="skip the VAE / prologue / per-kernel legs")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--master-port", type=int, default=0)
+    return ap.parse_args()
+
+
+def self_launch(a):
+    """--gpus N > 1 without a launcher: re-run this file under torch.distributed.run as a child process.  Nothing in this
+    process has touched the GPU yet (torch is not even imported), and the child is a plain subprocess, not an exec."""
+    port = a.master_port or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def build_inputs(dev, frames=FRAMES, latent=LATENT, tag="bench"):
-    from mmgt_amd.synthetic import hash_uniform, synth_masks
-    from tests.golden_cases import bank_spatial
-    case = dict(block_out_channels=(320, 640, 1280, 1280), latent=latent)
+    import torch  # noqa: F401
+    from mmgt_amd.synthetic import bank_spatial, hash_uniform, synth_masks
     lips = synth_masks(tag + ".lips", frames, latent)
     face = synth_masks(tag + ".face", frames, latent)
     full = [1 + l for l in lips]
@@ -40,41 +73,57 @@ def build_inputs(dev, frames=FRAMES, latent=LATENT, tag="bench"):
         audio=hash_uniform(tag + ".audio", (1, frames, 32, 768), 1.7).to(dev),
         pose=hash_uniform(tag + ".pose", (1, 320, frames, latent, latent), 0.5).to(dev),
         full=[m.to(dev) for m in full], face=[m.to(dev) for m in face], lips=[m.to(dev) for m in lips],
-        banks={k: hash_uniform(tag + ".bank." + k, (2, n, c), 1.0).to(dev) for k, (n, c) in bank_spatial(case).items()},
+        banks={k: hash_uniform(tag + ".bank." + k, (2, n, c), 1.0).to(dev)
+               for k, (n, c) in bank_spatial((320, 640, 1280, 1280), latent).items()},
         motion_scale=[1.0, 1.0, 2.0])
+
+
+def operator_args(inp, dev):
+    """The CFG-batched operator call for `inp` (what Pose2VideoPipeline.denoise feeds the UNet for one window)."""
+    import torch
+    cat2 = lambda L: [torch.cat([m] * 2).to(dev) for m in L]
+    sample = inp["latents"].repeat(2, 1, 1, 1, 1).to(dev)
+    ehs = torch.cat([torch.zeros(1, 1, 768), inp["clip"].reshape(1, 1, 768).cpu()]).to(dev)
+    audio = torch.cat([torch.zeros_like(inp["audio"]), inp["audio"]]).to(dev)
+    pose = inp["pose"].repeat(2, 1, 1, 1, 1).to(dev)
+    return sample, ehs, audio, pose, cat2(inp["full"]), cat2(inp["face"]), cat2(inp["lips"])
 
 
 def cpu_baseline(sd_cpu, frames_sample=2):
     """Oracle (CPU fp32 restatement of the reference) timed on this box's host cores on a bounded sample: one CFG
     denoise-step forward at 512x512 with `frames_sample` of the 24 frames; cost is linear in frames (spatial ops are
-    per frame; temporal attention is <0.2% of the FLOPs), so steps/s = 1 / (t * 24 / frames_sample)."""
+    per frame; temporal attention is <0.2% of the FLOPs), so steps/s = 1 / (t * 24 / frames_sample).  With
+    frames_sample = 24 (--full-cpu-baseline) it is one measured step.  Returns (record, inputs, oracle output)."""
+    import torch
     from oracle import unet3d_ref as R
     cores = max(1, (os.cpu_count() or 2) // 2)
     torch.set_num_threads(cores)
-    inp = build_inputs("cpu", frames=frames_sample)
-    cat2 = lambda L: [torch.cat([m] * 2) for m in L]
-    sample = inp["latents"].repeat(2, 1, 1, 1, 1)
-    ehs = torch.cat([torch.zeros(1, 1, 768), inp["clip"].reshape(1, 1, 768)])
-    audio = torch.cat([torch.zeros_like(inp["audio"]), inp["audio"]])
-    pose = inp["pose"].repeat(2, 1, 1, 1, 1)
+    inp = build_inputs("cpu", frames=frames_sample, tag="bench.cpu")
+    sample, ehs, audio, pose, full, face, lips = operator_args(inp, "cpu")
     t0 = time.time()
     with torch.no_grad():
-        out = R.unet3d_forward(sd_cpu, R.UNet3DConfig(), sample, torch.tensor(499), ehs, audio, pose, cat2(inp["full"]),
-                               cat2(inp["face"]), cat2(inp["lips"]), inp["motion_scale"], inp["banks"], weighted=True)
+        out = R.unet3d_forward(sd_cpu, R.UNet3DConfig(), sample, torch.tensor(499), ehs, audio, pose, full, face, lips,
+                               inp["motion_scale"], inp["banks"], weighted=True)
     dt = time.time() - t0
     assert torch.isfinite(out).all()
-    return {"value": 1.0 / (dt * FRAMES / frames_sample), "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"one CFG denoise-step forward of the oracle (PyTorch CPU fp32) at 512x512 on {frames_sample} of 24 "
-                      f"frames: {dt:.1f} s, scaled x{FRAMES // frames_sample} to 24 frames",
-            "cpu": _cpu_name()}
+    what = (f"one CFG denoise-step forward of the oracle (PyTorch CPU fp32) at 512x512 on {frames_sample} of 24 frames: "
+            f"{dt:.1f} s" + (f", scaled x{FRAMES // frames_sample} to 24 frames" if frames_sample != FRAMES else " (measured, not scaled)"))
+    rec = {"value": 1.0 / (dt * FRAMES / frames_sample), "unit": "steps/s", "cores": cores, "kind": "port", "sample": what,
+           "cpu": _cpu_name()}
+    return rec, inp, out
 
 
 def pmc_traffic():
     """HBM-side bytes per denoise step from the committed rocprofv3 PMC passes (profiles/r*/pmc_traffic*.json: FETCH_SIZE and
     WRITE_SIZE collected in separate runs of this same command, gfx950 FETCH_SIZE x2 correction applied)."""
     import glob
-    latest = os.path.join(ROOT, "profiles", "r1", "pmc_traffic_s55.json")     # the passes that belong to the current build
-    files = [latest] if os.path.exists(latest) else sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic*.json")))
+    cur = os.path.join(ROOT, "profiles", "CURRENT_TRAFFIC")      # names the passes that belong to the current build
+    files = []
+    if os.path.exists(cur):
+        f = os.path.join(ROOT, open(cur).read().strip())
+        files = [f] if os.path.exists(f) else []
+    if not files:
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic*.json")), key=os.path.getmtime)
     if not files:
         return None, None
     d = json.load(open(files[-1]))
@@ -91,15 +140,108 @@ def _cpu_name():
     return "unknown"
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    a = ap.parse_args()
+def _time_ms(fn, reps=5, warm=1):
+    """Average device time of fn() in ms, HIP events on the stream the kernels are launched on (torch's current stream)."""
+    import torch
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
+
+def kernel_rooflines(unet, dev):
+    """Live HIP-event timings of the step's heaviest kernels at their in-step shapes (level 0: 48 frames x 4096 tokens x 320
+    channels), each against the roofline that bounds it.  Launch counts per step are from profiles/ (opshapes)."""
+    import torch
+    from mmgt_amd import hip
+    from mmgt_amd.synthetic import hash_uniform
+    dt = unet.dtype
+    out = []
+    M, C = 48 * 4096, 320
+    x = hash_uniform("k.x", (M, C), 1.0, dev).to(dt)
+    t = "down_blocks.0.attentions.0.transformer_blocks.0"
+    # GEGLU ff1 (N = 2560, K = 320) + ff2 (K = 1280)
+    w1, b1 = unet.w[t + ".ff.ff1.w"], unet.w[t + ".ff.ff1.bias"]
+    ms = _time_ms(lambda: hip.gemm(x, w1, b1, act=hip.ACT_GEGLU))
+    fl = 2.0 * M * 2560 * 320
+    out.append({"kernel": "gemm GEGLU ff1 M=196608 N=2560 K=320", "bound": "mfma", "ms": ms, "achieved": fl / ms / 1e9,
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS})
+    # spatial attention with bank (uncond half: 4096 keys, cond half: 8192 keys), hd 40
+    n, heads, hd = 4096, 8, 40
+    qk = hash_uniform("k.qk", (48 * n, 2 * C), 1.0, dev).to(dt)
+    vt = hash_uniform("k.vt", (48, C, n), 1.0, dev).to(dt)
+    kb = hash_uniform("k.kb", (2, n, C), 1.0, dev).to(dt)
+    vbt = hash_uniform("k.vbt", (2, C, n), 1.0, dev).to(dt)
+    o = torch.empty((48 * n, C), device=dev, dtype=dt)
+
+    def attn():
+        hip.attention(qk, qk[:, C:], vt, o, batch=48, heads=heads, hd=hd, nq=n, nk=n, scale=hd ** -0.5,
+                      q_str=(n * 2 * C, 0, 2 * C), k_str=(n * 2 * C, 0, 2 * C), v_str=(C * n, 0, n), o_str=(n * C, 0, C),
+                      v_transposed=True, k2=kb, v2=vbt, k2_str=(kb.stride(0), kb.stride(1)),
+                      v2_str=(vbt.stride(0), vbt.stride(1)), k2_bdiv=24, nk2=n, seg2_first_batch=24)
+    ms = _time_ms(attn)
+    fl = 4.0 * heads * hd * n * (24 * n + 24 * 2 * n)          # the uncond half never reads the bank
+    out.append({"kernel": "attention hd=40 nq=4096 nk=4096 (+4096 bank keys for the cond half)", "bound": "mfma", "ms": ms,
+                "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS})
+    # conv3x3 320 -> 320 at 64x64
+    xi = hash_uniform("k.xi", (48, 64, 64, C), 1.0, dev).to(dt)
+    wc, bc = unet.w["down_blocks.0.resnets.0.conv2.w"], unet.w["down_blocks.0.resnets.0.conv2.bias"]
+    ms = _time_ms(lambda: hip.conv3x3(xi, wc, bc))
+    fl = 2.0 * M * C * 9 * C
+    out.append({"kernel": "conv3x3 48x64x64 320->320", "bound": "mfma", "ms": ms, "achieved": fl / ms / 1e9,
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS})
+    # GroupNorm + SiLU at L0 (HBM: 2 reads + 1 write of the tensor)
+    g, b = unet.w["down_blocks.0.resnets.0.norm1.g"], unet.w["down_blocks.0.resnets.0.norm1.b"]
+    x3 = xi.view(48, 4096, C)
+    ms = _time_ms(lambda: hip.groupnorm(x3, g, b, 32, 1e-5, silu=True))
+    by = 3.0 * M * C * 2
+    out.append({"kernel": "groupnorm+silu 48x4096x320", "bound": "hbm", "ms": ms, "achieved": by / ms / 1e6, "peak": 8000.0,
+                "unit": "GB/s", "frac": by / ms / 1e6 / 8000.0})
+    return out
+
+
+def extras(pipe, unet, dev, dtype):
+    """VAE decode, prologue -- the once-per-clip legs SURVEY 8d asks to report next to the step rate."""
+    import torch
+    from mmgt_amd.synthetic import build_synthetic_pipeline, hash_uniform
+    res = {}
+    full = build_synthetic_pipeline(dev, dtype, with_prologue=True)
+    vae, clip, refnet, pg = full.vae, full.image_encoder, full.reference_unet, full.pose_guider
+    del full
+    # ---- VAE decode: 8 frames per call as decode_video batches them
+    z = hash_uniform("bench.z", (1, 4, 8, LATENT, LATENT), 1.0).to(dev)
+    ms = _time_ms(lambda: vae.decode_video(z), reps=2, warm=1) / 8
+    tf = VAE_TFLOP_PER_FRAME / (ms / 1e3)
+    res["vae_decode"] = {"ms_per_frame": ms, "ms_per_24_frame_clip": ms * 24, "achieved": tf, "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "tflop_per_frame": VAE_TFLOP_PER_FRAME}
+    # ---- prologue: CLIP embed, VAE encode of the reference image, ReferenceNet (banks), PoseGuider, bank K/V projection
+    ref = hash_uniform("bench.ref", (1, 3, 512, 512), 1.0).to(dev)
+    pix = hash_uniform("bench.clip_px", (1, 3, 224, 224), 1.5).to(dev)
+    pose = (hash_uniform("bench.pose_rgb", (1, 3, FRAMES, 512, 512), 0.5) + 0.5).to(dev)
+
+    def prologue():
+        emb = clip(pix.to(clip.dtype)).image_embeds.float().reshape(1, 1, -1)
+        ehs = torch.cat([torch.zeros_like(emb), emb])
+        lat = vae.encode_mean(ref) * 0.18215
+        banks = refnet.write_banks(lat.float().repeat(2, 1, 1, 1), 0, ehs)
+        unet.set_banks(banks)
+        return pg(pose)
+    res["prologue_ms"] = _time_ms(prologue, reps=2, warm=1)
+    return res
+
+
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(a))
+
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -188,8 +330,23 @@ def main():
                                  f"(SURVEY 8d; {EXEC_TFLOP_PER_STEP} as executed by the reference) / HIP-event time; "
                                  f"traffic = bytes per step from {traffic_src}"},
         }
+        if world == 1 and not a.no_extras:
+            res["roofline_kernels"] = kernel_rooflines(unet, dev)
+            res.update(extras(pipe, unet, dev, dtype))
         if sd_cpu is not None:
-            res["cpu_baseline"] = cpu_baseline(sd_cpu)
+            rec, cinp, cout = cpu_baseline(sd_cpu, FRAMES if a.full_cpu_baseline else 2)
+            res["cpu_baseline"] = rec
+            del sd_cpu
+            # the same sample through the bf16 HIP operator: the metric's "max|delta| vs CPU ref" 
+            sample, ehs_c, audio_c, pose_c, fm, fc, lp = operator_args(cinp, dev)
+            unet.set_banks({k: v.to(dev) for k, v in cinp["banks"].items()})
+            pred = unet.forward(sample, 499, ehs_c, audio_c, pose_cond_fea=pose_c, full_mask=fm, face_mask=fc, body_mask=lp,
+                                motion_scale=cinp["motion_scale"], return_dict=False)[0].float().cpu()
+            d = (pred - cout).abs()
+            res["max_abs_delta_vs_cpu"] = {"max_abs": float(d.max()), "mean_abs": float(d.mean()),
+                                           "max_rel_to_absmax": float(d.max() / cout.abs().max()),
+                                           "ref_mean_abs": float(cout.abs().mean()),
+                                           "what": f"{a.dtype} HIP UNet3D forward vs the CPU fp32 oracle on the cpu_baseline sample"}
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -13,6 +13,10 @@
  *    so sequences of calls may be captured into a hipGraph.
  *  - Return 0 on success, non-zero on error with a message in mmgt_last_error() (thread-local).  Unsupported shapes are
  *    errors; there is no fallback path.
+ *  - ONE DEVICE PER PROCESS, calls from one thread at a time: the library caches per-kernel launch state (the > 64 KB
+ *    dynamic-LDS opt-in and the resident-workgroup count of each GEMM tile) for the device current at the first call.
+ *    This is the deployment model of the path (one process per GPU); a process that switches devices must
+ *    not reuse the library.
  */
 #ifndef MMGT_HIP_H
 #define MMGT_HIP_H
@@ -32,7 +36,7 @@ extern "C" {
 
 int mmgt_abi_version(void);
 const char* mmgt_last_error(void);
-/* Benchmark-only knob: "gemm_cfg" = 0 (heuristic tile choice) or 1..5 (force a tile configuration). */
+/* Benchmark-only knob: "gemm_cfg" = 0 (heuristic tile choice) or 1, 3, 6, 9, 12 (force a tile configuration). */
 int mmgt_tune(const char* key, int value);
 
 /* out[M,N] = epi(A[M,K] . W[N,K]^T):  v = acc + bias[n] + bias2[m / bias2_rows][n]; v = act(v);
@@ -128,6 +132,12 @@ int mmgt_cfg_ddim_step(const float* pred_sum, const float* counter, const float*
  * Replaces: src/pipelines/pipeline_pose2vid_long.py:622-624. */
 int mmgt_accumulate_window(const void* pred, float* pred_sum, float* counter, const int* idx, int Fw, int F, int C,
                            int Cpad, int hw, int dtype, void* stream);
+
+/* The same for `rows` (1 or 2) CFG rows of pred_sum starting at row0: pred is ((rows*Fw), hw, Cpad).  The window-parallel
+ * sampler (one long video over several GPUs) exchanges single CFG rows sliced to Cpad == C and accumulates them one by
+ * one; bump_counter = 0 for the second row of a window so that counter counts windows, as :624 does. */
+int mmgt_accumulate_window_rows(const void* pred, float* pred_sum, float* counter, const int* idx, int Fw, int F, int C,
+                                int Cpad, int hw, int rows, int row0, int bump_counter, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

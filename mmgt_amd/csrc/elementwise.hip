@@ -106,8 +106,9 @@ __global__ void cfg_ddim_kernel(const float* __restrict__ ps, const float* __res
 
 template <typename T>
 __global__ void accumulate_window_kernel(const T* __restrict__ pred, float* __restrict__ ps, float* __restrict__ counter,
-                                         const int* __restrict__ idx, int Fw, int F, int C, int Cpad, int hw) {
-  const long total = 2l * C * Fw * hw;
+                                         const int* __restrict__ idx, int Fw, int F, int C, int Cpad, int hw, int rows,
+                                         int row0, int bump) {
+  const long total = (long)rows * C * Fw * hw;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int p = i % hw;
     long t = i / hw;
@@ -116,9 +117,9 @@ __global__ void accumulate_window_kernel(const T* __restrict__ pred, float* __re
     const int c = t % C;
     const int b = t / C;
     const float v = Elem<T>::ld(pred + (((long)b * Fw + j) * hw + p) * Cpad + c);
-    ps[(((long)b * C + c) * F + idx[j]) * hw + p] += v;  // window indices are distinct: no two threads share a target
+    ps[(((long)(row0 + b) * C + c) * F + idx[j]) * hw + p] += v;  // window indices are distinct: no two threads share a target
   }
-  if (blockIdx.x == 0 && threadIdx.x < Fw) counter[idx[threadIdx.x]] += 1.f;
+  if (bump && blockIdx.x == 0 && threadIdx.x < Fw) counter[idx[threadIdx.x]] += 1.f;
 }
 
 template <typename T>
@@ -210,20 +211,27 @@ extern "C" int mmgt_cfg_ddim_step(const float* pred_sum, const float* counter, c
   return 0;
 }
 
-extern "C" int mmgt_accumulate_window(const void* pred, float* pred_sum, float* counter, const int* idx, int Fw, int F,
-                                      int C, int Cpad, int hw, int dtype, void* stream) {
+extern "C" int mmgt_accumulate_window_rows(const void* pred, float* pred_sum, float* counter, const int* idx, int Fw, int F,
+                                           int C, int Cpad, int hw, int rows, int row0, int bump_counter, int dtype,
+                                           void* stream) {
   MMGT_CHECK(pred && pred_sum && counter && idx, "accumulate_window: null pointer");
   MMGT_CHECK(Fw > 0 && Fw <= 256 && F >= Fw && C > 0 && Cpad >= C && hw > 0, "accumulate_window: bad sizes");
+  MMGT_CHECK(rows >= 1 && row0 >= 0 && row0 + rows <= 2, "accumulate_window: CFG rows [%d, %d) outside [0, 2)", row0, row0 + rows);
   MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "accumulate_window: bad dtype");
-  const long total = 2l * C * Fw * hw;
+  const long total = (long)rows * C * Fw * hw;
   if (dtype == MMGT_BF16)
     hipLaunchKernelGGL(accumulate_window_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)pred, pred_sum, counter, idx, Fw, F, C, Cpad, hw);
+                       (const bf16_t*)pred, pred_sum, counter, idx, Fw, F, C, Cpad, hw, rows, row0, bump_counter);
   else
     hipLaunchKernelGGL(accumulate_window_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)pred, pred_sum, counter, idx, Fw, F, C, Cpad, hw);
+                       (const float*)pred, pred_sum, counter, idx, Fw, F, C, Cpad, hw, rows, row0, bump_counter);
   MMGT_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int mmgt_accumulate_window(const void* pred, float* pred_sum, float* counter, const int* idx, int Fw, int F,
+                                      int C, int Cpad, int hw, int dtype, void* stream) {
+  return mmgt_accumulate_window_rows(pred, pred_sum, counter, idx, Fw, F, C, Cpad, hw, 2, 0, 1, dtype, stream);
 }
 
 extern "C" int mmgt_softmax_rows(const void* x, long ldx, void* out, long ldo, int rows, int cols, float scale, int dtype,

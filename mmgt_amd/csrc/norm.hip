@@ -32,7 +32,11 @@ struct VecIO {
   }
 };
 
-// ---- GroupNorm pass 1: per (image, row chunk) partial sum / sum of squares per group.
+// ---- GroupNorm pass 1: per (image, row chunk) partial sum / sum of squares per group, of the values SHIFTED by a per-group
+// pivot p_g = x[image][pixel 0][first channel of the group]: var = E[(x - p)^2] - (E[x - p])^2 cancels against (mean - p)^2,
+// which is of the order of the variance itself for a pivot drawn from the data, instead of against mean^2 (real SD-1.5
+// activations have channels with |mean| >> std; the unshifted single pass lost the digits the fp32 parity mode is meant
+// to keep).  One pass, no extra HBM traffic: both kernels read the same pivot.
 // LPR lanes cover one pixel row (64 for wide tensors; 16 / 32 for the VAE's 128 / 256-channel tensors so that a wave
 // streams 64 / LPR rows at once with every lane busy); a lane always owns the same channels.
 template <typename T>
@@ -43,16 +47,29 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x0,
   __shared__ float ssum[GN_MAXC], ssq[GN_MAXC];
   const int C = C0 + C1, nvec = C / VEC;
   const int n = blockIdx.y, chunk = blockIdx.x;
+  {
+    const int cgp = C / G;
+    for (int c = threadIdx.x; c < C; c += 256) {      // pivot of channel c's group (ssum doubles as the table)
+      const int c0 = (c / cgp) * cgp;
+      ssum[c] = c0 < C0 ? Elem<T>::ld(x0 + (long)n * HW * C0 + c0) : Elem<T>::ld(x1 + (long)n * HW * C1 + (c0 - C0));
+    }
+    __syncthreads();
+  }
   const int rows_per = (HW + chunks - 1) / chunks;
   const int r0 = chunk * rows_per, r1 = min(HW, r0 + rows_per);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int rpw = 64 / lpr, sub = lane / lpr, li = lane - sub * lpr;
 
-  float s[MAXS][VEC], q[MAXS][VEC];
+  float s[MAXS][VEC], q[MAXS][VEC], pv[MAXS][VEC];
 #pragma unroll
   for (int i = 0; i < MAXS; ++i)
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) s[i][e] = q[i][e] = 0.f;
+    for (int e = 0; e < VEC; ++e) {
+      s[i][e] = q[i][e] = 0.f;
+      const int c = (li + lpr * i) * VEC + e;
+      pv[i][e] = c < C ? ssum[c] : 0.f;
+    }
+  __syncthreads();                                    // ssum is reused for the reduction below
 
   for (int r = r0 + wid * rpw + sub; r < r1; r += 4 * rpw) {
     const long pix = (long)n * HW + r;
@@ -65,7 +82,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x0,
         float f[VEC];
         VecIO<T>::load(src, f);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { s[i][e] += f[e]; q[i][e] += f[e] * f[e]; }
+        for (int e = 0; e < VEC; ++e) { const float d = f[e] - pv[i][e]; s[i][e] += d; q[i][e] += d * d; }
       }
     }
   }
@@ -126,9 +143,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
       b += src[1];
     }
     const float cnt = (float)HW * (float)cg;
-    const float mean = a / cnt;
-    float var = b / cnt - mean * mean;
+    const int c0 = threadIdx.x * cg;                   // the pivot gn_stats_kernel shifted this group's values by
+    const float piv = c0 < C0 ? Elem<T>::ld(x0 + (long)n * HW * C0 + c0) : Elem<T>::ld(x1 + (long)n * HW * C1 + (c0 - C0));
+    const float dm = a / cnt;
+    float var = b / cnt - dm * dm;
     var = var < 0.f ? 0.f : var;
+    const float mean = piv + dm;
     smean[threadIdx.x] = mean;
     srstd[threadIdx.x] = rsqrtf(var + eps);
   }

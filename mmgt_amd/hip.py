@@ -47,6 +47,8 @@ _SIGS = {
                                    c_float, c_float, c_float, c_void_p]),
     "mmgt_accumulate_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p]),
+    "mmgt_accumulate_window_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                            c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 EXPORTS = tuple(_SIGS)
@@ -311,12 +313,15 @@ def cfg_ddim_step(pred_sum, counter, latents, guidance, sa_t, sb_t, sa_p, sb_p):
     return out
 
 
-def accumulate_window(pred, pred_sum, counter, idx, C):
-    """pred ((2*Fw), H, W, cpad) channels-last; pred_sum (2, C, F, H, W) fp32 += pred at frames idx (int32 device)."""
+def accumulate_window(pred, pred_sum, counter, idx, C, rows=2, row0=0, bump_counter=True):
+    """pred ((rows*Fw), H, W, cpad) channels-last; pred_sum (2, C, F, H, W) fp32: CFG rows [row0, row0 + rows) += pred at
+    frames idx (int32 device); counter[idx] += 1 when bump_counter."""
     _dev(pred, pred_sum, counter, idx)
     assert idx.dtype == torch.int32 and pred.is_contiguous() and pred_sum.is_contiguous()
     Fw = idx.numel()
     F = pred_sum.shape[2]
     hw = pred.shape[1] * pred.shape[2]
-    _check(lib().mmgt_accumulate_window(_ptr(pred), _ptr(pred_sum), _ptr(counter), _ptr(idx), Fw, F, C, pred.shape[3], hw,
-                                        dtype_code(pred.dtype), _stream()), "mmgt_accumulate_window")
+    assert pred.shape[0] == rows * Fw and pred_sum.shape[0] == 2 and pred_sum.shape[3] * pred_sum.shape[4] == hw
+    _check(lib().mmgt_accumulate_window_rows(_ptr(pred), _ptr(pred_sum), _ptr(counter), _ptr(idx), Fw, F, C, pred.shape[3],
+                                             hw, rows, row0, int(bump_counter), dtype_code(pred.dtype), _stream()),
+           "mmgt_accumulate_window_rows")

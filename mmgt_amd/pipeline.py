@@ -90,25 +90,9 @@ class Pose2VideoPipeline:
         return torch.cat(parts, dim=2)[:, :, :f].cpu().float().numpy()
 
     def interpolate_latents(self, latents, interpolation_factor, device=None):
-        """pipeline_pose2vid_long.py:292-335 (no-op below factor 2)."""
-        if interpolation_factor < 2:
-            return latents
-        from .interp import get_tensor_interpolation_method
-        f = latents.shape[2]
-        new = torch.zeros((latents.shape[0], latents.shape[1], (f - 1) * interpolation_factor + 1, *latents.shape[3:]),
-                          device=latents.device, dtype=latents.dtype)
-        rate = [i / interpolation_factor for i in range(interpolation_factor)][1:]
-        idx = 0
-        v1 = None
-        for i0 in range(f - 1):
-            v0, v1 = latents[:, :, i0], latents[:, :, i0 + 1]
-            new[:, :, idx] = v0
-            idx += 1
-            for r in rate:
-                new[:, :, idx] = get_tensor_interpolation_method()(v0, v1, r)
-                idx += 1
-        new[:, :, idx] = v1
-        return new
+        """pipeline_pose2vid_long.py:292-335 (no-op below factor 2): all pairs and rates in one batched expression."""
+        from .interp import interpolate_frames
+        return interpolate_frames(latents, interpolation_factor)
 
     def _pose_window(self, pose_fea, c):
         """Pose features of one window for both CFG rows (pipeline_pose2vid_long.py:576-580), converted ONCE to the
@@ -125,14 +109,16 @@ class Pose2VideoPipeline:
     def denoise(self, latents, timesteps, encoder_hidden_states, pose_fea, audio_tensor_pre, full_masks, face_masks,
                 lip_masks, guidance_scale, motion_scale, context_frames, context_stride, context_overlap,
                 context_schedule="uniform", num_inference_steps=None, callback=None, callback_steps=1,
-                window_group=None):
+                window_group=None, cfg_split="auto"):
         """pipeline_pose2vid_long.py:494-643.  latents (1, C, L, h, w) fp32 on the GPU; returns the final latents.
 
         window_group: a torch.distributed process group (or True for the default group) turns on window-parallel sampling of
-        ONE long video: the windows of a DDIM step are dealt round-robin to the ranks, each round
-        ends in one all-gather of the per-window predictions (RCCL over xGMI on the GPUs, 1.6 MB per rank), and every rank
-        then accumulates ALL windows in the reference's window order and applies the identical overlap-average + CFG + DDIM
-        update -- so the latents stay bit-identical on every rank and to the single-process run, with no other exchange."""
+        ONE long video.  The units of a DDIM step -- the windows, or with `cfg_split` the (window, CFG
+        row) pairs -- are dealt round-robin to the ranks; each round ends in ONE all-gather of the units' predictions, sliced
+        to the C valid channels (fp32 (rows * Fw, h, w, C): 1.57 MB per CFG row at 24 x 64 x 64 x 4), and every rank then
+        accumulates ALL units in the reference's window order and applies the identical overlap-average + CFG + DDIM update --
+        so the latents stay bit-identical on every rank, with no other exchange.  cfg_split: "auto" splits the CFG rows when
+        that shortens the critical path (6 windows on 4 ranks: 3 rounds of half units instead of 2 rounds of whole ones)."""
         video_length = latents.shape[2]
         dev = latents.device
         sched = get_context_scheduler(context_schedule)
@@ -151,32 +137,68 @@ class Pose2VideoPipeline:
                 face=[t.view(2, video_length, -1)[:, c].reshape(-1, t.shape[-1]).contiguous() for t in face_masks],
                 lips=[t.view(2, video_length, -1)[:, c].reshape(-1, t.shape[-1]).contiguous() for t in lip_masks]))
         C = latents.shape[1]
+        group = world = rank = None
+        units = [(w, None) for w in range(len(windows))]
+        if window_group is not None:
+            group = None if window_group is True else window_group
+            world, rank = parallel.dist.get_world_size(group), parallel.dist.get_rank(group)
+            nw = len(windows)
+            if cfg_split == "auto":
+                cfg_split = -(-2 * nw // world) < 2 * -(-nw // world)      # rounds of half units vs rounds of whole units
+            if cfg_split:
+                units = [(w, row) for w in range(nw) for row in (0, 1)]
+        half_cond = {}
+
+        def unit_cond(w, row):
+            """Conditioning of one CFG row of window w (step-invariant, cut once)."""
+            if (w, row) not in half_cond:
+                cd, fw = cond[w], len(windows[w])
+                cut = lambda t: t.view(2, fw, -1)[row].contiguous()
+                pose = cd["pose"]
+                if pose is not None:
+                    pose = pose.view(2, fw, *pose.shape[1:])[row].contiguous() if pose.dim() == 4 else pose[row:row + 1]
+                half_cond[(w, row)] = dict(pose=pose, audio=cd["audio"][row:row + 1].contiguous(),
+                                           full=[cut(t) for t in cd["full"]], face=[cut(t) for t in cd["face"]],
+                                           lips=[cut(t) for t in cd["lips"]])
+            return half_cond[(w, row)]
+
         for i, t in enumerate(timesteps):
             pred_sum = torch.zeros((2,) + tuple(latents.shape[1:]), device=dev, dtype=torch.float32)
             counter = torch.zeros((video_length,), device=dev, dtype=torch.float32)
-            def run_window(w):
-                cd = cond[w]
-                latent_in = self.scheduler.scale_model_input(latents[:, :, win_long[w]].repeat(2, 1, 1, 1, 1), t)
+
+            def run_unit(w, row):
+                lat_w = self.scheduler.scale_model_input(latents[:, :, win_long[w]], t)
+                if row is None:
+                    cd, kw = cond[w], {}
+                    lat_w = lat_w.repeat(2, 1, 1, 1, 1)
+                else:
+                    cd, kw = unit_cond(w, row), dict(cfg_row=row)
                 return self.denoising_unet.denoise_window(
-                    latent_in, t, encoder_hidden_states=encoder_hidden_states, audio_embedding=cd["audio"],
+                    lat_w, t, encoder_hidden_states=encoder_hidden_states, audio_embedding=cd["audio"],
                     pose_cond_fea=cd["pose"], full_mask=cd["full"], face_mask=cd["face"], body_mask=cd["lips"],
-                    motion_scale=motion_scale)
+                    motion_scale=motion_scale, **kw)
 
             if window_group is None:
                 for w in range(len(windows)):
-                    hip.accumulate_window(run_window(w), pred_sum, counter, win_idx[w], C)
+                    hip.accumulate_window(run_unit(w, None), pred_sum, counter, win_idx[w], C)
             else:
-                group = None if window_group is True else window_group
-                world, rank = parallel.dist.get_world_size(group), parallel.dist.get_rank(group)
-                pred_shape = (2, C, len(windows[0])) + tuple(latents.shape[3:])
-                for w0 in range(0, len(windows), world):
-                    mine = w0 + rank
-                    pred = run_window(mine) if mine < len(windows) else \
-                        torch.zeros(pred_shape, device=dev, dtype=torch.float32)     # idle rank in the last round
-                    preds = parallel.allgather_window_predictions(pred.float(), group)
+                rows = 1 if units[0][1] is not None else 2
+                fw = len(windows[0])
+                wire_shape = (rows * fw,) + tuple(latents.shape[3:]) + (C,)
+                for u0 in range(0, len(units), world):
+                    mine = u0 + rank
+                    if mine < len(units):
+                        # the operator returns ((rows * Fw), h, w, 64) channels-last with C valid channels: only those travel
+                        pred = run_unit(*units[mine])[..., :C].float().contiguous()
+                        assert pred.shape == wire_shape, (pred.shape, wire_shape)
+                    else:                                   # idle rank in the last round: same shape and dtype on the wire
+                        pred = torch.zeros(wire_shape, device=dev, dtype=torch.float32)
+                    preds = parallel.allgather_window_predictions(pred, group)
                     for r in range(world):
-                        if w0 + r < len(windows):
-                            hip.accumulate_window(preds[r], pred_sum, counter, win_idx[w0 + r], C)
+                        if u0 + r < len(units):
+                            w, row = units[u0 + r]
+                            hip.accumulate_window(preds[r], pred_sum, counter, win_idx[w], C, rows=rows, row0=row or 0,
+                                                  bump_counter=row in (None, 0))
             sa_t, sb_t, sa_p, sb_p = self.scheduler.step_coefficients(t)
             latents = hip.cfg_ddim_step(pred_sum, counter, latents, float(guidance_scale), sa_t, sb_t, sa_p, sb_p)
             if callback is not None and i % callback_steps == 0:
@@ -252,7 +274,7 @@ class Pose2VideoPipeline:
         latents = self.denoise(latents, timesteps, encoder_hidden_states, pose_fea, audio_pre, full_masks, face_masks,
                                lip_masks, guidance_scale, motion_scale, context_frames, context_stride, context_overlap,
                                context_schedule, num_inference_steps, callback, callback_steps,
-                               window_group=kwargs.get("window_group"))
+                               window_group=kwargs.get("window_group"), cfg_split=kwargs.get("cfg_split", "auto"))
         unet.clear_banks()                                                                # :645-646
 
         if interpolation_factor > 0:

@@ -101,3 +101,47 @@ def synth_masks(tag: str, frames: int, latent_hw: int, device="cpu", dtype=torch
         if cur.shape[-1] >= 2:
             cur = torch.nn.functional.avg_pool2d(cur, 2)
     return levels
+
+
+def bank_spatial(block_out_channels=(320, 640, 1280, 1280), latent=64):
+    """{reference-attention reader prefix: (N, C)} in the reference's module order down -> up -> mid."""
+    boc, h = block_out_channels, latent
+    out = {}
+    for i in range(3):
+        for j in range(2):
+            out[f"down_blocks.{i}.attentions.{j}"] = ((h >> i) ** 2, boc[i])
+    for i in range(1, 4):
+        for j in range(3):
+            out[f"up_blocks.{i}.attentions.{j}"] = ((h >> (3 - i)) ** 2, boc[3 - i])
+    out["mid_block.attentions.0"] = ((h >> 3) ** 2, boc[3])
+    return out
+
+
+def build_synthetic_pipeline(dev, dtype, with_prologue=True):
+    """Pose2VideoPipeline over random-init weights of the reference architecture (no checkpoints ship with the reference):
+    UNet3D denoiser (+ ReferenceNet, PoseGuider, VAE, CLIP ViT-L/14 when with_prologue), scripts/pose2vid.py:144-197."""
+    from .pipeline import Pose2VideoPipeline
+    from .scheduler import DDIMScheduler
+    from .unet3d import UNet3DConditionModel
+    from .unet3d_spec import unet2d_reference_spec, unet3d_spec
+    unet = UNet3DConditionModel(device=dev, dtype=dtype)
+    unet.load_state_dict(synth_state_dict(unet3d_spec(), device=dev))
+    unet.enable_gradient_checkpointing()                      # scripts/pose2vid.py:183-184
+    ref = pg = vae = clip = None
+    if with_prologue:
+        from .clip_vision import CLIPVisionModelWithProjection, clip_vision_spec
+        from .reference_unet import UNet2DConditionModel
+        from .side_models import PoseGuider
+        from .vae import AutoencoderKL, vae_decoder_spec, vae_encoder_spec
+        ref = UNet2DConditionModel(device=dev, dtype=dtype)
+        ref.load_state_dict(synth_state_dict(unet2d_reference_spec(), prefix="refnet.", device=dev))
+        pg = PoseGuider(320, block_out_channels=(16, 32, 96, 256), device=dev, dtype=dtype)   # :158
+        pg.load_state_dict(synth_state_dict(pg.spec, prefix="pose_guider.", device=dev))
+        vae = AutoencoderKL(device=dev, dtype=dtype)
+        vae_spec = vae_decoder_spec()
+        vae_spec.update(vae_encoder_spec())                   # the encoder turns the reference image into ref_image_latents
+        vae.load_state_dict(synth_state_dict(vae_spec, prefix="vae.", device=dev))
+        clip = CLIPVisionModelWithProjection(device=dev, dtype=dtype)     # ViT-L/14, the reference's image_encoder (:158-162)
+        clip.load_state_dict(synth_state_dict(clip_vision_spec(), prefix="clip.", device=dev))
+    return Pose2VideoPipeline(vae=vae, image_encoder=clip, reference_unet=ref, denoising_unet=unet, pose_guider=pg,
+                              scheduler=DDIMScheduler())

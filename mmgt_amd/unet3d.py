@@ -322,11 +322,12 @@ class UNet3DConditionModel:
                 if has(f"{t}.attn2_{i}.to_out.0.weight") and has(f"{t}.{z}.weight"):
                     # zero_conv_i(mask_i * to_out_i(a)) = mask_i * (a (Wz Wo)^T + Wz b_o) + b_z  (attention.py:730-760): the
                     # per-token mask is a row scalar, so the 1x1 conv folds into the Linear -- one GEMM per branch
-                    wz = sd[f"{t}.{z}.weight"].to(torch.float32).reshape(sd[f"{t}.{z}.weight"].shape[0], -1)
-                    wo = sd[f"{t}.attn2_{i}.to_out.0.weight"].to(torch.float32)
-                    bo = sd[f"{t}.attn2_{i}.to_out.0.bias"].to(torch.float32)
-                    w[f"{t}.oz{i}.w"] = self._t(wz @ wo)
-                    w[f"{t}.oz{i}.bias"] = self._f(wz @ bo)
+                    # (Wz Wo and Wz b_o: fp32 GEMMs of the library itself, once per load_state_dict)
+                    wz = self._f(sd[f"{t}.{z}.weight"].reshape(sd[f"{t}.{z}.weight"].shape[0], -1))
+                    wo_t = self._f(sd[f"{t}.attn2_{i}.to_out.0.weight"].t())
+                    bo = self._f(sd[f"{t}.attn2_{i}.to_out.0.bias"])[None, :].contiguous()
+                    w[f"{t}.oz{i}.w"] = self._t(hip.gemm(wz, wo_t))
+                    w[f"{t}.oz{i}.bias"] = hip.gemm(wz, bo).reshape(-1).contiguous()
             ff(t + ".ff")
 
         self._motion = [k[: -len(".temporal_transformer.norm.weight")] for k in self.spec
@@ -432,8 +433,10 @@ class UNet3DConditionModel:
             self.w[f"{p}.sc.w.1"] = wsc[:, c0:].contiguous()
         return self.w[key]
 
-    def _self_attention(self, t, n1, nb, n, inner, bank=None, frames=1):
-        """attn1: q,k from one GEMM, V^T from a batched W.X^T GEMM, flash attention, returns (nb*n, inner)."""
+    def _self_attention(self, t, n1, nb, n, inner, bank=None, frames=1, cfg_row=None):
+        """attn1: q,k from one GEMM, V^T from a batched W.X^T GEMM, flash attention, returns (nb*n, inner).
+        cfg_row: None = both CFG rows batched (the bank is read by the second half of the batch only); 0 / 1 = the batch
+        holds the unconditional / conditional row alone (window-parallel sampling splits them over ranks)."""
         hd = inner // self.heads
         qk = hip.gemm(n1, self.w[t + ".qk.w"])
         npad = round_up(n, 8)
@@ -441,16 +444,18 @@ class UNet3DConditionModel:
         hip.gemm_batched_wx(self.w[t + ".v.w"], n1.view(nb, n, inner), out=vt)
         o = torch.empty((nb * n, inner), device=self._device, dtype=self._dtype)
         kw = {}
-        if bank is not None:
+        if bank is not None and cfg_row != 0:
             kb, vbt, nkb = bank
+            if cfg_row == 1:                 # only bank row 1 (the conditional row's features) is ever read: SURVEY App. C-6
+                kb, vbt = kb[1:], vbt[1:]
             kw = dict(k2=kb, v2=vbt, k2_str=(kb.stride(0), kb.stride(1)), v2_str=(vbt.stride(0), vbt.stride(1)),
-                      k2_bdiv=frames, nk2=nkb, seg2_first_batch=nb // 2)
+                      k2_bdiv=frames, nk2=nkb, seg2_first_batch=0 if cfg_row == 1 else nb // 2)
         hip.attention(qk, qk[:, inner:], vt, o, batch=nb, heads=self.heads, hd=hd, nq=n, nk=n, scale=hd ** -0.5,
                       q_str=(n * 2 * inner, 0, 2 * inner), k_str=(n * 2 * inner, 0, 2 * inner),
                       v_str=(inner * npad, 0, npad), o_str=(n * inner, 0, inner), v_transposed=True, **kw)
         return o
 
-    def _spatial_transformer(self, p, x, ehs, frames, write=None):
+    def _spatial_transformer(self, p, x, ehs, frames, write=None, cfg_row=None):
         """Transformer3DModel + TemporalBasicTransformerBlock in bank-read mode (transformer_3d.py:139-268,
         mutual_self_attention.py:149-230)."""
         nb, h, ww, c = x.shape
@@ -464,16 +469,18 @@ class UNet3DConditionModel:
         if write is not None:            # ReferenceNet "write" mode: bank.append(norm_hidden_states) (mutual_self_attention.py:139-148)
             write[p] = n1.view(nb, n, inner).float()
         o = self._self_attention(t + ".attn1", n1, nb, n, inner, bank=None if write is not None else self._banks.get(p),
-                                 frames=frames)
+                                 frames=frames, cfg_row=cfg_row)
         if ehs.shape[1] == 1:
             # one key: softmax == 1, attn2 output is the per-CFG-row constant to_out(to_v(e))
             cvec = self._clip_vector(t, ehs)
-            rows = nb // ehs.shape[0] * n if ehs.shape[0] != nb else n
+            if cfg_row is not None:
+                cvec = cvec[cfg_row:cfg_row + 1]
+            rows = nb // cvec.shape[0] * n if cvec.shape[0] != nb else n
             hid = hip.gemm(o, self.w[t + ".attn1.o.w"], self.w[t + ".attn1.o.bias"], residual=hid,
                            bias2=cvec, bias2_rows=rows)
         else:
             hid = hip.gemm(o, self.w[t + ".attn1.o.w"], self.w[t + ".attn1.o.bias"], residual=hid)
-            hid = self._cross_attention(t, hid, ehs, nb, n, inner)
+            hid = self._cross_attention(t, hid, ehs if cfg_row is None else ehs[cfg_row:cfg_row + 1], nb, n, inner)
         hid = self._ff(t + ".ff", self._ln(t + ".norm3", hid), hid)
         out = hip.gemm(hid, self.w[p + ".proj_out.w"], self.w[p + ".proj_out.bias"], residual=x.view(m, c))
         return out.view(nb, h, ww, c)
@@ -602,9 +609,14 @@ class UNet3DConditionModel:
     __call__ = forward
 
     def denoise_window(self, sample, timestep, encoder_hidden_states, audio_embedding=None, pose_cond_fea=None,
-                       full_mask=None, face_mask=None, body_mask=None, motion_scale=None):
+                       full_mask=None, face_mask=None, body_mask=None, motion_scale=None, cfg_row=None):
         """The operator body; returns the prediction channels-last ((b f), h, w, 64) with the first 4 channels valid
-        (what mmgt_accumulate_window consumes, so the sampler never converts layouts)."""
+        (what mmgt_accumulate_window consumes, so the sampler never converts layouts).
+        cfg_row (0 or 1): `sample`, the audio, pose and masks hold ONE CFG row (b = 1) -- the unconditional row never reads
+        the reference banks, the conditional row reads them in every frame; `encoder_hidden_states` stays the (2, 1, 768)
+        pair.  The window-parallel sampler deals the two rows of a window to different GPUs."""
+        if cfg_row is not None and (cfg_row not in (0, 1) or sample.shape[0] != 1 or encoder_hidden_states.shape[0] != 2):
+            raise RuntimeError("cfg_row: one CFG row (b = 1) with the (2, ...) encoder_hidden_states pair")
         if not self._loaded:
             raise RuntimeError("UNet3DConditionModel.forward before load_state_dict")
         if not sample.is_cuda:
@@ -640,7 +652,7 @@ class UNet3DConditionModel:
             for j in range(lpb):
                 x = self._resnet(f"{p}.resnets.{j}", x, temb)
                 if i < 3:
-                    x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs, f)
+                    x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs, f, cfg_row=cfg_row)
                     if f"{p}.audio_modules.{j}" in self._audio:
                         x = self._audio_transformer(f"{p}.audio_modules.{j}", x, audio, masks, i, ms)
                 x = self._motion_module(f"{p}.motion_modules.{j}", x, f)
@@ -650,7 +662,7 @@ class UNet3DConditionModel:
                 skips.append(x)
 
         x = self._resnet("mid_block.resnets.0", x, temb)
-        x = self._spatial_transformer("mid_block.attentions.0", x, ehs, f)
+        x = self._spatial_transformer("mid_block.attentions.0", x, ehs, f, cfg_row=cfg_row)
         x = self._motion_module("mid_block.motion_modules.0", x, f)
         x = self._resnet("mid_block.resnets.1", x, temb)
 
@@ -659,7 +671,7 @@ class UNet3DConditionModel:
             for j in range(lpb + 1):
                 x = self._resnet(f"{p}.resnets.{j}", x, temb, skip=skips.pop())
                 if i > 0:
-                    x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs, f)
+                    x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs, f, cfg_row=cfg_row)
                 x = self._motion_module(f"{p}.motion_modules.{j}", x, f)
             if i != 3:
                 x = hip.conv3x3(x, self.w[f"{p}.upsamplers.0.conv.w"], self.w[f"{p}.upsamplers.0.conv.bias"], upsample=True)

@@ -169,12 +169,17 @@ class AutoencoderKL:
                 w[p + ".bias"] = self._f(pad_rows(b, round_up(m.shape[0], 64)))
         f32 = lambda t: t.to(torch.float32)
         for a in ["decoder.mid_block.attentions.0"] + (["encoder.mid_block.attentions.0"] if enc_present else []):
-            w[a + ".q.w"], w[a + ".q.bias"] = self._t(sd[a + ".to_q.weight"]), self._f(sd[a + ".to_q.bias"])
-            w[a + ".k.w"], w[a + ".k.bias"] = self._t(sd[a + ".to_k.weight"]), self._f(sd[a + ".to_k.bias"])
-            w[a + ".v.w"] = self._t(sd[a + ".to_v.weight"])
-            w[a + ".o.w"] = self._t(sd[a + ".to_out.0.weight"])
+            # The single 512-wide head runs in the fp32 instantiation of the kernels whatever the model dtype: with real
+            # sd-vae-ft-mse weights the logits reach hundreds, where a bf16 score has an ulp of 1-2; the reference
+            # runs this block in fp16/fp32.  34 GFLOP per frame: 0.3 ms at the fp32 MFMA rate, against ~100 ms of convs.
+            w[a + ".q.w"], w[a + ".q.bias"] = self._f(sd[a + ".to_q.weight"]), self._f(sd[a + ".to_q.bias"])
+            w[a + ".k.w"], w[a + ".k.bias"] = self._f(sd[a + ".to_k.weight"]), self._f(sd[a + ".to_k.bias"])
+            w[a + ".v.w"] = self._f(sd[a + ".to_v.weight"])
+            w[a + ".o.w"] = self._f(sd[a + ".to_out.0.weight"])
             # softmax rows sum to 1, so P (V + 1 b_v^T) = P V + b_v^T: the value bias moves into the output bias
-            w[a + ".o.bias"] = self._f(f32(sd[a + ".to_out.0.weight"]) @ f32(sd[a + ".to_v.bias"]) + f32(sd[a + ".to_out.0.bias"]))
+            # (W_o b_v as an fp32 GEMM with one output column, on the device like every other product of this library)
+            wob = hip.gemm(w[a + ".o.w"], self._f(sd[a + ".to_v.bias"])[None, :].contiguous()).reshape(-1)
+            w[a + ".o.bias"] = (wob + self._f(sd[a + ".to_out.0.bias"])).contiguous()
         self._loaded = True
         self._has_encoder = bool(enc_present)
         return [], [k for k in sd if k not in spec]
@@ -197,18 +202,18 @@ class AutoencoderKL:
     def _mid_attention(self, x, a="decoder.mid_block.attentions.0"):
         nb, h, ww, c = x.shape
         n = h * ww
-        t = self._gn(a + ".group_norm", x, False).view(nb * n, c)
+        t = self._gn(a + ".group_norm", x, False).view(nb * n, c).float()                    # fp32 from here (see load_state_dict)
         q = hip.gemm(t, self.w[a + ".q.w"], self.w[a + ".q.bias"]).view(nb, n, c)
         k = hip.gemm(t, self.w[a + ".k.w"], self.w[a + ".k.bias"]).view(nb, n, c)
-        vt = torch.empty((nb, c, n), device=self._device, dtype=self._dtype)
+        vt = torch.empty((nb, c, n), device=self._device, dtype=torch.float32)
         hip.gemm_batched_wx(self.w[a + ".v.w"], t.view(nb, n, c), out=vt)                    # V^T without its bias
-        s_ = torch.empty((nb, n, n), device=self._device, dtype=self._dtype)
+        s_ = torch.empty((nb, n, n), device=self._device, dtype=torch.float32)
         hip.gemm_batched(q, k, out=s_)                                                        # scores, one frame per z
         hip.softmax_rows(s_.view(nb * n, n), c ** -0.5, out=s_.view(nb * n, n))
-        o = torch.empty((nb, n, c), device=self._device, dtype=self._dtype)
+        o = torch.empty((nb, n, c), device=self._device, dtype=torch.float32)
         hip.gemm_batched(s_, vt, out=o)
-        out = hip.gemm(o.view(nb * n, c), self.w[a + ".o.w"], self.w[a + ".o.bias"], residual=x.view(nb * n, c))
-        return out.view(nb, h, ww, c)
+        out = hip.gemm(o.view(nb * n, c), self.w[a + ".o.w"], self.w[a + ".o.bias"], residual=x.view(nb * n, c).float())
+        return out.to(self._dtype).view(nb, h, ww, c)
 
     # ------------------------------------------------------------------------------------------------ API
     def decode_nhwc(self, z):

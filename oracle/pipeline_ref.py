@@ -11,8 +11,15 @@ from .vae_ref import decode_latents
 
 def pose2vid(sd_unet, sd_refnet, sd_pose, sd_vae, *, clip_image_embeds, ref_image_latents, pose_images, audio_tensor,
              full_mask, face_mask, lip_mask, latents, num_inference_steps, guidance_scale, motion_scale,
-             context_frames=12, context_stride=1, context_overlap=4, cfg=None, decode=True, trajectory=None):
+             context_frames=12, context_stride=1, context_overlap=4, cfg=None, decode=True, trajectory=None,
+             unet_dtype=torch.float32):
+    """unet_dtype=torch.bfloat16 runs the denoiser (weights and activations) under PyTorch CPU bf16 while the sampler state
+    stays fp32, as the HIP product mode does: the measured bf16 noise floor the bf16 gates of tests/ are set against."""
     cfg = cfg or R.UNet3DConfig()
+    low = unet_dtype != torch.float32
+    cst = (lambda t: t.to(unet_dtype)) if low else (lambda t: t)
+    if low:
+        sd_unet = {k: cst(v) for k, v in sd_unet.items()}
     sched = DDIMRef()
     sched.set_timesteps(num_inference_steps)
     ehs = clip_image_embeds.reshape(1, 1, -1)
@@ -31,8 +38,10 @@ def pose2vid(sd_unet, sd_refnet, sd_pose, sd_vae, *, clip_image_embeds, ref_imag
             lat_in = latents[:, :, c].repeat(2, 1, 1, 1, 1)
             pose_in = pose_fea[:, :, c].repeat(2, 1, 1, 1, 1)
             sel = lambda ms: [m.view(2, video_length, -1)[:, c, :].reshape(-1, m.shape[-1]) for m in ms]   # :573-586
-            pred = R.unet3d_forward(sd_unet, cfg, lat_in, t, ehs, audio[:, c], pose_in, sel(full_mask), sel(face_mask),
-                                    sel(lip_mask), motion_scale, banks, weighted=True)
+            pred = R.unet3d_forward(sd_unet, cfg, cst(lat_in), t, cst(ehs), cst(audio[:, c]), cst(pose_in),
+                                    [cst(m) for m in sel(full_mask)], [cst(m) for m in sel(face_mask)],
+                                    [cst(m) for m in sel(lip_mask)], motion_scale,
+                                    {k: cst(v) for k, v in banks.items()} if low else banks, weighted=True).float()
             noise_pred[:, :, c] = noise_pred[:, :, c] + pred                               # :622-624
             counter[:, :, c] = counter[:, :, c] + 1
         u, ctext = (noise_pred / counter).chunk(2)                                          # :627-631

@@ -82,6 +82,7 @@ def timestep_embedding(sd, timesteps, dim):
     freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
     emb = timesteps[:, None].float() * freqs[None]
     emb = torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+    emb = emb.to(sd["time_embedding.linear_1.weight"].dtype)      # t_emb.to(dtype=self.dtype), unet_3d.py:500
     emb = _lin(sd, "time_embedding.linear_1", emb)
     return _lin(sd, "time_embedding.linear_2", F.silu(emb))
 

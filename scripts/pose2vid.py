@@ -48,30 +48,8 @@ def parse_args():
 
 
 def build_synthetic(dev, dtype):
-    from mmgt_amd.clip_vision import CLIPVisionModelWithProjection, clip_vision_spec
-    from mmgt_amd.pipeline import Pose2VideoPipeline
-    from mmgt_amd.reference_unet import UNet2DConditionModel
-    from mmgt_amd.scheduler import DDIMScheduler
-    from mmgt_amd.side_models import PoseGuider
-    from mmgt_amd.synthetic import synth_state_dict
-    from mmgt_amd.unet3d import UNet3DConditionModel
-    from mmgt_amd.unet3d_spec import unet2d_reference_spec, unet3d_spec
-    from mmgt_amd.vae import AutoencoderKL, vae_decoder_spec, vae_encoder_spec
-    unet = UNet3DConditionModel(device=dev, dtype=dtype)
-    unet.load_state_dict(synth_state_dict(unet3d_spec(), device=dev))
-    unet.enable_gradient_checkpointing()                      # scripts/pose2vid.py:183-184
-    ref = UNet2DConditionModel(device=dev, dtype=dtype)
-    ref.load_state_dict(synth_state_dict(unet2d_reference_spec(), prefix="refnet.", device=dev))
-    pg = PoseGuider(320, block_out_channels=(16, 32, 96, 256), device=dev, dtype=dtype)   # :158
-    pg.load_state_dict(synth_state_dict(pg.spec, prefix="pose_guider.", device=dev))
-    vae = AutoencoderKL(device=dev, dtype=dtype)
-    vae_spec = vae_decoder_spec()
-    vae_spec.update(vae_encoder_spec())                       # the encoder turns the reference image into ref_image_latents
-    vae.load_state_dict(synth_state_dict(vae_spec, prefix="vae.", device=dev))
-    clip = CLIPVisionModelWithProjection(device=dev, dtype=dtype)     # ViT-L/14, the reference's image_encoder (:158-162)
-    clip.load_state_dict(synth_state_dict(clip_vision_spec(), prefix="clip.", device=dev))
-    return Pose2VideoPipeline(vae=vae, image_encoder=clip, reference_unet=ref, denoising_unet=unet, pose_guider=pg,
-                              scheduler=DDIMScheduler())
+    from mmgt_amd.synthetic import build_synthetic_pipeline
+    return build_synthetic_pipeline(dev, dtype)
 
 
 def main():

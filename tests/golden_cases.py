@@ -13,21 +13,27 @@ UNET_CASES = {
     # BASELINE config 1 geometry at full width: 64x64 px -> 8x8 latent, 8 frames
     "full_cfg1": dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768, audio_attention_dim=768,
                       frames=8, latent=8, timestep=499),
+    # G4: BASELINE config 2 = the benchmarked shape, 512x512 px -> 64x64 latent, 24 frames.  The fixture holds a
+    # strided sub-sample + moments of the reference's (2,4,24,64,64) output (tools/refgen/gen_golden.py --only full_cfg2).
+    "full_cfg2": dict(block_out_channels=(320, 640, 1280, 1280), cross_attention_dim=768, audio_attention_dim=768,
+                      frames=24, latent=64, timestep=499),
 }
+
+G4_STRIDE = 97          # flat-index stride of the committed sub-sample (prime: walks every (b, c, f, y, x) residue)
+
+
+def g4_summary(out):
+    """The committed summary of a (2,4,F,H,W) prediction: strided sub-sample + per-(b,c) and per-(b,frame) moments."""
+    flat = out.reshape(-1)
+    return dict(sub=flat[::G4_STRIDE].clone(), mean_bc=out.mean(dim=(2, 3, 4)), std_bc=out.std(dim=(2, 3, 4)),
+                absmax_bc=out.abs().amax(dim=(2, 3, 4)), mean_bf=out.mean(dim=(1, 3, 4)), std_bf=out.std(dim=(1, 3, 4)),
+                mean_abs=out.abs().mean())
 
 
 def bank_spatial(case):
     """{reader prefix: (N, C)} in the reference's module order down -> up -> mid."""
-    boc, h = case["block_out_channels"], case["latent"]
-    out = {}
-    for i in range(3):
-        for j in range(2):
-            out[f"down_blocks.{i}.attentions.{j}"] = ((h >> i) ** 2, boc[i])
-    for i in range(1, 4):
-        for j in range(3):
-            out[f"up_blocks.{i}.attentions.{j}"] = ((h >> (3 - i)) ** 2, boc[3 - i])
-    out["mid_block.attentions.0"] = ((h >> 3) ** 2, boc[3])
-    return out
+    from mmgt_amd.synthetic import bank_spatial as _bs
+    return _bs(case["block_out_channels"], case["latent"])
 
 
 def unet_inputs(case, tag="u"):

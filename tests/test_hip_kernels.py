@@ -202,6 +202,35 @@ def test_groupnorm(dt, c0, c1, hw, silu):
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
 
+@pytest.mark.parametrize("c0,c1,hw,eps", [(320, 0, 4096, 1e-5), (640, 320, 1024, 1e-5), (512, 0, 4096, 1e-6), (1280, 0, 64, 1e-6)])
+def test_groupnorm_mean_much_larger_than_std_fp32(c0, c1, hw, eps):
+    """Real SD-1.5 / VAE activations have channels whose |mean| is 30-100x their std: the statistics
+    must not lose the variance to cancellation.  Per-channel means up to +-100 with unit-scale noise, a few whole groups
+    sitting at mean 100 with std 1, eps down to the VAE's 1e-6; fp32 mode at the north-star tolerance."""
+    from mmgt_amd import hip
+    nb, C = 2, c0 + c1
+    mean_c = rnd("gn.mean", (C,), 30.0)
+    mean_c[: C // 32 * 3] = 100.0 + rnd("gn.mean2", (C // 32 * 3,), 0.5)      # three groups: |mean| = 100 std
+    x = rnd("gn.x", (nb, hw, C), 1.7) + mean_c
+    x0, x1 = (x[..., :c0].contiguous(), x[..., c0:].contiguous()) if c1 else (x, None)
+    g = rnd("g", (C,), 0.2) + 1.0
+    b = rnd("b", (C,), 0.2)
+    ref = F.group_norm(x.double().permute(0, 2, 1), 32, g.double(), b.double(), eps).permute(0, 2, 1)
+    out = hip.groupnorm(x0, g, b, 32, eps, silu=False, x1=x1)
+    torch.testing.assert_close(out.double(), ref, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("C", [320, 1280])
+def test_layernorm_mean_much_larger_than_std_fp32(C):
+    from mmgt_amd import hip
+    rows = 517
+    x = rnd("ln.x", (rows, C), 1.0) + 30.0 * rnd("ln.mean", (rows, 1), 3.0)       # row means up to +-90, unit-scale spread
+    g = rnd("g", (C,), 0.2) + 1.0
+    b = rnd("b", (C,), 0.2)
+    ref = F.layer_norm(x.double(), (C,), g.double(), b.double(), 1e-5)
+    torch.testing.assert_close(hip.layernorm(x, g, b).double(), ref, rtol=1e-3, atol=1e-4)
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("C", [320, 640, 768, 1280])
 def test_layernorm(dt, C):
@@ -345,6 +374,17 @@ def test_cfg_ddim_and_window_accumulate():
         ref_cnt[win] += 1
     torch.testing.assert_close(ps, ref_ps)
     torch.testing.assert_close(cnt, ref_cnt)
+    # the window-parallel form: one CFG row at a time, sliced to the C valid channels (Cpad == C), counter bumped once per window
+    ps2, cnt2 = torch.zeros_like(ps), torch.zeros_like(cnt)
+    for wi, win in enumerate([[0, 1, 2, 3], [2, 3, 4, 5], [4, 5, 0, 1]]):
+        pred = rnd(f"pred{wi}", (2 * len(win), hw, hw, 64), 1.0, torch.bfloat16)
+        idx = torch.tensor(win, device=dev(), dtype=torch.int32)
+        rows = pred[..., :C].float().contiguous().view(2, len(win), hw, hw, C)
+        for row in (0, 1):
+            hip.accumulate_window(rows[row].contiguous(), ps2, cnt2, idx, C, rows=1, row0=row, bump_counter=row == 0)
+    assert torch.equal(ps2, ps) and torch.equal(cnt2, cnt)
+    with pytest.raises(RuntimeError, match="CFG rows"):
+        hip.accumulate_window(rows[0].contiguous(), ps2, cnt2, idx, C, rows=1, row0=2)
     g, sa_t, sb_t, sa_p, sb_p = 3.5, 0.6, 0.8, 0.9, math.sqrt(1 - 0.81)
     out = hip.cfg_ddim_step(ps, cnt, lat, g, sa_t, sb_t, sa_p, sb_p)
     eps = ps / cnt[None, None, :, None, None]

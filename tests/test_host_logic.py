@@ -117,6 +117,25 @@ def test_interp_matches_reference_golden(golden_dir):
     torch.testing.assert_close(interp.slerp(i["v0"], i["v0"] * 1.0001, 0.25), torch.from_numpy(g["slerp_parallel"]))
 
 
+def test_interpolate_frames_equals_the_reference_loop():
+    """pipeline_pose2vid_long.py:292-335 restated as its Python loop over pairs and rates vs the batched expression."""
+    from mmgt_amd import interp
+    lat = torch.randn(1, 4, 5, 8, 8, generator=torch.Generator().manual_seed(3))
+    try:
+        for spherical in (False, True):
+            interp.set_tensor_interpolation_method(spherical)
+            fn = interp.get_tensor_interpolation_method()
+            want = []
+            for k in range(4):
+                want.append(lat[:, :, k])
+                want += [fn(lat[:, :, k], lat[:, :, k + 1], r) for r in (1 / 3, 2 / 3)]
+            want.append(lat[:, :, 4])
+            torch.testing.assert_close(interp.interpolate_frames(lat, 3), torch.stack(want, 2))
+        assert interp.interpolate_frames(lat, 1) is lat
+    finally:
+        interp.set_tensor_interpolation_method(False)
+
+
 # ------------------------------------------------------------------------------------------------ C ABI surface
 def test_c_abi_exports_every_declared_symbol():
     from mmgt_amd import hip
@@ -189,21 +208,36 @@ def test_clip_parallel_plumbing_world_size_2():
 
 
 class _FakeWindowUNet:
-    """Test double for the window-parallel host logic only (the HIP UNet has no CPU path): a deterministic, window- and
-    conditioning-dependent function of its inputs."""
+    """Test double for the window-parallel host logic only (the HIP UNet has no CPU path): a deterministic, window-, row-
+    and conditioning-dependent function of its inputs, returned in the operator's REAL layout -- channels-last
+    ((rows * Fw), h, w, 64) with the first 4 channels valid and garbage in the padding (mmgt_amd/unet3d.py denoise_window)."""
     device = torch.device("cpu")
 
     def denoise_window(self, latent_in, t, encoder_hidden_states, audio_embedding, pose_cond_fea, full_mask, face_mask,
-                       body_mask, motion_scale):
-        a = audio_embedding.float().mean(dim=(2, 3)).view(2, 1, -1, 1, 1)
-        return (latent_in * (0.9 - 1e-4 * float(t)) + 0.1 * a + 0.01 * full_mask[0].float().mean()).float()
+                       body_mask, motion_scale, cfg_row=None):
+        rows = latent_in.shape[0]
+        assert rows == (2 if cfg_row is None else 1) and encoder_hidden_states.shape[0] == 2
+        assert audio_embedding.shape[0] == rows and full_mask[0].shape[0] == rows * latent_in.shape[2]
+        a = audio_embedding.float().mean(dim=(2, 3)).view(rows, 1, -1, 1, 1)
+        m = full_mask[0].float().view(rows, latent_in.shape[2], -1).mean(dim=2).view(rows, 1, -1, 1, 1)
+        e = encoder_hidden_states.float().mean(dim=(1, 2))
+        e = (e if cfg_row is None else e[cfg_row:cfg_row + 1]).view(rows, 1, 1, 1, 1)
+        pred = (latent_in * (0.9 - 1e-4 * float(t)) + 0.1 * a + 0.01 * m + 0.05 * e).float()      # (rows, C, Fw, h, w)
+        b, c, f, h, w = pred.shape
+        out = torch.full((b * f, h, w, 64), 1e9)                                                   # padding must never travel
+        out[..., :c] = pred.permute(0, 2, 3, 4, 1).reshape(b * f, h, w, c)
+        return out
 
 
-def _install_cpu_doubles(monkeypatch_target):
-    """CPU restatements of the two elementwise HIP ops the loop calls (pipeline_pose2vid_long.py:621-635), for this test."""
-    def accumulate_window(pred, pred_sum, counter, idx, C):
-        pred_sum[:, :, idx.long()] += pred
-        counter[idx.long()] += 1
+def _install_cpu_doubles(monkeypatch, hip_mod):
+    """CPU restatements of the two elementwise HIP ops the loop calls (pipeline_pose2vid_long.py:621-635), installed through
+    pytest's monkeypatch so that the real bindings are back for every later test of the session."""
+    def accumulate_window(pred, pred_sum, counter, idx, C, rows=2, row0=0, bump_counter=True):
+        fw = idx.numel()
+        p5 = pred[..., :C].reshape(rows, fw, pred.shape[1], pred.shape[2], C).permute(0, 4, 1, 2, 3)
+        pred_sum[row0:row0 + rows, :, idx.long()] += p5
+        if bump_counter:
+            counter[idx.long()] += 1
 
     def cfg_ddim_step(pred_sum, counter, latents, g, sa_t, sb_t, sa_p, sb_p):
         avg = pred_sum / counter.view(1, 1, -1, 1, 1)
@@ -211,53 +245,81 @@ def _install_cpu_doubles(monkeypatch_target):
         x0 = sa_t * latents - sb_t * v
         eps = sa_t * v + sb_t * latents
         return sa_p * x0 + sb_p * eps
-    monkeypatch_target.accumulate_window = accumulate_window
-    monkeypatch_target.cfg_ddim_step = cfg_ddim_step
+    monkeypatch.setattr(hip_mod, "accumulate_window", accumulate_window)
+    monkeypatch.setattr(hip_mod, "cfg_ddim_step", cfg_ddim_step)
 
 
-def _window_parallel_run(window_group):
+def _window_parallel_run(monkeypatch, window_group, L=40, ctx_frames=12, overlap=4, cfg_split="auto"):
     from mmgt_amd import pipeline as PL
-    _install_cpu_doubles(PL.hip)
+    _install_cpu_doubles(monkeypatch, PL.hip)
     sched = DDIMScheduler()
     sched.set_timesteps(4)
     pipe = PL.Pose2VideoPipeline(vae=None, image_encoder=None, reference_unet=None, denoising_unet=_FakeWindowUNet(),
                                  pose_guider=None, scheduler=sched)
     g = torch.Generator().manual_seed(7)
-    L, hw = 40, 4
+    hw = 4
     lat = torch.randn(1, 4, L, hw, hw, generator=g)
     audio = torch.randn(2, L, 3, 5, generator=g)
     masks = [torch.rand(2 * L, hw * hw, generator=g)]
-    return pipe.denoise(lat, sched.timesteps, torch.zeros(2, 1, 8), None, audio, masks, masks, masks, 3.5, None,
-                        context_frames=12, context_stride=1, context_overlap=4, num_inference_steps=4,
-                        window_group=window_group)
+    ehs = torch.cat([torch.zeros(1, 1, 8), torch.randn(1, 1, 8, generator=g)])
+    return pipe.denoise(lat, sched.timesteps, ehs, None, audio, masks, masks, masks, 3.5, None,
+                        context_frames=ctx_frames, context_stride=1, context_overlap=overlap, num_inference_steps=4,
+                        window_group=window_group, cfg_split=cfg_split)
 
 
-def _wp_worker(rank, world, port, q):
+def _wp_worker(rank, world, port, q, kw):
+    import pytest as _pytest
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    mp_ = _pytest.MonkeyPatch()
     try:
-        q.put((rank, _window_parallel_run(True).numpy()))
+        q.put((rank, _window_parallel_run(mp_, True, **kw).numpy()))
     finally:
+        mp_.undo()
         dist.destroy_process_group()
 
 
-def test_window_parallel_denoise_world_size_2_is_bit_identical():
-    """40 frames / context 12 / overlap 4 = 5 windows over 2 ranks (3 rounds, rank 1 idle in the last):
-    both ranks end with the same latents, equal bit for bit to the single-process loop."""
+def _run_window_parallel(world, port_base, **kw):
     import torch.multiprocessing as mp
-    want = _window_parallel_run(None).numpy()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_wp_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = port_base + os.getpid() % 2000
+    procs = [ctx.Process(target=_wp_worker, args=(r, world, port, q, kw)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=180) for _ in procs)
+    res = dict(q.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert np.array_equal(res[0], want) and np.array_equal(res[1], want)
+    return res
+
+
+@pytest.mark.parametrize("world,kw,split", [
+    (2, dict(L=40, ctx_frames=12, overlap=4), False),                       # 5 windows on 2 ranks: rank 1 idle in round 3
+    (3, dict(L=40, ctx_frames=12, overlap=4), False),                       # 5 windows on 3 ranks: one rank idle in round 2
+    (3, dict(L=40, ctx_frames=12, overlap=4, cfg_split=True), True),        # 10 row units on 3 ranks: two idle in round 4
+    (8, dict(L=96, ctx_frames=24, overlap=8, cfg_split=True), True),        # config 5: 6 windows = 12 row units on 8 ranks
+    (4, dict(L=96, ctx_frames=24, overlap=8), None),                        # auto: 12 row units in 3 rounds beat 2 whole rounds
+])
+def test_window_parallel_denoise_matches_single_process(monkeypatch, world, kw, split):
+    """SURVEY 8e config 5 / pipeline_pose2vid_long.py:554-635: every rank ends with the same latents bit for bit, and they
+    equal the single-process loop (bit for bit: the CPU doubles are order-preserving, as the HIP kernels are)."""
+    from mmgt_amd.context import get_context_scheduler
+    nw = len(list(get_context_scheduler("uniform")(0, 4, kw["L"], kw["ctx_frames"], 1, kw["overlap"])))
+    if split is not None:
+        assert (nw * (2 if split else 1)) % world != 0, "the case must leave ranks idle in the last round"
+    want = _window_parallel_run(monkeypatch, None, **{k: v for k, v in kw.items() if k != "cfg_split"}).numpy()
+    res = _run_window_parallel(world, 31500 + 37 * world, **kw)
+    for r in range(world):
+        assert np.array_equal(res[r], want), f"rank {r} diverged"
+
+
+def test_cpu_doubles_do_not_leak():
+    """The doubles above are scoped to their test: the real ctypes bindings are in place afterwards."""
+    from mmgt_amd import hip
+    assert hip.accumulate_window.__module__ == "mmgt_amd.hip" and hip.cfg_ddim_step.__module__ == "mmgt_amd.hip"
 
 
 # ------------------------------------------------------------------------------------------------ conditioning layout

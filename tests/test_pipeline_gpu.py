@@ -77,23 +77,100 @@ def test_pipeline_fp32_matches_oracle(weights, frames, ctx, ov):
     torch.testing.assert_close(out.videos, want, rtol=1e-3, atol=2e-4)
 
 
-def test_pipeline_bf16_runs_and_stays_close(weights):
+def test_pipeline_bf16_within_measured_noise_floor(weights):
+    """bf16 product mode, 4 DDIM steps: final latents against the fp32 oracle, gated at 1.5x the error the SAME oracle makes
+    when its denoiser runs under PyTorch CPU bf16 on the same inputs (measured here, not quoted)."""
     from oracle import pipeline_ref
     sds, sds_cpu = weights
     inp = _inputs(8, 8)
+    kw = dict(clip_image_embeds=inp["clip"], ref_image_latents=inp["ref_lat"], pose_images=inp["pose"],
+              audio_tensor=inp["audio"], full_mask=inp["full"], face_mask=inp["face"], lip_mask=inp["lips"],
+              latents=inp["latents"], num_inference_steps=4, guidance_scale=3.5, motion_scale=[1.0, 1.0, 2.0], decode=False)
     with torch.no_grad():
-        want = pipeline_ref.pose2vid(sds_cpu["unet"], sds_cpu["refnet"], sds_cpu["pose"], sds_cpu["vae"],
-                                     clip_image_embeds=inp["clip"], ref_image_latents=inp["ref_lat"], pose_images=inp["pose"],
-                                     audio_tensor=inp["audio"], full_mask=inp["full"], face_mask=inp["face"],
-                                     lip_mask=inp["lips"], latents=inp["latents"], num_inference_steps=4, guidance_scale=3.5,
-                                     motion_scale=[1.0, 1.0, 2.0], decode=False)
+        want = pipeline_ref.pose2vid(sds_cpu["unet"], sds_cpu["refnet"], sds_cpu["pose"], sds_cpu["vae"], **kw)
+        floor = (pipeline_ref.pose2vid(sds_cpu["unet"], sds_cpu["refnet"], sds_cpu["pose"], sds_cpu["vae"],
+                                       unet_dtype=torch.bfloat16, **kw) - want).abs()
     pipe = _build(sds, torch.bfloat16)
     got = pipe(None, inp["pose"], inp["audio"], inp["full"], inp["face"], inp["lips"], 64, 64, 8, 4, 3.5,
                motion_scale=[1.0, 1.0, 2.0], latents=inp["latents"], clip_image_embeds=inp["clip"],
                ref_image_latents=inp["ref_lat"], decode=False).videos.cpu()
     d = (got - want).abs()
-    print("bf16 pipeline final latents: max|d|", d.max().item(), "mean|d|", d.mean().item(), "mean|x|", want.abs().mean().item())
-    assert torch.isfinite(got).all() and d.mean() < 3e-2 and d.max() < 0.3
+    print(f"bf16 pipeline final latents: HIP max|d| {d.max().item():.3e} mean|d| {d.mean().item():.3e}; CPU-bf16 floor max "
+          f"{floor.max().item():.3e} mean {floor.mean().item():.3e}; mean|x| {want.abs().mean().item():.3f}")
+    assert torch.isfinite(got).all()
+    assert d.max() <= 1.5 * floor.max() and d.mean() <= 1.5 * floor.mean()
+
+
+def test_long_video_96_frames_six_wrapping_windows(weights):
+    """BASELINE config 5 at its real window geometry (L = 96, context 24, overlap 8 => 6 closed-loop windows, the last one
+    wrapping 80..7; context.py:15-42, pipeline_pose2vid_long.py:522-635) at 64x64 px, 2 DDIM steps, fp32 mode against the
+    oracle's latent trajectory.  The same run through the window-parallel branch (1-rank group, CFG rows split: 12 units)
+    must agree with it to fp32 rounding."""
+    import os
+    import torch.distributed as dist
+    from oracle import pipeline_ref
+    from mmgt_amd.context import uniform
+    sds, sds_cpu = weights
+    L = 96
+    wins = list(uniform(0, 2, L, 24, 1, 8))
+    assert len(wins) == 6 and wins[-1][0] == 80 and wins[-1][-1] == 7
+    inp = _inputs(L, 8)
+    traj = []
+    with torch.no_grad():
+        pipeline_ref.pose2vid(sds_cpu["unet"], sds_cpu["refnet"], sds_cpu["pose"], sds_cpu["vae"],
+                              clip_image_embeds=inp["clip"], ref_image_latents=inp["ref_lat"], pose_images=inp["pose"],
+                              audio_tensor=inp["audio"], full_mask=inp["full"], face_mask=inp["face"], lip_mask=inp["lips"],
+                              latents=inp["latents"], num_inference_steps=2, guidance_scale=3.5,
+                              motion_scale=[1.0, 1.0, 2.0], context_frames=24, context_overlap=8, decode=False,
+                              trajectory=traj)
+    pipe = _build(sds, torch.float32)
+    kw = dict(motion_scale=[1.0, 1.0, 2.0], context_frames=24, context_overlap=8, latents=inp["latents"],
+              clip_image_embeds=inp["clip"], ref_image_latents=inp["ref_lat"], decode=False)
+    got = []
+    pipe(None, inp["pose"], inp["audio"], inp["full"], inp["face"], inp["lips"], 64, 64, L, 2, 3.5,
+         callback=lambda i, t, lat: got.append(lat.cpu().clone()), **kw)
+    assert len(got) == 2
+    for a_, b_ in zip(got, traj):
+        torch.testing.assert_close(a_, b_, rtol=1e-3, atol=1e-4)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        par = pipe(None, inp["pose"], inp["audio"], inp["full"], inp["face"], inp["lips"], 64, 64, L, 2, 3.5,
+                   window_group=True, cfg_split=True, **kw).videos.cpu()
+    finally:
+        dist.destroy_process_group()
+    torch.testing.assert_close(par, traj[-1], rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(par, got[-1], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_operator_single_cfg_row_equals_batched_rows(weights, dtype):
+    """denoise_window(cfg_row=r) on one CFG row == row r of the CFG-batched call: the unconditional row never reads the
+    banks, the conditional row reads bank row 1 in every frame (mutual_self_attention.py:150-188)."""
+    from mmgt_amd.unet3d import UNet3DConditionModel
+    from tests import golden_cases as gc
+    sds, _ = weights
+    case = dict(gc.UNET_CASES["full_cfg1"], frames=3)
+    inp = gc.unet_inputs(case)
+    mv = lambda t: t.cuda()
+    m = UNet3DConditionModel(device="cuda:0", dtype=dtype)
+    m.load_state_dict(sds["unet"])
+    m.enable_gradient_checkpointing()
+    m.set_banks({k: mv(v) for k, v in inp["banks"].items()})
+    f = case["frames"]
+    both = m.denoise_window(mv(inp["sample"]), 499, mv(inp["ehs"]), mv(inp["audio"]), mv(inp["pose"]),
+                            [mv(x) for x in inp["full"]], [mv(x) for x in inp["face"]], [mv(x) for x in inp["lips"]],
+                            inp["motion_scale"])[..., :4].float()
+    for row in (0, 1):
+        cut = lambda L: [mv(x).view(2, f, -1)[row].contiguous() for x in L]
+        one = m.denoise_window(mv(inp["sample"][row:row + 1]), 499, mv(inp["ehs"]), mv(inp["audio"][row:row + 1]),
+                               mv(inp["pose"][row:row + 1]), cut(inp["full"]), cut(inp["face"]), cut(inp["lips"]),
+                               inp["motion_scale"], cfg_row=row)[..., :4].float()
+        # same arithmetic per row; the GEMM tile choice may differ with M, which only reorders nothing today (bit-equal), but
+        # the gate allows a couple of bf16 ulps so that a future tile with another MFMA shape stays legal
+        tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=2e-3)
+        torch.testing.assert_close(one, both[row * f:(row + 1) * f], **tol)
 
 
 def test_window_parallel_group_path_equals_serial_loop(weights):

@@ -1,10 +1,16 @@
 """The HIP denoise-step operator (mmgt_amd.UNet3DConditionModel, through the C ABI) against the oracle on identical
 weights, latents and conditioning.
 
-  * fp32-I/O mode: rtol 1e-3 / atol 1e-4 (the north-star tolerance) at BASELINE config-1 geometry, full width.
-  * bf16 mode: gated against the bf16 noise floor of this 1.4 B-parameter network (PyTorch's own CPU bf16 path differs
-    from fp32 by max|d| 1.0e-2 on outputs of mean|x| 0.29): max|d| <= 6e-2, mean|d| <= 8e-3.
+  * fp32-I/O mode: rtol 1e-3 / atol 1e-4 (the north-star tolerance) at BASELINE config-1 geometry, full width, and at the
+    benchmarked BASELINE config-2 shape (512x512x24) against the REFERENCE's own output (G4 golden).
+  * bf16 mode: no bf16 implementation of this 1.4 B-parameter network meets 1e-3 / 1e-4 against an fp32 reference, so it is
+    gated against the MEASURED bf16 noise floor: the oracle run under PyTorch CPU bf16 on the same inputs (inside the test
+    at config-1 size; at 512x512 the floor is the committed tools/gen_bf16_floor.py measurement at the full shape).  The HIP
+    bf16 max|d| and mean|d| must stay within 1.5x that floor.
 """
+import os
+
+import numpy as np
 import pytest
 import torch
 
@@ -48,13 +54,25 @@ def _run_hip(sd_gpu, case, dtype, weighted=True):
     return out.float().cpu()
 
 
-def _run_oracle(sd_cpu, case, weighted=True):
+def _run_oracle(sd_cpu, case, weighted=True, dtype=torch.float32):
+    """dtype=bfloat16: every weight and activation of the oracle in bf16 (PyTorch CPU kernels) = the measured noise floor."""
     cfg = R.UNet3DConfig()
     inp = gc.unet_inputs(case)
+    c = (lambda t: t.to(dtype) if torch.is_tensor(t) and t.is_floating_point() else t) if dtype != torch.float32 else (lambda t: t)
+    cl = lambda L: [c(x) for x in L]
+    sd = sd_cpu if dtype == torch.float32 else {k: c(v) for k, v in sd_cpu.items()}
     with torch.no_grad():
-        return R.unet3d_forward(sd_cpu, cfg, inp["sample"], inp["timestep"], inp["ehs"], inp["audio"], inp["pose"],
-                                inp["full"], inp["face"], inp["lips"], inp["motion_scale"], inp["banks"],
-                                weighted=weighted)
+        return R.unet3d_forward(sd, cfg, c(inp["sample"]), inp["timestep"], c(inp["ehs"]), c(inp["audio"]), c(inp["pose"]),
+                                cl(inp["full"]), cl(inp["face"]), cl(inp["lips"]), inp["motion_scale"],
+                                {k: c(v) for k, v in inp["banks"].items()}, weighted=weighted).float()
+
+
+FLOOR_SLACK = 1.5      # HIP bf16 error <= 1.5 x the measured CPU-bf16 error of the same oracle on the same inputs
+
+
+def _floor_cfg2(golden_dir):
+    f = np.load(os.path.join(golden_dir, "unet3d_full_cfg2_bf16floor.npz"))
+    return float(f["max_abs"]), float(f["mean_abs"])
 
 
 def test_unet_fp32_mode_matches_oracle_config1(full_sd):
@@ -84,15 +102,17 @@ def test_unet_matches_reference_golden_config1(full_sd, golden_dir):
     torch.testing.assert_close(out, g, rtol=1e-3, atol=1e-4)
 
 
-def test_unet_bf16_mode_within_noise_floor(full_sd):
+def test_unet_bf16_mode_within_measured_noise_floor(full_sd):
     sd_gpu, sd_cpu = full_sd
     case = gc.UNET_CASES["full_cfg1"]
     ref = _run_oracle(sd_cpu, case)
+    floor = (_run_oracle(sd_cpu, case, dtype=torch.bfloat16) - ref).abs()
     out = _run_hip(sd_gpu, case, torch.bfloat16)
     d = (out - ref).abs()
-    print("bf16 mode: max|d|", d.max().item(), "mean|d|", d.mean().item(), "mean|x|", ref.abs().mean().item())
+    print(f"bf16 mode: HIP max|d| {d.max().item():.3e} mean|d| {d.mean().item():.3e}; CPU-bf16 floor max {floor.max().item():.3e} "
+          f"mean {floor.mean().item():.3e}; mean|x| {ref.abs().mean().item():.3f}")
     assert torch.isfinite(out).all()
-    assert d.max() <= 6e-2 and d.mean() <= 8e-3
+    assert d.max() <= FLOOR_SLACK * floor.max() and d.mean() <= FLOOR_SLACK * floor.mean()
 
 
 def test_unet_wider_geometry_fp32(full_sd):
@@ -104,7 +124,7 @@ def test_unet_wider_geometry_fp32(full_sd):
     torch.testing.assert_close(out, ref, rtol=1e-3, atol=1e-4)
 
 
-def test_unet_full_resolution_512x512_six_frames(full_sd):
+def test_unet_full_resolution_512x512_six_frames(full_sd, golden_dir):
     """BASELINE config-2 spatial size (512x512 px = 64x64 latent, 4096 tokens and 4096 bank keys at level 0) on 6 frames:
     the shapes at which the production tile configurations are chosen (128x320 conv tile from 49152 output rows, 256x128
     for the GEGLU / long-K GEMMs, 64-key attention tiles without ragged-tail code).  fp32-I/O mode against the CPU oracle
@@ -118,6 +138,34 @@ def test_unet_full_resolution_512x512_six_frames(full_sd):
     torch.testing.assert_close(out, ref, rtol=1e-3, atol=1e-4)
     out16 = _run_hip(sd_gpu, case, torch.bfloat16)
     d16 = (out16 - ref).abs()
-    print("512x512x6 bf16 mode: max|d|", d16.max().item(), "mean|d|", d16.mean().item())
+    fmax, fmean = _floor_cfg2(golden_dir)       # CPU-bf16 floor of the oracle at 512x512 (24 frames: tools/gen_bf16_floor.py)
+    print(f"512x512x6 bf16 mode: max|d| {d16.max().item():.3e} mean|d| {d16.mean().item():.3e} (floor {fmax:.3e} / {fmean:.3e})")
     assert torch.isfinite(out16).all()
-    assert d16.max() <= 8e-2 and d16.mean() <= 8e-3
+    assert d16.max() <= FLOOR_SLACK * fmax and d16.mean() <= FLOOR_SLACK * fmean
+
+
+def test_unet_benchmarked_shape_512x512x24_matches_reference_golden(full_sd, golden_dir):
+    """G4: BASELINE config 2 = exactly what bench.py times -- latent (2,4,24,64,64), M = 196608 token rows at
+    level 0, the tile choices that only trigger at 24 frames.  The fixture is a strided sub-sample + moments of the
+    REFERENCE's own fp32 output (tools/refgen/gen_golden.py --only full_cfg2: 233 s of the reference's UNet3DConditionModel
+    on the build container's CPU); the oracle agrees with that full tensor to max|d| 4.5e-6.
+    fp32-I/O mode at the north-star tolerance; bf16 product mode within 1.5x the CPU-bf16 floor measured at this shape."""
+    sd_gpu, _ = full_sd
+    case = gc.UNET_CASES["full_cfg2"]
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, "unet3d_full_cfg2.npz")).items()}
+    out = _run_hip(sd_gpu, case, torch.float32)
+    assert out.shape == (2, 4, 24, 64, 64)
+    got = gc.g4_summary(out)
+    d = (got["sub"] - g["sub"]).abs()
+    print(f"512x512x24 fp32 mode vs reference golden: max|d| {d.max().item():.3e} over {d.numel()} samples")
+    torch.testing.assert_close(got["sub"], g["sub"], rtol=1e-3, atol=1e-4)
+    for k in ("mean_bc", "std_bc", "absmax_bc", "mean_bf", "std_bf", "mean_abs"):
+        torch.testing.assert_close(got[k], g[k], rtol=1e-3, atol=1e-4)
+    del out
+    out16 = _run_hip(sd_gpu, case, torch.bfloat16)
+    d16 = (gc.g4_summary(out16)["sub"] - g["sub"]).abs()
+    fmax, fmean = _floor_cfg2(golden_dir)
+    print(f"512x512x24 bf16 mode vs reference golden: max|d| {d16.max().item():.3e} mean|d| {d16.mean().item():.3e} "
+          f"(CPU-bf16 floor {fmax:.3e} / {fmean:.3e})")
+    assert torch.isfinite(out16).all()
+    assert d16.max() <= FLOOR_SLACK * fmax and d16.mean() <= FLOOR_SLACK * fmean

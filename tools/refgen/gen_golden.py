@@ -60,7 +60,7 @@ def gen_unet(case_name):
             key = name.replace(".transformer_blocks.0", "")
             mod.bank = [inp["banks"][key].to(torch.float16)]          # what update(writer) stores: mutual_self_attention.py:340
     outs = {}
-    for mode in ("script", "eval"):
+    for mode in (("script",) if case_name == "full_cfg2" else ("script", "eval")):
         if mode == "script":                                          # scripts/pose2vid.py:151-156,183-184
             m.train()
             m.enable_gradient_checkpointing()
@@ -72,6 +72,11 @@ def gen_unet(case_name):
                            face_mask=inp["face"], body_mask=inp["lips"], motion_scale=inp["motion_scale"],
                            return_dict=False)[0]
     print(case_name, "ref forward done in", round(time.time() - t0, 1), "s; mean|x|", outs["script"].abs().mean().item())
+    if case_name == "full_cfg2":       # G4: the full tensor is 3 MB; commit the strided sub-sample + moments only
+        full_path = os.environ.get("MMGT_G4_FULL")          # optional scratch copy (never committed) for oracle cross-checks
+        if full_path:
+            np.save(full_path, outs["script"].numpy())
+        outs = gc.g4_summary(outs["script"])
     save("unet3d_" + case_name, **outs)
 
 
@@ -204,9 +209,12 @@ if __name__ == "__main__":
     torch.set_grad_enabled(True)
     steps = {"context": gen_context, "interp": gen_interp, "side": gen_side_models, "blocks": gen_blocks,
              "refnet_tiny": lambda: gen_refnet("tiny"), "refnet_full": lambda: gen_refnet("full"),
-             "tiny": lambda: gen_unet("tiny"), "full": lambda: gen_unet("full_cfg1")}
+             "tiny": lambda: gen_unet("tiny"), "full": lambda: gen_unet("full_cfg1"),
+             "full_cfg2": lambda: gen_unet("full_cfg2")}
     for k, fn in steps.items():
         if a.only and k != a.only:
+            continue
+        if k == "full_cfg2" and a.only != k:        # minutes of CPU and ~15 GB: only on request
             continue
         if k == "full" and a.skip_full:
             continue
