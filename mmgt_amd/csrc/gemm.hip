@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gemm_common.h"
 #include "mmgt_hip.h"
 
 // Main-loop variant (A/B-able by building a second library with -DMMGT_GEMM_VARIANT=n, tools/ab_gemm.py):
@@ -44,48 +45,6 @@ constexpr bool V_ILV = (MMGT_GEMM_VARIANT & 2) != 0;
 constexpr bool V_LATE = (MMGT_GEMM_VARIANT & 4) != 0;
 constexpr bool V_LATE_ALL = (MMGT_GEMM_VARIANT & 8) != 0;
 constexpr bool V_NODMA = (MMGT_GEMM_VARIANT & 16) != 0;   // timing diagnostic only (wrong results): no LDS-DMA after the ring fill
-
-struct ADesc {
-  const char* src0;
-  const char* src1;
-  long ld0;           // dense: row stride (elements)
-  long bs0, bs1;      // batch (grid.z) stride in elements
-  int C0, C1;         // conv: channels of the two sources (Cin = C0 + C1)
-  int IH, IW, OH, OW; // conv: stored input dims and output dims
-  int stride, up;     // conv: stride; up = 1 -> the conv sees the nearest-2x upsampled input
-  int pad;            // conv: zero rows / columns in front (1; 0 for the VAE encoder's (0, 1) padded downsample)
-};
-
-struct Epi {
-  const float* bias;       // [N]
-  const float* bias2;      // [ceil(M / bias2_rows)][N]   (time-embedding add: one row per CFG batch entry)
-  const float* row_scale;  // [M]                         (motion-mask multiply)
-  const float* bias_post;  // [N]  added AFTER the row scale / alpha (the zero-conv bias of a merged out-proj . zero-conv)
-  const char* residual;    // T [M][ldr]
-  char* out;               // T [M][ldo]
-  long ldr, ldo, bsr, bso; // strides in elements; bs* = grid.z strides
-  int bias2_rows;
-  float alpha;
-  int act;                 // 0 none, 1 GEGLU (packed weights, out has N/2 columns), 2 SiLU, 3 ReLU, 4 quick-GELU
-  int fast;                // 1: N % 8 == 0 and every row / pointer 16-byte aligned -> vectorised epilogue
-};
-
-// LDS-DMA through a buffer resource (buffer_load_dwordx4 ... offen lds): SGPR descriptor + one 32-bit VGPR offset per lane
-// + an SGPR offset for the position along K, instead of a 64-bit VGPR address per lane -- half the address registers, no
-// per-chunk vector address arithmetic, and out-of-range offsets READ AS ZERO, which is the conv's zero padding.
-// Operands are described as raw buffers of 2 GiB (the host checks the sizes); POISON is any offset beyond that.
-constexpr unsigned DMA_RANGE = 0x80000000u, DMA_POISON = 0xC0000000u;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t dma_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)DMA_RANGE, 0x00020000);
-}
-__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, void* lds_dst) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_dst, 16, (int)voff, soff, 0, 0);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // Transpose of 16-byte elements between the S (4 or 2) lanes r = lane & (S - 1) of a DPP quad and a lane's S registers:
 // afterwards x[s] of lane r holds what x[r] of lane s held (an involution).  Butterfly of quad_perm moves: per exchanged
@@ -769,7 +728,13 @@ int launch_cfg(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, i
   return 0;
 }
 
-int g_gemm_cfg = 0;   // 0 = heuristic; 1, 3, 6, 9, 12 force a tile configuration (mmgt_tune("gemm_cfg", v), benchmarking only)
+int g_gemm_cfg = 0;   // 0 = heuristic; 1, 3, 6, 9, 12, 16 force a tile configuration (mmgt_tune("gemm_cfg", v), benchmarking only)
+
+}  // namespace
+// gemm16.hip: the bf16 256x256 8-phase core on 16x16x32 MFMAs (cfg 16)
+int mmgt_gemm16_launch(int mode, const void* ad, const void* W, long bsw, const void* ep, int M, int N, int K, int batch,
+                       void* stream);
+namespace {
 
 template <typename T, int MODE>
 int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
@@ -800,6 +765,11 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     else cfg = 1;
   }
   if (geglu && (cfg == 3 || cfg == 12)) cfg = 1;   // GEGLU pairs need 64-column wave tiles
+  if (cfg == 16) {   // bf16, plain vectorised epilogue only; anything else falls back to the 32x32x16 tiles
+    if (std::is_same<T, bf16_t>::value && ep.fast && ep.act <= 1 && !ep.row_scale && ep.alpha == 1.f && !ep.bias_post)
+      return mmgt_gemm16_launch(MODE, &ad, W, bsw, &ep, M, N, K, batch, s);
+    cfg = 9;
+  }
   // anything beyond bias / per-batch bias / GEGLU / residual on the vectorised path runs the FULL instantiation (128x128 tile)
   if (!ep.fast || ep.act >= 2) return launch_cfg<T, MODE, 128, 128, 2, 2, 2, 128, 2>(ad, W, bsw, ep, M, N, K, batch, s);
   if (ep.row_scale || ep.alpha != 1.f || ep.bias_post) {

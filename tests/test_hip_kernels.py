@@ -110,7 +110,7 @@ def test_gemm_batched_vt(dt):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("cfg", [1, 3, 6, 9, 12])
+@pytest.mark.parametrize("cfg", [1, 3, 6, 9, 12, 16])
 def test_gemm_and_conv_forced_tile_configs(dt, cfg):
     """Every tile configuration the heuristic can pick (128x128, 128x64, 256x128, 256x256 with 64-byte LDS rows, and the
     320-column tiles with the barrier inside the chunk) against fp64 torch math, incl. ragged M/N, two bias2 rows per
@@ -146,6 +146,44 @@ def test_gemm_and_conv_forced_tile_configs(dt, cfg):
 
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
+
+
+def test_gemm16_core_exact_integers_and_geglu():
+    """The 16x16x32 8-phase core (cfg 16, bf16 only): (a) exact small-integer operands with an ASYMMETRIC weight matrix --
+    any row/column or k-order mix-up in the fragment maps, the permlane16 epilogue or the swizzle shows as a wrong integer;
+    (b) GEGLU with packed weights, (c) ragged M / N edges and several tiles per persistent workgroup, (d) bias2 + residual."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_geglu
+    dt = torch.bfloat16
+    try:
+        hip.tune("gemm_cfg", 16)
+        for M, N, K in [(256, 256, 64), (300, 264, 128), (2000, 1288, 320)]:
+            a = torch.randint(-3, 4, (M, K), device=dev()).to(dt)
+            w = torch.randint(-2, 3, (N, K), device=dev()).to(dt)
+            w[:, 0] = (torch.arange(N, device=dev()) % 5 - 2).to(dt)               # column- and row-dependent pattern
+            a[:, 1] = (torch.arange(M, device=dev()) % 7 - 3).to(dt)
+            out = hip.gemm(a, w)
+            ref = a.double() @ w.double().t()
+            assert ref.abs().max() < 256                                            # exactly representable in bf16
+            assert torch.equal(out.double(), ref), (M, N, K, (out.double() - ref).abs().max().item())
+        M, C = 777, 320
+        x = rnd("g16.x", (M, C), 1.0, dt)
+        w1 = rnd("g16.w1", (8 * C, C), 1.0 / math.sqrt(C), dt)
+        b1 = rnd("g16.b1", (8 * C,), 0.3)
+        wp, bp = pack_geglu(w1.float().cpu(), b1.cpu())
+        out = hip.gemm(x, wp.to(dev()).to(dt), bp.to(dev()), act=hip.ACT_GEGLU)
+        y = x.double() @ w1.double().t() + b1.double()
+        h, g = y.chunk(2, dim=-1)
+        torch.testing.assert_close(out.double(), h * F.gelu(g), **tol(dt))
+        M, N, K = 5000, 1280, 640
+        a, w = rnd("g16.a", (M, K), 1.0, dt), rnd("g16.w", (N, K), 1.0 / math.sqrt(K), dt)
+        bias, res = rnd("g16.b", (N,), 0.5), rnd("g16.r", (M, N), 1.0, dt)
+        b2 = rnd("g16.b2", ((M + 2047) // 2048, N), 0.5)
+        out = hip.gemm(a, w, bias, residual=res, bias2=b2, bias2_rows=2048)
+        ref = ref_gemm(a, w) + bias.double() + b2.double().repeat_interleave(2048, 0)[:M] + res.double()
+        torch.testing.assert_close(out.double(), ref, **tol(dt))
+    finally:
+        hip.tune("gemm_cfg", 0)
 
 
 @pytest.mark.parametrize("dt", DT)
