@@ -732,8 +732,8 @@ int g_gemm_cfg = 0;   // 0 = heuristic; 1, 3, 6, 9, 12, 16 force a tile configur
 
 }  // namespace
 // gemm16.hip: the bf16 256x256 8-phase core on 16x16x32 MFMAs (cfg 16)
-int mmgt_gemm16_launch(int mode, const void* ad, const void* W, long bsw, const void* ep, int M, int N, int K, int batch,
-                       void* stream);
+int mmgt_gemm16_launch(int mode, int bn, const void* ad, const void* W, long bsw, const void* ep, int M, int N, int K,
+                       int batch, void* stream);
 namespace {
 
 template <typename T, int MODE>
@@ -758,17 +758,29 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     // the grid still covers the chip -- with the slim common epilogue it no longer spills: GEGLU ff1 -11..-13%, q/k/v
     // projections of the motion modules -13%, the N = 1280 family -5..-10%.
     const bool sq_ok = ((N + 255) / 256) * 256l * 100 <= (long)N * 107 && tiles256sq >= 192;
-    if (MODE == 1) cfg = (N % 320 == 0 && M >= 49152) ? 12 : big_ok ? 9 : tiles128 < 512 ? 3 : 1;
-    else if (sq_ok) cfg = 9;
+    // cfg 16 (gemm16.hip: 256x256, 16x16x32 MFMAs, two wave groups in ping-pong; bf16 only) replaces cfg 9 wherever that ran and
+    // takes the convs whose width fills 256-column tiles: measured (tools/ab_cfg.py, one process) -17..-19% on the 16x16-level
+    // convs and the 16 -> 32 up-conv, -7..-10% on the long-K / wide dense shapes, -7% on the 32 -> 64 up-conv (N = 640: three
+    // tiles with 17% padding still beat the 128x320 tile); it loses on K = 320 GEGLU (epilogue-bound) and on N = 320 / 640.
+    // cfg 17 = the same core with a 256x320 tile (every width of the UNet is a multiple of 320): the L0 / L1 convs and the
+    // 32 -> 64 / 16 -> 32 up-convs (-2..-22%), and the dense N = 320 / 640 / 960 shapes of the 64x64 level (-6..-27%).
+    const bool b16 = std::is_same<T, bf16_t>::value;
+    if (MODE == 1) {
+      if (b16 && N % 320 == 0 && M >= 49152) cfg = 17;
+      else if (b16 && N % 256 == 0 && tiles256sq >= 192) cfg = 16;
+      else cfg = (N % 320 == 0 && M >= 49152) ? 12 : big_ok ? 9 : tiles128 < 512 ? 3 : 1;
+    } else if (b16 && !geglu && N % 320 == 0 && N <= 960 && M >= 131072) cfg = 17;
+    else if (sq_ok) cfg = (b16 && !(geglu && K < 640)) ? 16 : 9;
     else if (geglu || K >= 1280) cfg = tiles256 >= 256 ? 6 : 1;
     else if (M >= 131072 && N >= 640) cfg = 6;
     else cfg = 1;
   }
   if (geglu && (cfg == 3 || cfg == 12)) cfg = 1;   // GEGLU pairs need 64-column wave tiles
-  if (cfg == 16) {   // bf16, plain vectorised epilogue only; anything else falls back to the 32x32x16 tiles
-    if (std::is_same<T, bf16_t>::value && ep.fast && ep.act <= 1 && !ep.row_scale && ep.alpha == 1.f && !ep.bias_post)
-      return mmgt_gemm16_launch(MODE, &ad, W, bsw, &ep, M, N, K, batch, s);
-    cfg = 9;
+  if (cfg == 16 || cfg == 17) {   // gemm16.hip, 256 / 320 columns: bf16, plain vectorised epilogue only (GEGLU: 256); else fall back
+    if (std::is_same<T, bf16_t>::value && ep.fast && ep.act <= (cfg == 16 ? 1 : 0) && !ep.row_scale && ep.alpha == 1.f &&
+        !ep.bias_post)
+      return mmgt_gemm16_launch(MODE, cfg == 16 ? 256 : 320, &ad, W, bsw, &ep, M, N, K, batch, s);
+    cfg = cfg == 16 ? 9 : geglu ? 1 : 12;   // (GEGLU pairs need 64-column wave tiles: not the 320-column tile)
   }
   // anything beyond bias / per-batch bias / GEGLU / residual on the vectorised path runs the FULL instantiation (128x128 tile)
   if (!ep.fast || ep.act >= 2) return launch_cfg<T, MODE, 128, 128, 2, 2, 2, 128, 2>(ad, W, bsw, ep, M, N, K, batch, s);
@@ -898,6 +910,8 @@ extern "C" int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1,
   ADesc ad{};
   ad.src0 = (const char*)x0; ad.src1 = (const char*)x1; ad.C0 = C0; ad.C1 = C1; ad.IH = IH; ad.IW = IW; ad.OH = OH;
   ad.OW = OW; ad.stride = stride; ad.up = upsample; ad.pad = pad_lo;
+  make_fastdiv((unsigned)(OH * OW), ad.fd_hw);
+  make_fastdiv((unsigned)OW, ad.fd_ow);
   Epi ep{};
   ep.bias = bias; ep.bias2 = bias2; ep.bias2_rows = bias2_rows; ep.alpha = 1.f; ep.residual = (const char*)residual;
   ep.ldr = Cout; ep.out = (char*)out; ep.ldo = Cout; ep.act = act;

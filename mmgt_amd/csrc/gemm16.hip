@@ -1,4 +1,5 @@
-// bf16 GEMM / implicit-GEMM conv3x3 core on 16x16x32 MFMAs: 256 x 256 tile, 8 waves, two wave groups in ping-pong (gfx950).
+// bf16 GEMM / implicit-GEMM conv3x3 core on 16x16x32 MFMAs: 256 x 256 or 256 x 320 tile, 8 waves, two wave groups in
+// ping-pong (gfx950).
 //
 //   out[M, N] = epilogue( A[M, K] * W[N, K]^T )      same operands, LDS image and epilogue semantics as gemm.hip
 //
@@ -6,24 +7,28 @@
 // its fragment reads in front of its own MFMAs, so the matrix pipe idles through every chunk's load phase (PMC, round 1:
 // matrix pipe 55 % busy, 40 % of wave cycles stalled at instruction issue; 1.12 PFLOP/s at 8192^3).  Here the two waves
 // that share a SIMD (wave w of rows 0..127 and wave w + 4 of rows 128..255) are kept ONE BARRIER APART for the whole
-// kernel: a K chunk of 64 is worked in four phases {load part | s_barrier | 16 MFMAs | s_barrier}, and while one group
-// multiplies, its SIMD partners run their load part (fragment reads of the next C quadrant, a slice of the next chunk's
-// LDS-DMA).  The 16x16x32 MFMA shape holds a higher clock than 32x32x16 at equal cycles per FLOP
-// (MI355X_MICROARCH.md, DVFS give-back item 7) and gives 4-register accumulator tiles whose epilogue needs one
-// v_permlane16_swap per register to turn two tiles into 16-byte row vectors.
+// kernel: a K chunk of 64 is worked in NPH = BN / 64 phases {load part | s_barrier | 16 MFMAs | s_barrier}, and while one
+// group multiplies, its SIMD partners run their load part (fragment reads, two LDS-DMA pieces of the chunks ahead).  The
+// 16x16x32 MFMA shape holds a higher clock than 32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back
+// item 7) and gives 4-register accumulator tiles whose epilogue needs one v_permlane16_swap per register to turn two tiles
+// into 16-byte row vectors.  8192^3: 1.38 PFLOP/s against 1.12 (random data, one process, tools/ab_cfg.py).
 //
-// Per wave: output 128 x 64 = 8 x 4 accumulator tiles (128 registers); per chunk and phase p one C quadrant of 64 x 32:
-//   p0: read B0 (4 x ds_read_b128), A0 (8)   -> rows  0..63  x cols  0..31        DMA pieces [0, 2) of the next chunk
-//   p1: read B1 (4)                          -> rows  0..63  x cols 32..63        DMA pieces [2, 5)
-//   p2: read A1 (8)                          -> rows 64..127 x cols 32..63        DMA pieces [5, 8)
-//   p3: (nothing to read: A1, B0 are live)   -> rows 64..127 x cols  0..31        s_waitcnt vmcnt(0): next chunk landed
-// LDS: 2 stages x (256 + 256 rows) x 128 B = 128 KiB; rows are 128 B, the 16-byte chunk index is XOR-swizzled by
+// Per wave (grid 4 x 2): output 64 x BN/2 = 4 x NT accumulator tiles (NT = BN / 32: 128 or 160 registers).  Phase p of a
+// chunk multiplies the wave's four A row tiles (read once per chunk, in phase 0: 8 x ds_read_b128) with W column tiles
+// 2p, 2p + 1 (4 x ds_read_b128 per phase): 16 MFMAs.  BN = 320 fits every width of the UNet (320 k) without padding.
+// LDS: 2 stages x (256 + BN rows) x 128 B = 128 / 144 KiB; rows are 128 B, the 16-byte chunk index is XOR-swizzled by
 // (row >> 1) & 7 on the per-lane DMA SOURCE offset and on the read (conflict-free for this fragment shape too: the sixteen
 // lanes of a ds_read_b128 group cover rows r..r+3, r+12..r+15 of one chunk column and rows r+4..r+11 of the next).
-// Hazards: a stage is refilled in phases 0-2 of the chunk AFTER the one that read it last (its last reads, phase 2, are
-// retired by an lgkmcnt(0) in front of that phase's barrier, three barriers earlier for either group); the refill is
-// waited for (vmcnt) in phase 3's load part by every issuing wave, in front of a barrier both groups pass before their
-// first read of it.
+// LDS-DMA (1-KiB pieces, 4 x A + NW x W per wave and chunk, NW = BN / 64): the A half of a stage is read in phase 0 only,
+// the W half in every phase, so the W pieces of chunk c + 1 (other stage, idle since chunk c - 1) go out first and the
+// A pieces of chunk c + 2 follow into the stage chunk c is still multiplying from: piece s of the sequence
+// [W 0 .. W NW-1 | A 0 .. A 3] is issued in phase s / 2.  The last phase waits s_waitcnt vmcnt(4): chunk c + 1 has landed,
+// the four A pieces of chunk c + 2 stay in flight (two to three half-tiles ahead of the MFMAs).
+// Hazards.  WAR: every load part ends in s_waitcnt lgkmcnt(0) in front of its barrier, so a region's reads are retired when
+// the barrier releases; group 1 runs one barrier behind group 0; the first A piece into a stage is issued in phase 2 (four
+// barriers after group 0's phase-0 reads, three after group 1's), the first W piece in phase 0 of the next chunk (two / one
+// barriers after the groups' last-phase reads).  RAW: chunk c + 1 is waited for (counted vmcnt) in the last phase's load part
+// by every issuing wave, in front of a barrier both groups pass before their first read of that chunk.
 #include <type_traits>
 
 #include "common.h"
@@ -38,27 +43,24 @@ __device__ __forceinline__ acc4 mma16(s16x8 a, s16x8 b, acc4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-// GLDS_SPLIT: how the 8 LDS-DMA pieces (4 x A, 4 x B, 1 KiB per wave each) of the next chunk are dealt to phases 0..2.
-#ifndef MMGT_G16_SPLIT
-#define MMGT_G16_SPLIT 0
-#endif
-
-template <int MODE>
+template <int MODE, int BN>
 __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __restrict__ W, long bsw, Epi ep, int M, int N,
                                                         int K, int tiles_m, int tiles_n) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   typedef bf16_t T;
-  constexpr int ESZ = 2, BM = 256, BN = 256, ROWB = 128, BK = 64, NW = 8, NSTAGE = 2;
+  static_assert(BN == 256 || BN == 320, "BN");
+  constexpr int ESZ = 2, BM = 256, ROWB = 128, BK = 64, NW = 8;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int CPR = 8, RPD = 8;               // 16-byte chunks per row; rows per 1-KiB DMA piece
-  constexpr int GA = BM / RPD / NW, GB = BN / RPD / NW;   // pieces per wave: 4 + 4
-  constexpr int P0 = MMGT_G16_SPLIT == 1 ? 4 : 2, P1 = MMGT_G16_SPLIT == 1 ? 8 : 5;   // piece ranges [0,P0) [P0,P1) [P1,8)
+  constexpr int GA = BM / RPD / NW, GB = BN / RPD / NW;   // pieces per wave and chunk: 4 x A + 4 or 5 x W
+  constexpr int NPH = BN / 64, NT = BN / 32;    // phases per chunk; accumulator tiles per row tile
   auto swz = [](int row) { return (row >> 1) & 7; };
 
   const int nwg = tiles_m * tiles_n;
   const int bz = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wid >> 2, wc = wid & 3;        // wave group (M half) and N quarter
+  const int wr = wid >> 2;                      // wave group: waves 0-3 / 4-7 (SIMD partners w, w + 4 are in different groups)
+  const int wm = wid >> 1, wn = wid & 1;        // 4 x 2 wave grid: 64 rows x BN / 2 columns per wave
   const int lm = lane & 15, lq = lane >> 4;
 
   auto decode = [&](int v, int& tm, int& tn) {  // XCD-aware virtual tile order (see gemm.hip)
@@ -73,45 +75,42 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
   const T* a0 = reinterpret_cast<const T*>(ad.src0) + (long)bz * ad.bs0;
   const T* a1 = ad.src1 ? reinterpret_cast<const T*>(ad.src1) + (long)bz * ad.bs1 : nullptr;
   const T* wbase = reinterpret_cast<const T*>(W) + (long)bz * bsw;
+  // The pieces of a wave are 8 rows apart, which goes into the SCALAR offset of the DMA, so the per-lane state of a stream
+  // is one offset per piece parity (the swizzled 16-byte chunk of piece i is c0 ^ 4 ((wid G + i) & 1): row = 8 (wid G + i) +
+  // srow, so (row >> 1) & 7 = (4 (wid G + i) + (srow >> 1)) & 7 with srow >> 1 in 0..3) plus the number of valid rows from the lane's first row:
+  // pieces beyond M / N get the poison offset in their VECTOR offset (the part the hardware range-checks) and read as zeros.
   const __amdgpu_buffer_rsrc_t rA0 = dma_rsrc(a0), rA1 = dma_rsrc(a1 ? a1 : a0), rW = dma_rsrc(wbase);
-  unsigned aoff[GA];
-  // conv: per piece the image's first pixel index and the output pixel (y << 16 | x); the swizzled chunk of piece i is
-  // (c0 ^ 4 (i & 1)): row = 32 wid + 8 i + srow, so (row >> 1) & 7 = (4 i + (srow >> 1)) & 7 with srow >> 1 in 0..3
-  unsigned cbase[GA], cyx[GA];
   const int c0sw = spos ^ (srow >> 1);
-  unsigned woff[GB];
+  int limA = 0, limW = 0;
+  unsigned aoff[MODE == 0 ? 2 : GA];   // dense: [piece parity]; conv: the current tap's pixel of every piece (zero padding = poison)
+  unsigned woff[2];
+  unsigned am0 = 0;                    // conv: output row of piece 0 (piece i: + 8 i)
+  int a_step = 0, w_step = 0;          // scalar byte distance between consecutive pieces (dense A rows / W rows, 8 apart)
   int p_tap = 0, p_c = 0, a_soff = 0;
   bool a_second = false;
-  auto setup = [&](int tm, int tn) {
+  // The A and the W stream run at different distances ahead of the MFMAs (see the schedule above), so each keeps its own
+  // position: tile, chunk inside the tile, chunks issued so far.
+  auto setupA = [&](int tm) {
+    const unsigned row = (unsigned)(tm * BM + wid * GA * RPD + srow);
+    if (MODE == 0) {
+      a_step = (int)(RPD * ad.ld0 * ESZ);
+      limA = M - (int)row;
 #pragma unroll
-    for (int i = 0; i < GA; ++i) {
-      const int row = (wid * GA + i) * RPD + srow;
-      const int chunk = spos ^ swz(row);
-      int m = tm * BM + row;
-      if (m >= M) m = M - 1;
-      if (MODE == 0) {
-        aoff[i] = (unsigned)((long)m * ad.ld0 * ESZ) + chunk * 16;
-      } else {
-        const int hw = ad.OH * ad.OW;
-        const int cn = m / hw;
-        const int rem = m - cn * hw;
-        const int oy = rem / ad.OW;
-        cbase[i] = (unsigned)cn * (unsigned)(ad.IH * ad.IW);
-        cyx[i] = ((unsigned)oy << 16) | (unsigned)(rem - oy * ad.OW);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < GB; ++i) {
-      const int row = (wid * GB + i) * RPD + srow;
-      const int chunk = spos ^ swz(row);
-      int n = tn * BN + row;
-      if (n >= N) n = N - 1;
-      woff[i] = (unsigned)((long)n * K * ESZ) + chunk * 16;
+      for (int q = 0; q < 2; ++q) aoff[q] = row * (unsigned)(ad.ld0 * ESZ) + (unsigned)((c0sw ^ (4 * ((q + wid * GA) & 1))) << 4);
+    } else {
+      am0 = row;
     }
     p_tap = 0;
     p_c = 0;
   };
-  auto prep = [&](int ch) {
+  auto setupW = [&](int tn) {
+    const unsigned row = (unsigned)(tn * BN + wid * GB * RPD + srow);
+    w_step = RPD * K * ESZ;
+    limW = N - (int)row;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) woff[q] = row * (unsigned)(K * ESZ) + (unsigned)((c0sw ^ (4 * ((q + wid * GB) & 1))) << 4);
+  };
+  auto prepA = [&](int ch) {   // source offsets of the A pieces of chunk `ch` of the A stream's tile (chunks come strictly in order)
     if (MODE == 0) {
       a_soff = ch * ROWB;
     } else {
@@ -125,10 +124,13 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
         a_soff = 0;
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
-          const int iy = (int)(cyx[i] >> 16) * ad.stride + ky - ad.pad, ix = (int)(cyx[i] & 0xffffu) * ad.stride + kx - ad.pad;
-          const bool ok = iy >= 0 && iy < vh && ix >= 0 && ix < vw;
+          const unsigned m = am0 + RPD * i;
+          const unsigned cn = fastdiv(m, ad.fd_hw), rem = m - cn * (unsigned)(ad.OH * ad.OW);
+          const unsigned oy = fastdiv(rem, ad.fd_ow), ox = rem - oy * (unsigned)ad.OW;
+          const int iy = (int)oy * ad.stride + ky - ad.pad, ix = (int)ox * ad.stride + kx - ad.pad;
+          const bool ok = (int)m < M && iy >= 0 && iy < vh && ix >= 0 && ix < vw;
           const int sy = ad.up ? iy >> 1 : iy, sx = ad.up ? ix >> 1 : ix;
-          const unsigned off = (cbase[i] + (unsigned)(sy * ad.IW + sx)) * cpb + (unsigned)((c0sw ^ (4 * (i & 1))) << 4);
+          const unsigned off = (cn * (unsigned)(ad.IH * ad.IW) + (unsigned)(sy * ad.IW + sx)) * cpb + (unsigned)((c0sw ^ (4 * ((i + wid * GA) & 1))) << 4);
           aoff[i] = ok ? off : DMA_POISON;
         }
       } else {
@@ -138,17 +140,15 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
       if (p_c == cin) { p_c = 0; ++p_tap; }
     }
   };
-  // pieces 0..3 = A, 4..7 = W of the chunk prepared by prep(); [LO, HI) go out now
-  auto issue = [&](int stage, int ch, auto LOc, auto HIc) {
-    constexpr int LO = decltype(LOc)::value, HI = decltype(HIc)::value;
-    char* st = smem + stage * STAGE_BYTES;
+  auto issueA = [&](int stage, auto Ic) {     // A piece I of the chunk prepared by prepA()
+    constexpr int I = decltype(Ic)::value;
     const __amdgpu_buffer_rsrc_t rA = (MODE == 1 && a_second) ? rA1 : rA0;
-#pragma unroll
-    for (int i = 0; i < GA; ++i)
-      if (i >= LO && i < HI) blds16(rA, aoff[i], a_soff, st + (wid * GA + i) * 1024);
-#pragma unroll
-    for (int i = 0; i < GB; ++i)
-      if (GA + i >= LO && GA + i < HI) blds16(rW, woff[i], ch * ROWB, st + A_BYTES + (wid * GB + i) * 1024);
+    if (MODE == 0) blds16(rA, RPD * I < limA ? aoff[I & 1] : DMA_POISON, a_soff + I * a_step, smem + stage * STAGE_BYTES + (wid * GA + I) * 1024);
+    else blds16(rA, aoff[I], a_soff, smem + stage * STAGE_BYTES + (wid * GA + I) * 1024);
+  };
+  auto issueW = [&](int stage, int ch, auto Ic) {
+    constexpr int I = decltype(Ic)::value;
+    blds16(rW, RPD * I < limW ? woff[I & 1] : DMA_POISON, ch * ROWB + I * w_step, smem + stage * STAGE_BYTES + A_BYTES + (wid * GB + I) * 1024);
   };
   using std::integral_constant;
 
@@ -156,167 +156,174 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
   // of a row depends on lm only ((16 t + lm) >> 1 & 7 == lm >> 1 & 7), so two per-lane offsets (ks = 0, 1) serve every tile
   const int sw = (lm >> 1) & 7;
   const int roff0 = lm * ROWB + ((lq ^ sw) << 4), roff1 = lm * ROWB + (((4 + lq) ^ sw) << 4);
-  const int a_base = wr * (BM / 2) * ROWB;                 // this wave's 128 A rows
-  const int b_base = A_BYTES + wc * (BN / 4) * ROWB;       // this wave's 64 W rows
+  const int a_base = wm * 64 * ROWB;                       // this wave's 64 A rows
+  const int b_base = A_BYTES + wn * (BN / 2) * ROWB;       // this wave's BN / 2 W rows
 
   const int nchunks = K / BK;
   const int G = gridDim.x;
   const int my_tiles = (nwg - (int)blockIdx.x + G - 1) / G;
   const int total = my_tiles * nchunks;
-  int vt_i = blockIdx.x, ich = 0, gi = 0, sl = 0;   // DMA side
+  int vtA = blockIdx.x, ichA = 0, giA = 0;          // A stream: tile, chunk in tile, chunks issued
+  int vtW = blockIdx.x, ichW = 0, giW = 0;          // W stream
   int sc = 0;                                       // MFMA side: stage to read
   {
     int tm, tn;
-    decode(vt_i, tm, tn);
-    setup(tm, tn);
+    decode(vtA, tm, tn);
+    setupA(tm);
+    setupW(tn);
   }
-  auto advance_dma = [&]() {
-    ++gi;
-    sl ^= 1;
-    if (++ich == nchunks) {
-      ich = 0;
-      vt_i += G;
-      if (vt_i < nwg) {
+  auto advanceA = [&]() {
+    ++giA;
+    if (++ichA == nchunks) {
+      ichA = 0;
+      vtA += G;
+      if (vtA < nwg) {
         int tm, tn;
-        decode(vt_i, tm, tn);
-        setup(tm, tn);
+        decode(vtA, tm, tn);
+        setupA(tm);
       }
     }
   };
+  auto advanceW = [&]() {
+    ++giW;
+    if (++ichW == nchunks) {
+      ichW = 0;
+      vtW += G;
+      if (vtW < nwg) {
+        int tm, tn;
+        decode(vtW, tm, tn);
+        setupW(tn);
+      }
+    }
+  };
+  // static loops over compile-time indices
+  auto for_n = [&](auto Nc, auto&& f) {
+    constexpr int N_ = decltype(Nc)::value;
+    [&]<int... I>(std::integer_sequence<int, I...>) { (f(integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N_>{});
+  };
+  // prologue: chunk 0 whole, the A half of chunk 1 (the A stream runs two chunks ahead of the MFMAs, the W stream one)
   if (total > 0) {
-    prep(ich);
-    issue(sl, ich, integral_constant<int, 0>{}, integral_constant<int, 8>{});
-    advance_dma();
+    prepA(ichA);
+    for_n(integral_constant<int, GA>{}, [&](auto i) { issueA(0, i); });
+    advanceA();
+    for_n(integral_constant<int, GB>{}, [&](auto i) { issueW(0, ichW, i); });
+    advanceW();
   }
-  wait_vmcnt<0>();
+  if (total > 1) {
+    prepA(ichA);
+    for_n(integral_constant<int, GA>{}, [&](auto i) { issueA(1, i); });
+    advanceA();
+    wait_vmcnt<GA>();
+  } else {
+    wait_vmcnt<0>();
+  }
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();   // the stagger: group 1 runs one barrier behind group 0 from here on
 
   for (int vt = blockIdx.x; vt < nwg; vt += G) {
     int tm, tn;
     decode(vt, tm, tn);
-    const int row0 = tm * BM + wr * (BM / 2), col0 = tn * BN + wc * (BN / 4);
+    const int row0 = tm * BM + wm * 64, col0 = tn * BN + wn * (BN / 2);
 
-    acc4 acc[8][4];
+    acc4 acc[4][NT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (acc4)(0.f);
+      for (int j = 0; j < NT; ++j) acc[i][j] = (acc4)(0.f);
 
-    // bias[n] + bias2[batch row][n] of the lane's W row n = col0 + 16 j + lm (two bias2 rows at most per tile); they enter
-    // the accumulators as one more MFMA after the main loop
     const int b2div = ep.bias2 ? ep.bias2_rows : 0x7fffffff;
     const int b2r0 = (tm * BM) / b2div;
     int mlast = tm * BM + BM - 1;
     if (mlast >= M) mlast = M - 1;
     const bool b2two = mlast / b2div > b2r0;
-    float bsum[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = col0 + 16 * j + lm;
-      const bool ok = n < N;
-      const float b = (ok && ep.bias) ? ep.bias[n] : 0.f;
-      bsum[j][0] = b + ((ok && ep.bias2) ? ep.bias2[(long)b2r0 * N + n] : 0.f);
-      bsum[j][1] = b + ((ok && ep.bias2 && b2two) ? ep.bias2[(long)(b2r0 + 1) * N + n] : 0.f);
-    }
 
-    s16x8 fa[4][2], fb0[2][2], fb1[2][2];   // [tile][ks]
+    s16x8 fa[4][2], fb[2][2];   // [tile][ks]
     for (int ch = 0; ch < nchunks; ++ch) {
       const char* st = smem + sc * STAGE_BYTES;
-      const bool more = gi < total;
-      const int st_i = sl, ch_i = ich;
-      if (more) prep(ich);
-      auto rdA = [&](int half) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const char* p = st + a_base + (half * 64 + 16 * t) * ROWB;
-          fa[t][0] = *reinterpret_cast<const s16x8*>(p + roff0);
-          fa[t][1] = *reinterpret_cast<const s16x8*>(p + roff1);
-        }
-      };
-      auto rdB = [&](int half, s16x8 (&f)[2][2]) {
+      const bool moreW = giW < total, moreA = giA < total;   // uniform: chunk c + 1 (W) / chunk c + 2 (A) exist
+      const int stW = giW & 1, stA = giA & 1, chW = ichW;
+      if (moreA) prepA(ichA);
+      for_n(integral_constant<int, NPH>{}, [&](auto Pc) {
+        constexpr int P = decltype(Pc)::value;
+        // ---- load part
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const char* p = st + b_base + (half * 32 + 16 * t) * ROWB;
-          f[t][0] = *reinterpret_cast<const s16x8*>(p + roff0);
-          f[t][1] = *reinterpret_cast<const s16x8*>(p + roff1);
+          const char* pb = st + b_base + (32 * P + 16 * t) * ROWB;
+          fb[t][0] = *reinterpret_cast<const s16x8*>(pb + roff0);
+          fb[t][1] = *reinterpret_cast<const s16x8*>(pb + roff1);
         }
-      };
-      auto mfmas = [&](auto MHc, auto NHc, s16x8 (&f)[2][2]) {
-        constexpr int mh = decltype(MHc)::value, nh = decltype(NHc)::value;
+        if (P == 0) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const char* pa = st + a_base + 16 * t * ROWB;
+            fa[t][0] = *reinterpret_cast<const s16x8*>(pa + roff0);
+            fa[t][1] = *reinterpret_cast<const s16x8*>(pa + roff1);
+          }
+        }
+        for_n(integral_constant<int, 2>{}, [&](auto Uc) {     // pieces 2 P, 2 P + 1 of [W 0 .. W GB-1 | A 0 .. A GA-1]
+          constexpr int S = 2 * P + decltype(Uc)::value;
+          if constexpr (S < GB) {
+            if (moreW) issueW(stW, chW, integral_constant<int, S>{});
+            if constexpr (S == GB - 1) { if (moreW) advanceW(); }
+          } else if constexpr (S < GB + GA) {
+            if (moreA) issueA(stA, integral_constant<int, S - GB>{});
+            if constexpr (S == GB + GA - 1) { if (moreA) advanceA(); }
+          }
+        });
+        if (P == NPH - 1) {
+          // chunk c + 1 must have landed before the barrier that precedes its first read; the GA A pieces of chunk c + 2
+          // issued during this chunk are the only younger LDS-DMA (epilogue loads / stores of a tile end are older)
+          if (moreA) wait_vmcnt<GA>(); else wait_vmcnt<0>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads have returned: the barrier may free their region
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- multiply part
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) acc[mh * 4 + t][nh * 2 + u] = mma16(f[u][ks], fa[t][ks], acc[mh * 4 + t][nh * 2 + u]);
+            for (int u = 0; u < 2; ++u) acc[t][2 * P + u] = mma16(fb[u][ks], fa[t][ks], acc[t][2 * P + u]);
         __builtin_amdgcn_s_setprio(0);
-      };
-      auto load_done = [&]() {   // this wave's LDS reads have returned: the phase's barrier may release their stage
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-      };
-      auto mfma_done = [&]() {
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      // ---- phase 0
-      rdB(0, fb0);
-      rdA(0);
-      if (more) issue(st_i, ch_i, integral_constant<int, 0>{}, integral_constant<int, P0>{});
-      load_done();
-      mfmas(integral_constant<int, 0>{}, integral_constant<int, 0>{}, fb0);
-      mfma_done();
-      // ---- phase 1
-      rdB(1, fb1);
-      if (more) issue(st_i, ch_i, integral_constant<int, P0>{}, integral_constant<int, P1>{});
-      load_done();
-      mfmas(integral_constant<int, 0>{}, integral_constant<int, 1>{}, fb1);
-      mfma_done();
-      // ---- phase 2
-      rdA(1);
-      if (more) issue(st_i, ch_i, integral_constant<int, P1>{}, integral_constant<int, 8>{});
-      load_done();
-      mfmas(integral_constant<int, 1>{}, integral_constant<int, 1>{}, fb1);
-      mfma_done();
-      // ---- phase 3: the next chunk must have landed before the barrier that precedes its first read
-      if (more) advance_dma();
-      wait_vmcnt<0>();
-      load_done();
-      mfmas(integral_constant<int, 1>{}, integral_constant<int, 0>{}, fb0);
-      mfma_done();
+      });
       sc ^= 1;
     }
 
-    // ---- bias as one more MFMA: D[n][m] += sum_c bsum[c][n] * sel[c][m]; values split into bf16 head + tail
+    // everything below derives its per-lane addressing from these opaque copies, so none of it is hoisted above the main loop
+    // (where it would only lengthen live ranges: the loop runs at the register limit)
+    int lme = lm, lqe = lq;
+    asm volatile("" : "+v"(lme), "+v"(lqe));
+    // ---- bias[n] + bias2[batch row][n] as one more MFMA: D[n][m] += sum_c bsum[c][n] * sel[c][m] (two bias2 rows at most per
+    // tile; values split into a bf16 head + tail so the sum is exact to ~2^-17 relative)
     if (ep.bias || ep.bias2) {
-      s16x8 fsel[8];
+      s16x8 fsel[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        int m = row0 + 16 * i + lm;
+      for (int i = 0; i < 4; ++i) {
+        int m = row0 + 16 * i + lme;
         if (m >= M) m = M - 1;
         const int c = m / b2div - b2r0;
         const short one = (short)0x3F80;
-        const short s0 = (lq == 0 && c == 0) ? one : (short)0, s1 = (lq == 0 && c == 1) ? one : (short)0;
+        const short s0 = (lqe == 0 && c == 0) ? one : (short)0, s1 = (lqe == 0 && c == 1) ? one : (short)0;
         fsel[i] = (s16x8){s0, s0, s1, s1, 0, 0, 0, 0};
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        s16x8 fbias = (s16x8)(0);
-        if (lq == 0) {
+      for (int j = 0; j < NT; ++j) {
+        const int n = col0 + 16 * j + lme;
+        const bool ok = n < N && lqe == 0;
+        const float b = (ok && ep.bias) ? ep.bias[n] : 0.f;
+        const float b0 = b + ((ok && ep.bias2) ? ep.bias2[(long)b2r0 * N + n] : 0.f);
+        const float b1 = b + ((ok && ep.bias2 && b2two) ? ep.bias2[(long)(b2r0 + 1) * N + n] : 0.f);
+        const bf16_t h0 = f32_to_bf16(b0), h1 = f32_to_bf16(b1);
+        const s16x8 fbias = (s16x8){(short)h0, (short)f32_to_bf16(b0 - bf16_to_f32(h0)), (short)h1,
+                                    (short)f32_to_bf16(b1 - bf16_to_f32(h1)), 0, 0, 0, 0};
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const bf16_t hi = f32_to_bf16(bsum[j][c]);
-            fbias[2 * c] = (short)hi;
-            fbias[2 * c + 1] = (short)f32_to_bf16(bsum[j][c] - bf16_to_f32(hi));
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i][j] = mma16(fbias, fsel[i], acc[i][j]);
+        for (int i = 0; i < 4; ++i) acc[i][j] = mma16(fbias, fsel[i], acc[i][j]);
       }
     }
 
@@ -326,70 +333,64 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
     // store per lane and tile pair, 64 contiguous bytes per output row and instruction.
     T* out = reinterpret_cast<T*>(ep.out) + (long)bz * ep.bso;
     const T* res = ep.residual ? reinterpret_cast<const T*>(ep.residual) + (long)bz * ep.bsr : nullptr;
-    const bool geglu = ep.act == 1;
-    const int cofs = 16 * (lq & 1) + 8 * (lq >> 1);
-    // two m-tiles at a time: their residual vectors are requested together (clamped addresses, no branches around the loads)
-    // before any of them is consumed, so the loads overlap instead of paying one memory round trip each
+    const bool geglu = ep.act == 1;              // BN = 256 only (host): a wave's 128 columns = two packed [32 h | 32 gate] groups
+    const int cofs = 16 * (lqe & 1) + 8 * (lqe >> 1);
+    constexpr int NPAIR = NT / 2;
 #pragma unroll
-    for (int ih = 0; ih < 4; ++ih) {
-      u32x4 rv[2][2];
+    for (int i = 0; i < 4; ++i) {
+      const int m = row0 + 16 * i + lme;
+      // the row tile's residual vectors are requested together (clamped addresses, no branches around the loads)
+      u32x4 rv[NPAIR];
       if (res) {
+        const int mc = m < M ? m : M - 1;
 #pragma unroll
-        for (int i4 = 0; i4 < 2; ++i4)
-#pragma unroll
-          for (int jp = 0; jp < 2; ++jp) {
-            int mc = row0 + 16 * (2 * ih + i4) + lm, nc = col0 + 32 * jp + cofs;
-            mc = mc < M ? mc : M - 1;
-            nc = nc < N ? nc : N - 8;
-            rv[i4][jp] = *reinterpret_cast<const u32x4*>(res + (long)mc * ep.ldr + nc);
-          }
+        for (int jp = 0; jp < NPAIR; ++jp) {
+          int nc = col0 + 32 * jp + cofs;
+          nc = nc < N ? nc : N - 8;
+          rv[jp] = *reinterpret_cast<const u32x4*>(res + (long)mc * ep.ldr + nc);
+        }
       }
 #pragma unroll
-      for (int i4 = 0; i4 < 2; ++i4) {
-        const int i = 2 * ih + i4;
-        const int m = row0 + 16 * i + lm;
-#pragma unroll
-        for (int jp = 0; jp < 2; ++jp) {
-          if (geglu && jp == 1) continue;        // tiles 2, 3 are the gates of tiles 0, 1 (packed weights: [32 h | 32 gate])
-          acc4 x = acc[i][2 * jp], y = acc[i][2 * jp + 1];
-          if (geglu) {
-            const acc4 gx = acc[i][2], gy = acc[i][3];
-            const f32x2 g0 = gelu_erf_f2((f32x2){gx[0], gx[1]}), g1 = gelu_erf_f2((f32x2){gx[2], gx[3]});
-            const f32x2 g2 = gelu_erf_f2((f32x2){gy[0], gy[1]}), g3 = gelu_erf_f2((f32x2){gy[2], gy[3]});
-            x[0] *= g0[0]; x[1] *= g0[1]; x[2] *= g1[0]; x[3] *= g1[1];
-            y[0] *= g2[0]; y[1] *= g2[1]; y[2] *= g3[0]; y[3] *= g3[1];
-          }
-          float o8[8];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const auto sw2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[r]), __float_as_uint(y[r]), false, false);
-            o8[r] = __uint_as_float(sw2[0]);
-            o8[4 + r] = __uint_as_float(sw2[1]);
-          }
-          const int nacc = col0 + 32 * jp + cofs;                     // column in the accumulator's N space
-          const long ocol = geglu ? (long)(col0 >> 1) + cofs : (long)nacc;
-          if (res) {
-            union { u32x4 u; bf16_t e[8]; } r8;
-            r8.u = rv[i4][jp];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] += bf16_to_f32(r8.e[e]);
-          }
-          if (m < M && nacc < N)
-            *reinterpret_cast<u32x4*>(out + (long)m * ep.ldo + ocol) =
-                (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])};
+      for (int jp = 0; jp < NPAIR; ++jp) {
+        if (geglu && (jp & 1)) continue;         // tile pairs 1, 3 are the gates of pairs 0, 2
+        acc4 x = acc[i][2 * jp], y = acc[i][2 * jp + 1];
+        if (BN == 256 && geglu) {
+          const acc4 gx = acc[i][(2 * jp + 2) % NT], gy = acc[i][(2 * jp + 3) % NT];
+          const f32x2 g0 = gelu_erf_f2((f32x2){gx[0], gx[1]}), g1 = gelu_erf_f2((f32x2){gx[2], gx[3]});
+          const f32x2 g2 = gelu_erf_f2((f32x2){gy[0], gy[1]}), g3 = gelu_erf_f2((f32x2){gy[2], gy[3]});
+          x[0] *= g0[0]; x[1] *= g0[1]; x[2] *= g1[0]; x[3] *= g1[1];
+          y[0] *= g2[0]; y[1] *= g2[1]; y[2] *= g3[0]; y[3] *= g3[1];
         }
+        float o8[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const auto sw2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[r]), __float_as_uint(y[r]), false, false);
+          o8[r] = __uint_as_float(sw2[0]);
+          o8[4 + r] = __uint_as_float(sw2[1]);
+        }
+        const int nacc = col0 + 32 * jp + cofs;                       // column in the accumulator's N space
+        const long ocol = geglu ? (long)(col0 >> 1) + 16 * jp + cofs : (long)nacc;
+        if (res) {
+          union { u32x4 u; bf16_t e[8]; } r8;
+          r8.u = rv[jp];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o8[e] += bf16_to_f32(r8.e[e]);
+        }
+        if (m < M && nacc < N)
+          *reinterpret_cast<u32x4*>(out + (long)m * ep.ldo + ocol) =
+              (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])};
       }
     }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();   // group 0 meets group 1's last barrier
 }
 
-template <int MODE>
+template <int MODE, int BN>
 int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
-  constexpr int BM = 256, BN = 256;
+  constexpr int BM = 256;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = (size_t)2 * (BM + BN) * 128;
-  auto kern = gemm16_kernel<MODE>;
+  auto kern = gemm16_kernel<MODE, BN>;
   static int resident = 0;
   if (!resident) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -403,7 +404,7 @@ int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int
       mmgt_set_error("gemm16: device query failed");
       return 2;
     }
-    resident = prop.multiProcessorCount;   // 128 KiB of LDS: one workgroup per CU
+    resident = prop.multiProcessorCount;   // 128 / 144 KiB of LDS: one workgroup per CU
   }
   long gx = (resident + batch - 1) / batch;
   gx = (gx + 7) / 8 * 8;
@@ -416,12 +417,13 @@ int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int
 
 }  // namespace
 
-// Entry for gemm.hip's dispatcher.  Preconditions (checked there): bf16, vectorised epilogue (ep.fast), act in {none, GEGLU},
-// no row scale / alpha / post-scale bias, K % 64 == 0.
-int mmgt_gemm16_launch(int mode, const void* adp, const void* W, long bsw, const void* epp, int M, int N, int K, int batch,
-                       void* stream) {
+// Entry for gemm.hip's dispatcher.  Preconditions (checked there): bf16, vectorised epilogue (ep.fast), act in {none, GEGLU}
+// (GEGLU with bn = 256 only), no row scale / alpha / post-scale bias, K % 64 == 0.
+int mmgt_gemm16_launch(int mode, int bn, const void* adp, const void* W, long bsw, const void* epp, int M, int N, int K,
+                       int batch, void* stream) {
   const ADesc& ad = *reinterpret_cast<const ADesc*>(adp);
   const Epi& ep = *reinterpret_cast<const Epi*>(epp);
   hipStream_t s = (hipStream_t)stream;
-  return mode == 0 ? launch16<0>(ad, W, bsw, ep, M, N, K, batch, s) : launch16<1>(ad, W, bsw, ep, M, N, K, batch, s);
+  if (bn == 320) return mode == 0 ? launch16<0, 320>(ad, W, bsw, ep, M, N, K, batch, s) : launch16<1, 320>(ad, W, bsw, ep, M, N, K, batch, s);
+  return mode == 0 ? launch16<0, 256>(ad, W, bsw, ep, M, N, K, batch, s) : launch16<1, 256>(ad, W, bsw, ep, M, N, K, batch, s);
 }

@@ -14,7 +14,23 @@ struct ADesc {
   int IH, IW, OH, OW; // conv: stored input dims and output dims
   int stride, up;     // conv: stride; up = 1 -> the conv sees the nearest-2x upsampled input
   int pad;            // conv: zero rows / columns in front (1; 0 for the VAE encoder's (0, 1) padded downsample)
+  unsigned fd_hw[3], fd_ow[3];   // conv: division of an output row index by OH * OW and by OW as multiply-high + shifts (fastdiv)
 };
+
+// Unsigned division by a launch-time constant as multiply-high and two shifts (Granlund & Montgomery), exact for every 32-bit
+// numerator: the conv gather of gemm16.hip re-derives (image, y, x) of its output rows at every tap change instead of keeping
+// them in registers.
+inline void make_fastdiv(unsigned d, unsigned (&fd)[3]) {
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  fd[0] = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  fd[1] = l < 1 ? l : 1;
+  fd[2] = l > 0 ? l - 1 : 0;
+}
+__device__ __forceinline__ unsigned fastdiv(unsigned n, const unsigned (&fd)[3]) {
+  const unsigned t = __umulhi(fd[0], n);
+  return (t + ((n - t) >> fd[1])) >> fd[2];
+}
 
 struct Epi {
   const float* bias;       // [N]

@@ -110,7 +110,7 @@ def test_gemm_batched_vt(dt):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("cfg", [1, 3, 6, 9, 12, 16])
+@pytest.mark.parametrize("cfg", [1, 3, 6, 9, 12, 16, 17])
 def test_gemm_and_conv_forced_tile_configs(dt, cfg):
     """Every tile configuration the heuristic can pick (128x128, 128x64, 256x128, 256x256 with 64-byte LDS rows, and the
     320-column tiles with the barrier inside the chunk) against fp64 torch math, incl. ragged M/N, two bias2 rows per
@@ -148,18 +148,19 @@ def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
 
-def test_gemm16_core_exact_integers_and_geglu():
-    """The 16x16x32 8-phase core (cfg 16, bf16 only): (a) exact small-integer operands with an ASYMMETRIC weight matrix --
+@pytest.mark.parametrize("cfg", [16, 17])
+def test_gemm16_core_exact_integers_and_geglu(cfg):
+    """The 16x16x32 ping-pong core (cfg 16: 256 x 256 tile, cfg 17: 256 x 320; bf16 only; GEGLU runs on cfg 16 only): (a) exact small-integer operands with an ASYMMETRIC weight matrix --
     any row/column or k-order mix-up in the fragment maps, the permlane16 epilogue or the swizzle shows as a wrong integer;
     (b) GEGLU with packed weights, (c) ragged M / N edges and several tiles per persistent workgroup, (d) bias2 + residual."""
     from mmgt_amd import hip
     from mmgt_amd.packing import pack_geglu
     dt = torch.bfloat16
     try:
-        hip.tune("gemm_cfg", 16)
-        for M, N, K in [(256, 256, 64), (300, 264, 128), (2000, 1288, 320)]:
-            a = torch.randint(-3, 4, (M, K), device=dev()).to(dt)
-            w = torch.randint(-2, 3, (N, K), device=dev()).to(dt)
+        hip.tune("gemm_cfg", cfg)
+        for M, N, K in [(256, 256, 64), (300, 264, 128), (2000, 1288, 320), (1000, 320, 192), (520, 640, 64)]:
+            a = torch.randint(-1, 2, (M, K), device=dev()).to(dt)
+            w = torch.randint(-1, 2, (N, K), device=dev()).to(dt)
             w[:, 0] = (torch.arange(N, device=dev()) % 5 - 2).to(dt)               # column- and row-dependent pattern
             a[:, 1] = (torch.arange(M, device=dev()) % 7 - 3).to(dt)
             out = hip.gemm(a, w)
