@@ -506,6 +506,11 @@ int launch_t(const AttnParams& p, int batch, int heads, int hd, int vt, hipStrea
 
 }  // namespace
 
+// tattn.hip: the motion modules' temporal self-attention (one sequence = the <= 32 frames of one pixel)
+int mmgt_tattn_try(const void* q, long q_bs0, long q_bs1, long q_ts, const void* k, long k_bs0, long k_bs1, long k_ts,
+                   const void* v, long v_bs0, long v_bs1, long v_ts, void* o, long o_bs0, long o_bs1, long o_ts, int bdiv,
+                   int batch, int heads, int hd, int frames, float scale, int dtype, void* stream);
+
 extern "C" int mmgt_attention(const void* q, long q_bs0, long q_bs1, long q_ts, const void* k, long k_bs0, long k_bs1,
                               long k_ts, const void* v, long v_bs0, long v_bs1, long v_ts, void* o, long o_bs0,
                               long o_bs1, long o_ts, int bdiv, const void* k2, const void* v2, long k2_bs, long k2_ts,
@@ -524,6 +529,11 @@ extern "C" int mmgt_attention(const void* q, long q_bs0, long q_bs1, long q_ts, 
              "attention: strides must keep 16-byte alignment");
   MMGT_CHECK(!k2 || (k2_ts % vec == 0 && k2_bs % vec == 0 && v2_ts % vec == 0 && v2_bs % vec == 0),
              "attention: segment-2 strides must keep 16-byte alignment");
+  if (nq == nk && nk <= 32 && !k2 && !v_transposed) {   // temporal pattern: the memory-stream kernel of tattn.hip
+    const int rc = mmgt_tattn_try(q, q_bs0, q_bs1, q_ts, k, k_bs0, k_bs1, k_ts, v, v_bs0, v_bs1, v_ts, o, o_bs0, o_bs1, o_ts, bdiv,
+                                  batch, heads, hd, nq, scale, dtype, stream);
+    if (rc >= 0) return rc;
+  }
   AttnParams p{};
   p.q = (const char*)q; p.k = (const char*)k; p.v = (const char*)v; p.k2 = (const char*)k2; p.v2 = (const char*)v2;
   p.o = (char*)o;

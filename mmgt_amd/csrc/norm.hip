@@ -60,32 +60,36 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x0,
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int rpw = 64 / lpr, sub = lane / lpr, li = lane - sub * lpr;
 
-  float s[MAXS][VEC], q[MAXS][VEC], pv[MAXS][VEC];
+  float s[MAXS][VEC], q[MAXS][VEC];
 #pragma unroll
   for (int i = 0; i < MAXS; ++i)
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      s[i][e] = q[i][e] = 0.f;
-      const int c = (li + lpr * i) * VEC + e;
-      pv[i][e] = c < C ? ssum[c] : 0.f;
-    }
-  __syncthreads();                                    // ssum is reused for the reduction below
+    for (int e = 0; e < VEC; ++e) s[i][e] = q[i][e] = 0.f;
 
+  // the pivots stay in LDS (ssq doubles as their table until the reduction below) and are re-read per row: holding them in
+  // registers next to the 2 x MAXS x VEC accumulators cost the kernel half its occupancy (174 VGPRs, 2 waves per SIMD)
+  for (int c = threadIdx.x; c < C; c += 256) ssq[c] = ssum[c];
+  __syncthreads();
   for (int r = r0 + wid * rpw + sub; r < r1; r += 4 * rpw) {
     const long pix = (long)n * HW + r;
+    int keep = 0;
+    asm volatile("" : "+v"(keep));                    // opaque zero: keeps the pivot reads inside the row loop
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
       const int vc = li + lpr * i;
       if (vc < nvec) {
         const int c = vc * VEC;
         const T* src = c < C0 ? x0 + pix * C0 + c : x1 + pix * C1 + (c - C0);
-        float f[VEC];
+        float f[VEC], pv[VEC];
         VecIO<T>::load(src, f);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { const float d = f[e] - pv[i][e]; s[i][e] += d; q[i][e] += d * d; }
+        for (int e = 0; e < VEC; e += 4) *reinterpret_cast<f32x4*>(&pv[e]) = *reinterpret_cast<const f32x4*>(&ssq[c + e + keep]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { const float d = f[e] - pv[e]; s[i][e] += d; q[i][e] += d * d; }
       }
     }
   }
+  __syncthreads();                                    // every wave is done with the pivot table: ssq is reused below
   // fold the wave's row slots together (fixed xor tree), then the four waves in a fixed order
   for (int o = lpr; o < 64; o <<= 1) {
 #pragma unroll

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Times GroupNorm / LayerNorm at the step's shapes (HIP events, one process): python tools/bench_norm.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mmgt_amd import hip  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def t_us(fn, reps=20):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+for nb, hw, c in [(48, 4096, 320), (48, 4096, 640), (48, 1024, 640), (48, 256, 1280), (48, 64, 1280), (48, 4096, 960)]:
+    x = torch.randn(nb, hw, c, device=dev).bfloat16()
+    g, b = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+    o = torch.empty_like(x)
+    us = t_us(lambda: hip.groupnorm(x, g, b, 32, 1e-5, silu=True, out=o))
+    print(f"groupnorm nb={nb} hw={hw} c={c}: {us:7.1f} us  {3 * x.numel() * 2 / us / 1e6:6.2f} TB/s (3 passes)")
+for rows, c in [(196608, 320), (49152, 640), (12288, 1280)]:
+    x = torch.randn(rows, c, device=dev).bfloat16()
+    g, b = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+    o = torch.empty_like(x)
+    us = t_us(lambda: hip.layernorm(x, g, b, out=o))
+    print(f"layernorm rows={rows} c={c}: {us:7.1f} us  {2 * x.numel() * 2 / us / 1e6:6.2f} TB/s (2 passes)")

@@ -38,7 +38,9 @@ def key_of(name, args, kw):
         return (f"conv nb={x.shape[0]} h={x.shape[1]} cin={cin} cout={wp.shape[0]} s={st} up={int(up)}",
                 2 * x.shape[0] * oh * oh * wp.shape[0] * 9 * cin)
     if name == "attention":
-        fl = 4 * kw["batch"] * kw["heads"] * kw["hd"] * kw["nq"] * (kw["nk"] + kw.get("nk2", 0))
+        # the second key segment (reference bank) is read by batches >= seg2_first_batch only (the conditional CFG half)
+        nb2 = kw["batch"] - kw.get("seg2_first_batch", 0) if kw.get("nk2", 0) else 0
+        fl = 4 * kw["heads"] * kw["hd"] * kw["nq"] * (kw["batch"] * kw["nk"] + nb2 * kw.get("nk2", 0))
         return (f"attn b={kw['batch']} h={kw['heads']} hd={kw['hd']} nq={kw['nq']} nk={kw['nk']} nk2={kw.get('nk2', 0)} "
                 f"vt={int(kw.get('v_transposed', False))}", fl)
     if name == "groupnorm":
@@ -70,7 +72,7 @@ def main():
     for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
               "ncfhw_to_nhwc", "nhwc_to_ncfhw", "timestep_features", "silu", "cfg_ddim_step", "accumulate_window"]:
         wrap(n)
-    sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline"]
+    sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
     import io
     import contextlib
     # run bench.main() (its own warmup is recorded too: drop those records afterwards)
