@@ -33,6 +33,8 @@ extern "C" {
 #define MMGT_ACT_SILU 2
 #define MMGT_ACT_RELU 3
 #define MMGT_ACT_QUICK_GELU 4 /* x * sigmoid(1.702 x): the CLIP vision tower's MLP (transformers activations.py) */
+#define MMGT_ACT_GELU 5       /* exact-erf GELU: SMGA's feed-forward blocks (src/audio2pose_model/SMGA.py:92) */
+#define MMGT_ACT_MISH 6       /* x * tanh(softplus(x)): SMGA's time MLP (src/audio2pose_model/model.py:370-374) */
 
 int mmgt_abi_version(void);
 const char* mmgt_last_error(void);
@@ -138,6 +140,25 @@ int mmgt_accumulate_window(const void* pred, float* pred_sum, float* counter, co
  * one; bump_counter = 0 for the second row of a window so that counter counts windows, as :624 does. */
 int mmgt_accumulate_window_rows(const void* pred, float* pred_sum, float* counter, const int* idx, int Fw, int F, int C,
                                 int Cpad, int hw, int rows, int row0, int bump_counter, int dtype, void* stream);
+
+/* ---- Stage-1 SMGA audio -> pose sampler: the element-wise glue between its Linear / attention / LayerNorm calls.
+ * out = x rotated pairwise by the angle table cos_sin[(row % seq)][dim / 2][2] (cos, sin): RotaryEmbedding.rotate_queries_or_keys,
+ * src/audio2pose_model/rotary_embedding_torch.py:38-61,106-113 (call sites model.py:121,267,298-299). */
+int mmgt_rotary(const void* x, const float* cos_sin, void* out, long rows, int dim, int seq, int dtype, void* stream);
+/* out = res (+ res2) + (scale[b] + 1) * x + shift[b], b = row / rows_per_batch, scale_shift fp32 rows of [scale(dim) | shift(dim)]
+ * with row stride ld_ss: featurewise_affine of a DenseFiLM output plus the residual, model.py:44-64,231,246-259. */
+int mmgt_film_residual(const void* x, const float* scale_shift, long ld_ss, const void* res, const void* res2, void* out, long rows,
+                       int dim, int rows_per_batch, int dtype, void* stream);
+/* out[b][c] (fp32) = mean over tokens of x[b][t][c]: model.py:460. */
+int mmgt_mean_tokens(const void* x, float* out, int batch, int tokens, int dim, int dtype, void* stream);
+/* out = act(x) element-wise for act in {MMGT_ACT_SILU, MMGT_ACT_GELU, MMGT_ACT_MISH}: DenseFiLM's Mish in front of its Linear
+ * (model.py:50-52) where no GEMM epilogue can carry it. */
+int mmgt_activation(const void* x, void* out, long n, int act, int dtype, void* stream);
+/* x0 = clamp(u + (c - u) g, -1, 1); eps = (x sqrt(1/a) - x0) / sqrt(1/a - 1); out = last ? x0 : x0 sqrt(a') + c eps + sigma noise:
+ * guided_forward + model_predictions + the DDIM update of src/audio2pose_model/diffusion.py:149-156,257-273 (fp32 sampler state). */
+int mmgt_smga_ddim_step(const void* pred_uncond, const void* pred_cond, const float* x, const float* noise, float* out, long n,
+                        float guidance, float sqrt_recip_acp, float sqrt_recipm1_acp, float sqrt_acp_next, float c, float sigma,
+                        int last, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

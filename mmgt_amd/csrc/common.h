@@ -97,6 +97,12 @@ __device__ __forceinline__ float frag_get(const Frag<float>& f, int j) { return 
 __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+// Mish (SMGA's FiLM generators and time MLP): x * tanh(softplus(x)) = x * (e^2 + 2 e) / (e^2 + 2 e + 2), e = exp(x)
+__device__ __forceinline__ float mish_f(float x) {
+  if (x > 20.f) return x;                                     // tanh(softplus(x)) == 1 to fp32 precision; avoids inf / inf
+  const float e = __expf(x), n = e * (e + 2.f);
+  return x * n / (n + 2.f);
+}
 // CLIP's activation (transformers `quick_gelu`): x * sigmoid(1.702 x)
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.f + __expf(-1.702f * x)); }
 // Exact-erf GELU, x * Phi(x), with erf from Abramowitz & Stegun 7.1.28:

@@ -568,6 +568,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
               } else if (FULL_OK && ep.act == 4) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = quick_gelu_f(v[r]);
+              } else if (FULL_OK && ep.act == 5) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = gelu_erf_f(v[r]);
+              } else if (FULL_OK && ep.act == 6) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = mish_f(v[r]);
               }
               if (scaled) v *= rs;
             }
@@ -684,6 +690,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
               if (ep.act == 2) x = silu_f(x);
               if (ep.act == 3) x = fmaxf(x, 0.f);
               if (ep.act == 4) x = quick_gelu_f(x);
+              if (ep.act == 5) x = gelu_erf_f(x);
+              if (ep.act == 6) x = mish_f(x);
               x *= (ep.row_scale ? ep.row_scale[m] : 1.f) * ep.alpha;
               if (POST_OK && ep.bias_post) x += ep.bias_post[ncol];
             }
@@ -825,7 +833,7 @@ int check_common(int dtype, int M, int N, int K, int act) {
   MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "gemm: bad dtype %d", dtype);
   MMGT_CHECK(M > 0 && N > 0 && K > 0, "gemm: empty problem M=%d N=%d K=%d", M, N, K);
   MMGT_CHECK(K % 64 == 0, "gemm: K=%d must be a multiple of 64 (pad channels on the host)", K);
-  MMGT_CHECK(act >= 0 && act <= 4, "gemm: bad act %d", act);
+  MMGT_CHECK(act >= 0 && act <= 6, "gemm: bad act %d", act);
   MMGT_CHECK(act != 1 || N % 64 == 0, "gemm: GEGLU needs N %% 64 == 0 (N=%d)", N);
   return 0;
 }

@@ -42,7 +42,7 @@ struct Epi {
   long ldr, ldo, bsr, bso; // strides in elements; bs* = grid.z strides
   int bias2_rows;
   float alpha;
-  int act;                 // 0 none, 1 GEGLU (packed weights, out has N/2 columns), 2 SiLU, 3 ReLU, 4 quick-GELU
+  int act;                 // 0 none, 1 GEGLU (packed weights, out has N/2 columns), 2 SiLU, 3 ReLU, 4 quick-GELU, 5 GELU (erf), 6 Mish
   int fast;                // 1: N % 8 == 0 and every row / pointer 16-byte aligned -> vectorised epilogue
 };
 

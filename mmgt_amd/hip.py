@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmgt_hip.so")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_RELU, ACT_QUICK_GELU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_RELU, ACT_QUICK_GELU, ACT_GELU, ACT_MISH = 0, 1, 2, 3, 4, 5, 6
 
 _lib = None
 
@@ -47,6 +47,12 @@ _SIGS = {
                                    c_float, c_float, c_float, c_void_p]),
     "mmgt_accumulate_window": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p]),
+    "mmgt_rotary": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p]),
+    "mmgt_film_residual": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_void_p]),
+    "mmgt_mean_tokens": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_activation": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
+    "mmgt_smga_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float,
+                                    c_float, c_float, c_int, c_int, c_void_p]),
     "mmgt_accumulate_window_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                             c_int, c_int, c_int, c_int, c_void_p]),
 }
@@ -325,3 +331,57 @@ def accumulate_window(pred, pred_sum, counter, idx, C, rows=2, row0=0, bump_coun
     _check(lib().mmgt_accumulate_window_rows(_ptr(pred), _ptr(pred_sum), _ptr(counter), _ptr(idx), Fw, F, C, pred.shape[3],
                                              hw, rows, row0, int(bump_counter), dtype_code(pred.dtype), _stream()),
            "mmgt_accumulate_window_rows")
+
+
+# ------------------------------------------------------------------------------------------------------------ SMGA glue
+
+def rotary(x, cos_sin, seq):
+    """x (rows, dim) -> rotated pairs, angle table cos_sin (>= seq, dim/2, 2) fp32 indexed by row % seq."""
+    _dev(x, cos_sin)
+    assert x.dim() == 2 and x.is_contiguous() and cos_sin.is_contiguous() and cos_sin.shape[0] >= seq
+    out = torch.empty_like(x)
+    _check(lib().mmgt_rotary(_ptr(x), _ptr(_f32(cos_sin, "cos_sin")), _ptr(out), x.shape[0], x.shape[1], seq, dtype_code(x.dtype),
+                             _stream()), "mmgt_rotary")
+    return out
+
+
+def film_residual(x, scale_shift, rows_per_batch, res=None, res2=None):
+    """res (+ res2) + (scale + 1) * x + shift; scale_shift: fp32 (B, >= 2 dim) view with unit column stride, [scale | shift] per row."""
+    _dev(x, scale_shift, res, res2)
+    assert x.dim() == 2 and x.is_contiguous() and scale_shift.dtype == torch.float32 and scale_shift.stride(1) == 1
+    assert scale_shift.shape[1] >= 2 * x.shape[1] and scale_shift.shape[0] * rows_per_batch >= x.shape[0]
+    for r in (res, res2):
+        assert r is None or (r.shape == x.shape and r.is_contiguous() and r.dtype == x.dtype)
+    out = torch.empty_like(x)
+    _check(lib().mmgt_film_residual(_ptr(x), _ptr(scale_shift), scale_shift.stride(0), _ptr(res), _ptr(res2), _ptr(out), x.shape[0],
+                                    x.shape[1], rows_per_batch, dtype_code(x.dtype), _stream()), "mmgt_film_residual")
+    return out
+
+
+def mean_tokens(x):
+    """(B, T, C) -> fp32 (B, C)."""
+    _dev(x)
+    assert x.dim() == 3 and x.is_contiguous()
+    out = torch.empty((x.shape[0], x.shape[2]), device=x.device, dtype=torch.float32)
+    _check(lib().mmgt_mean_tokens(_ptr(x), _ptr(out), x.shape[0], x.shape[1], x.shape[2], dtype_code(x.dtype), _stream()),
+           "mmgt_mean_tokens")
+    return out
+
+
+def activation(x, act):
+    _dev(x)
+    assert x.is_contiguous()
+    out = torch.empty_like(x)
+    _check(lib().mmgt_activation(_ptr(x), _ptr(out), x.numel(), act, dtype_code(x.dtype), _stream()), "mmgt_activation")
+    return out
+
+
+def smga_ddim_step(pred_uncond, pred_cond, x, noise, guidance, sqrt_recip, sqrt_recipm1, sqrt_next, c, sigma, last):
+    _dev(pred_uncond, pred_cond, x, noise)
+    assert pred_uncond.is_contiguous() and pred_cond.is_contiguous() and pred_uncond.dtype == pred_cond.dtype
+    assert x.dtype == torch.float32 and x.is_contiguous() and pred_uncond.numel() == x.numel() == pred_cond.numel()
+    out = torch.empty_like(x)
+    _check(lib().mmgt_smga_ddim_step(_ptr(pred_uncond), _ptr(pred_cond), _ptr(x), _ptr(_f32(noise, "noise")), _ptr(out), x.numel(),
+                                     guidance, sqrt_recip, sqrt_recipm1, sqrt_next, c, sigma, int(last),
+                                     dtype_code(pred_uncond.dtype), _stream()), "mmgt_smga_ddim_step")
+    return out
