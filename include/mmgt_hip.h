@@ -160,6 +160,26 @@ int mmgt_smga_ddim_step(const void* pred_uncond, const void* pred_cond, const fl
                         float guidance, float sqrt_recip_acp, float sqrt_recipm1_acp, float sqrt_acp_next, float c, float sigma,
                         int last, int dtype, void* stream);
 
+/* ---- conditioning producers and the output path on the device; uint8 image buffers are device pointers.
+ * blur_mask: (frames, H, W) u8 -> (frames, 64, 64) u8 = cv2.resize(64x64, bilinear) -> cv2.GaussianBlur(ksize, sigma from ksize,
+ * reflect-101) -> cv2.normalize(MINMAX, 0, 255): scripts/pose2vid.py:94-114, scripts/audio2vid.py:131-151. */
+int mmgt_blur_mask_u8(const unsigned char* masks, unsigned char* out, int frames, int H, int W, int ksize, void* stream);
+/* (frames, S, S) u8 -> (frames, D, D): PIL's two-pass 8-bit resampling with the caller's integer coefficient tables
+ * (bounds[D][2] = first tap, tap count; coeffs[D][ksize], 22 fractional bits), written as float / 255 (ToTensor) and / or u8:
+ * torchvision Resize + ToTensor of src/dataset/image_processor.py:75-102,311-333. */
+int mmgt_resample_u8(const unsigned char* in, float* out_f32, unsigned char* out_u8, int frames, int S, int D, const int* bounds,
+                     const int* coeffs, int ksize, void* stream);
+/* out[f][j] = x[clamp(f + j - half, 0, frames - 1)], j = 0 .. 2 half, rows of D floats: process_audio_emb, scripts/pose2vid.py:72-91. */
+int mmgt_window_stack(const float* x, float* out, int frames, long D, int half, void* stream);
+/* out (npix, 3) u8 = trunc(clamp(x[p][0..2] * scale + shift, 0, 1) * 255) from channels-last T (npix, cpad): decode_latents'
+ * (x / 2 + 0.5).clamp(0, 1) (pipeline_pose2vid_long.py:121-123) fused with save_videos_grid's (x * 255).astype(uint8)
+ * (src/utils/util.py:148-160). */
+int mmgt_frames_to_u8(const void* x, unsigned char* out, long npix, int cpad, float scale, float shift, int dtype, void* stream);
+/* SYNTHETIC stand-in for the DWPose drawing (src/dwpose/util.py, out of scope): channel c of frame t = 255 within `radius` pixels of
+ * a key point k in [lohi[2c], lohi[2c+1]) with score > 0.3; kp (frames, npoints, 3) = (x, y, score), x / y in [0, 1]. */
+int mmgt_splat_keypoints(const float* kp, unsigned char* out, int frames, int npoints, int H, int W, int channels, const int* lohi,
+                         float radius, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

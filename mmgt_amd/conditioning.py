@@ -6,10 +6,17 @@ define what `Pose2VideoPipeline.__call__` is handed.
                         four levels (H/8/2^k)^2, ToTensor() range [0,1], flattened to (L, N_k)
   * full_mask_from_lips scripts/audio2vid.py:470-476 convention: full[k] = 1 + lips[k]
 
-The reference resizes PIL images with torchvision's `Resize` (bilinear, antialias per torchvision version) and blurs with
-cv2; neither library is part of this build, so the resize is restated with `F.interpolate(mode="bilinear",
-antialias=True)` (PIL-equivalent for down-scaling) and is NOT pinned against the reference's image stack.
+The host functions below (`process_audio_emb`, `mask_pyramid`) are the original plain-torch forms.  The `*_device` functions
+run the same producers on the GPU through libmmgt_hip.so (csrc/conditioning.hip):
+
+  * blur_mask_device        scripts/pose2vid.py:94-114 (cv2.resize -> cv2.GaussianBlur -> cv2.normalize), float arithmetic with
+                            cv2's rounding points; cv2 is not part of this build, so this piece is parity-unpinned
+  * mask_pyramid_device     torchvision `Resize` on a PIL "L" image IS `PIL.Image.resize(BILINEAR)`: the kernel runs PIL's own
+                            two-pass fixed-point resampling from the integer coefficient tables computed here exactly as
+                            Pillow's Resample.c does -- bit-exact with PIL (tests/test_conditioning.py)
+  * process_audio_emb_device
 """
+import math
 from typing import List
 
 import torch
@@ -40,3 +47,65 @@ def mask_pyramid(masks: torch.Tensor, img_size: int = 512) -> List[torch.Tensor]
 
 def full_mask_from_lips(lips: List[torch.Tensor]) -> List[torch.Tensor]:
     return [1 + l for l in lips]
+
+
+# ------------------------------------------------------------------------------------------------ device producers
+
+def pil_bilinear_tables(in_size: int, out_size: int):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc (src/libImaging/Resample.c) for the BILINEAR (triangle) filter:
+    per output sample the first input tap, the tap count and the integer weights with 22 fractional bits.  Python floats are
+    IEEE doubles like the C code's, so the integers equal Pillow's."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds, kk = [], []
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        ss = 1.0 / filterscale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = []
+        for x in range(xmax):
+            v = abs((x + xmin - center + 0.5) * ss)
+            w.append(1.0 - v if v < 1.0 else 0.0)
+        ww = sum(w)
+        w = [(v / ww if ww != 0.0 else v) for v in w] + [0.0] * (ksize - xmax)
+        bounds.append((xmin, xmax))
+        kk.append([int(0.5 + v * (1 << 22)) if v >= 0 else int(-0.5 + v * (1 << 22)) for v in w])
+    return torch.tensor(bounds, dtype=torch.int32), torch.tensor(kk, dtype=torch.int32)
+
+
+_TABLES = {}
+
+
+def mask_pyramid_device(masks_u8: torch.Tensor, img_size: int = 512) -> List[torch.Tensor]:
+    """masks_u8 (L, S, S) uint8 on the GPU, S = img_size / 8 (the blurred 64 x 64 "L" masks) -> list[4] of (L, (S / 2^k)^2)
+    float32 in [0, 1]: ImageProcessor.preprocess_mov_mask (image_processor.py:311-333)."""
+    from . import hip
+    S = masks_u8.shape[1]
+    out = []
+    for k in range(4):
+        D = img_size // 8 // (2 ** k)
+        if D == S:
+            lvl = masks_u8.to(torch.float32) / 255.0                    # Resize to the same size is the identity; ToTensor
+        else:
+            key = (S, D, masks_u8.device)
+            if key not in _TABLES:
+                b, c = pil_bilinear_tables(S, D)
+                _TABLES[key] = (b.to(masks_u8.device), c.to(masks_u8.device))
+            lvl = hip.resample_u8(masks_u8, D, *_TABLES[key])
+        out.append(lvl.reshape(lvl.shape[0], -1))
+    return out
+
+
+def blur_mask_device(masks_u8: torch.Tensor, kernel_size: int) -> torch.Tensor:
+    """(L, H, W) uint8 mask frames on the GPU -> (L, 64, 64) uint8: blur_mask(resize_dim=(64, 64), kernel_size) of
+    scripts/pose2vid.py:94-114 (31 for the face masks, 21 for the lips: scripts/audio2vid.py:455-462)."""
+    from . import hip
+    return hip.blur_mask_u8(masks_u8.contiguous(), kernel_size)
+
+
+def process_audio_emb_device(audio_emb: torch.Tensor) -> torch.Tensor:
+    from . import hip
+    return hip.window_stack(audio_emb.to(torch.float32).contiguous(), 2)

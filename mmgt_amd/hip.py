@@ -53,6 +53,11 @@ _SIGS = {
     "mmgt_activation": (c_int, [c_void_p, c_void_p, c_long, c_int, c_int, c_void_p]),
     "mmgt_smga_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float, c_float,
                                     c_float, c_float, c_int, c_int, c_void_p]),
+    "mmgt_blur_mask_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_resample_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "mmgt_window_stack": (c_int, [c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
+    "mmgt_frames_to_u8": (c_int, [c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_int, c_void_p]),
+    "mmgt_splat_keypoints": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p]),
     "mmgt_accumulate_window_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                             c_int, c_int, c_int, c_int, c_void_p]),
 }
@@ -384,4 +389,58 @@ def smga_ddim_step(pred_uncond, pred_cond, x, noise, guidance, sqrt_recip, sqrt_
     _check(lib().mmgt_smga_ddim_step(_ptr(pred_uncond), _ptr(pred_cond), _ptr(x), _ptr(_f32(noise, "noise")), _ptr(out), x.numel(),
                                      guidance, sqrt_recip, sqrt_recipm1, sqrt_next, c, sigma, int(last),
                                      dtype_code(pred_uncond.dtype), _stream()), "mmgt_smga_ddim_step")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------ conditioning / output
+
+def blur_mask_u8(masks, ksize):
+    """(L, H, W) uint8 -> (L, 64, 64) uint8 (see mmgt_blur_mask_u8)."""
+    _dev(masks)
+    assert masks.dtype == torch.uint8 and masks.dim() == 3 and masks.is_contiguous()
+    out = torch.empty((masks.shape[0], 64, 64), device=masks.device, dtype=torch.uint8)
+    _check(lib().mmgt_blur_mask_u8(_ptr(masks), _ptr(out), masks.shape[0], masks.shape[1], masks.shape[2], ksize, _stream()),
+           "mmgt_blur_mask_u8")
+    return out
+
+
+def resample_u8(x, D, bounds, coeffs, as_float=True):
+    """(L, S, S) uint8 -> (L, D, D) float32 in [0, 1] (or uint8) with PIL's integer coefficient tables (int32 device tensors)."""
+    _dev(x, bounds, coeffs)
+    assert x.dtype == torch.uint8 and x.dim() == 3 and x.shape[1] == x.shape[2] and x.is_contiguous()
+    assert bounds.dtype == torch.int32 and coeffs.dtype == torch.int32 and bounds.shape == (D, 2) and coeffs.shape[0] == D
+    out = torch.empty((x.shape[0], D, D), device=x.device, dtype=torch.float32 if as_float else torch.uint8)
+    _check(lib().mmgt_resample_u8(_ptr(x), _ptr(out) if as_float else None, None if as_float else _ptr(out), x.shape[0], x.shape[1], D,
+                                  _ptr(bounds), _ptr(coeffs), coeffs.shape[1], _stream()), "mmgt_resample_u8")
+    return out
+
+
+def window_stack(x, half=2):
+    """(L, ...) float32 -> (L, 2 half + 1, ...)."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    L = x.shape[0]
+    D = x.numel() // L
+    out = torch.empty((L, 2 * half + 1) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+    _check(lib().mmgt_window_stack(_ptr(x), _ptr(out), L, D, half, _stream()), "mmgt_window_stack")
+    return out
+
+
+def frames_to_u8(x, scale=0.5, shift=0.5):
+    """channels-last (N, H, W, cpad) -> (N, H, W, 3) uint8 = trunc(clamp(x * scale + shift, 0, 1) * 255)."""
+    _dev(x)
+    assert x.dim() == 4 and x.is_contiguous()
+    out = torch.empty(tuple(x.shape[:3]) + (3,), device=x.device, dtype=torch.uint8)
+    _check(lib().mmgt_frames_to_u8(_ptr(x), _ptr(out), x.shape[0] * x.shape[1] * x.shape[2], x.shape[3], scale, shift,
+                                   dtype_code(x.dtype), _stream()), "mmgt_frames_to_u8")
+    return out
+
+
+def splat_keypoints(kp, H, W, lohi, radius):
+    _dev(kp, lohi)
+    assert kp.dtype == torch.float32 and kp.dim() == 3 and kp.shape[2] == 3 and kp.is_contiguous() and lohi.dtype == torch.int32
+    C = lohi.shape[0]
+    out = torch.empty((kp.shape[0], H, W, C), device=kp.device, dtype=torch.uint8)
+    _check(lib().mmgt_splat_keypoints(_ptr(kp), _ptr(out), kp.shape[0], kp.shape[1], H, W, C, _ptr(lohi), radius, _stream()),
+           "mmgt_splat_keypoints")
     return out

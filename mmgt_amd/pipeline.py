@@ -7,7 +7,8 @@ in two HIP kernels on fp32 latents that never leave the GPU.
 
 Extensions through **kwargs (allowed by the reference signature, :365): `latents=` (inject initial noise, parity tests),
 `clip_image_embeds=` / `ref_image_latents=` / `reference_banks=` / `pose_features=` (hand over prologue results when the module
-is None: the CLIP / ReferenceNet / VAE-encode prologue is a "next" row of SURVEY.md section 8f), `decode=False`.
+is None), `decode=False`, `window_group=` / `cfg_split=` (window-parallel sampling of one long video over several GPUs).
+`output_type="uint8"` returns the frames as uint8 (b, f, H, W, 3), converted on the device (what save_videos_grid writes).
 """
 import math
 from dataclasses import dataclass
@@ -71,12 +72,14 @@ class Pose2VideoPipeline:
         latents = latents.to(device=device, dtype=torch.float32)
         return (latents * self.scheduler.init_noise_sigma).contiguous()
 
-    def decode_latents(self, latents, window_group=None):
+    def decode_latents(self, latents, window_group=None, uint8=False):
         """pipeline_pose2vid_long.py:112-125: frame-by-frame VAE decode of z / 0.18215, (x/2+0.5).clamp(0,1), fp32 CPU.
         With a window_group the frames (independent units) are dealt in contiguous runs to the ranks and all-gathered, so
         every rank returns the whole video ("VAE decode sharded by frame")."""
         if self.vae is None:
             raise RuntimeError("decode_latents needs a VAE (pass decode=False to get latents)")
+        if window_group is None and uint8:
+            return self.vae.decode_video_uint8(latents).cpu().numpy()      # (b, f, H, W, 3) uint8: save_videos_grid's frames
         if window_group is None:
             video = self.vae.decode_video(latents)           # (b, 3, f, H, W) fp32 in [0, 1] on the GPU
             return video.cpu().float().numpy()
@@ -281,8 +284,8 @@ class Pose2VideoPipeline:
             latents = self.interpolate_latents(latents, interpolation_factor, dev)
         if not kwargs.get("decode", True):
             return Pose2VideoPipelineOutput(videos=latents) if return_dict else latents
-        images = self.decode_latents(latents, kwargs.get("window_group"))
-        if output_type == "tensor":
+        images = self.decode_latents(latents, kwargs.get("window_group"), uint8=output_type == "uint8")
+        if output_type in ("tensor", "uint8"):
             images = torch.from_numpy(images)
         if not return_dict:
             return images

@@ -288,3 +288,17 @@ class AutoencoderKL:
             y = self.decode_nhwc(x)
             outs.append(hip.nhwc_to_ncfhw(y, b, 3, scale=0.5, shift=0.5, clamp01=True))
         return torch.cat(outs, dim=2)
+
+    def decode_video_uint8(self, latents, frames_per_batch=8):
+        """The output path on the device: latents (b, 4, f, h, w) -> uint8 frames (b, f, 8h, 8w, 3) on the GPU =
+        save_videos_grid's (x * 255).astype(uint8) (src/utils/util.py:148-160) of decode_latents' clamped frames, fused into
+        one conversion kernel per batch of frames: 4x fewer bytes cross PCIe than the fp32 (b, 3, f, H, W) video."""
+        lat = latents.to(self._device, torch.float32).contiguous()
+        b, c, f, h, ww = lat.shape
+        outs = []
+        for f0 in range(0, f, frames_per_batch):
+            chunk = lat[:, :, f0:f0 + frames_per_batch].contiguous()
+            x = hip.ncfhw_to_nhwc(chunk, 64, self._dtype, scale=1.0 / 0.18215)
+            y = hip.frames_to_u8(self.decode_nhwc(x), 0.5, 0.5)                    # ((b fc), H, W, 3)
+            outs.append(y.view(b, -1, *y.shape[1:]))
+        return torch.cat(outs, dim=1)

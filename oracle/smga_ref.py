@@ -57,7 +57,7 @@ def rotary(x, dim):
     ang = ang.repeat_interleave(2, dim=-1)                         # "... n -> ... (n r)", r = 2
     x2 = x.reshape(*x.shape[:-1], -1, 2)
     rot = torch.stack((-x2[..., 1], x2[..., 0]), dim=-1).reshape(x.shape)
-    return x * ang.cos() + rot * ang.sin()
+    return (x * ang.cos() + rot * ang.sin()).to(x.dtype)
 
 
 def mha(sd, p, q_in, k_in, v_in, heads):
@@ -137,7 +137,7 @@ def forward(sd, cfg, x, cond_frame, cond_embed, times, keep_cond: bool):
     pooled = cond_tokens.mean(dim=-2)
     h = _ln(sd, "non_attn_cond_projection.0", pooled)
     cond_hidden = _lin(sd, "non_attn_cond_projection.3", F.silu(_lin(sd, "non_attn_cond_projection.1", h)))
-    t_hidden = F.mish(_lin(sd, "time_mlp.1", sinusoidal_pos_emb(times, cfg.latent_dim)))
+    t_hidden = F.mish(_lin(sd, "time_mlp.1", sinusoidal_pos_emb(times, cfg.latent_dim).to(sd["time_mlp.1.weight"].dtype)))
     t = _lin(sd, "to_time_cond.0", t_hidden)
     t_tokens = _lin(sd, "to_time_tokens.0", t_hidden).reshape(x.shape[0], 2, cfg.latent_dim)
     t = t + (cond_hidden if keep_cond else sd["null_cond_hidden"].expand_as(cond_hidden))

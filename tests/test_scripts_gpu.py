@@ -1,0 +1,34 @@
+"""The counterpart scripts of SURVEY 8c end to end on the device, at BASELINE config-1 size (64x64 px, 8 frames, few DDIM steps):
+scripts/pose2vid.py --synthetic and scripts/audio2vid.py --synthetic (BASELINE config 3: SMGA audio->pose chained into Stage 2,
+device-side conditioning, uint8 output path)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, *args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script), *args], capture_output=True, text=True, cwd=ROOT,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_audio2vid_synthetic_chain_smga_into_stage2(tmp_path):
+    rec = _run("audio2vid.py", "--synthetic", "-W", "64", "-H", "64", "-L", "8", "--steps", "2", "--dtype", "bf16", "--out_dir",
+               str(tmp_path))
+    assert rec["video"] == [1, 8, 64, 64, 3] and rec["video_dtype"] == "torch.uint8" and rec["keypoints_finite"] and rec["slices"] == 1
+    assert rec["mask_levels"] == [[8, 64], [8, 16], [8, 4], [8, 1]]
+    frames = np.load(rec["saved"])
+    assert frames.shape == (8, 64, 64, 3) and frames.dtype == np.uint8 and frames.std() > 0
+
+
+def test_pose2vid_synthetic(tmp_path):
+    rec = _run("pose2vid.py", "--synthetic", "-W", "64", "-H", "64", "-L", "8", "--steps", "2", "--out_dir", str(tmp_path))
+    assert rec["video"] == [1, 3, 8, 64, 64] and rec["finite"]

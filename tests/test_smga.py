@@ -92,9 +92,7 @@ def test_hip_ddim_sampler_matches_reference_golden(gold, spec):
     out16 = GestureDiffusion(m16, 80, 402).ddim_sample((1, 80, 402), inp["cond_frame"][:1].cuda(), inp["cond"][:1].cuda(), noises=noises)
     d16 = (out16.cpu() - gold["ddim_sample"]).abs()
     sd16 = {k: (v.bfloat16() if v.is_floating_point() else v) for k, v in sc.smga_state_dict(spec).items()}
-
-    class _BF16Forward:                      # the oracle's forward with bf16 weights / activations, fp32 sampler state
-        pass
+    # floor: the oracle's guided forward with bf16 weights / activations, fp32 sampler state (what the HIP bf16 mode does)
     cfg = R.SMGAConfig()
     orig = R.guided_forward
     try:
