@@ -38,7 +38,7 @@ extern "C" {
 
 int mmgt_abi_version(void);
 const char* mmgt_last_error(void);
-/* Benchmark-only knob: "gemm_cfg" = 0 (heuristic tile choice) or 1, 3, 6, 9, 12 (force a tile configuration). */
+/* Benchmark-only knob: "gemm_cfg" = 0 (heuristic tile choice) or 1, 3, 6, 9, 12, 16, 17 (force a tile configuration). */
 int mmgt_tune(const char* key, int value);
 
 /* out[M,N] = epi(A[M,K] . W[N,K]^T):  v = acc + bias[n] + bias2[m / bias2_rows][n]; v = act(v);

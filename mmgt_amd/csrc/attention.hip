@@ -8,20 +8,10 @@
 // O^T[d][q] += V^T[d][key] . P^T[key][q] (guide section 3, "an accumulator tile as the next MFMA's operand").
 // K and V tiles (64 keys) are staged through LDS and shared by the workgroup's waves.
 #include "common.h"
+#include "attn_common.h"
 #include "mmgt_hip.h"
 
 namespace {
-
-struct AttnParams {
-  const char *q, *k, *v, *k2, *v2;
-  char* o;
-  long q_bs0, q_bs1, q_ts, k_bs0, k_bs1, k_ts, v_bs0, v_bs1, v_ts, o_bs0, o_bs1, o_ts;
-  long k2_bs, k2_ts, v2_bs, v2_ts;
-  int bdiv, k2_bdiv, nk2, seg2_first_batch;
-  int nq, nk;
-  int nqb, npairs, heads;
-  float scale_log2e;
-};
 
 // KT = keys per LDS tile: 64, or 32 for the short key sets (temporal attention over <= 32 frames, the 32 audio tokens),
 // where a 64-key tile would spend half its MFMAs, exponentials and LDS on masked keys.
@@ -38,7 +28,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
   constexpr int DT = (HD + 31) / 32;            // 32-row tiles of O^T
   constexpr int HDV = DT * 32;
   constexpr int RSK = HDK * ESZ + 16;           // K tile row stride (bytes): odd multiple of 16 -> conflict-free b128
-  constexpr int RSV = VT ? (KT * ESZ + (ESZ == 2 ? 8 : 16)) : (HDV * ESZ + 16);
+  // bf16 V^T rows hold their keys PERMUTED inside every group of 16, [0-3, 8-11 | 4-7, 12-15]: the order the P fragment of a lane
+  // half wants them, so a V fragment is ONE ds_read_b128.  (Two 8-byte reads 16 bytes apart are fused by hipcc into a
+  // ds_read2_b64, which the LDS serves at a quarter of the b128 rate -- 16 LDS cycles per wave instruction against 4: with
+  // twelve waves per CU the V^T fragment reads alone kept the LDS busy longer than a tile's MFMAs + softmax took, which is why
+  // the matrix and vector pipes never overlapped in the round-1 counters.)  144-byte rows: an odd multiple of 16 bytes.
+  constexpr bool VPERM = VT && ESZ == 2;
+  constexpr int RSV = VT ? (KT * ESZ + 16) : (HDV * ESZ + 16);
   constexpr int VROWS = VT ? HDV : KT;
   constexpr int NT = NW * 64;
   // The kernel is VALU-bound at head_dim 40, so two per-score VALU operations ride in the MFMAs' zero padding instead:
@@ -196,10 +192,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
   };
   auto store_v = [&](char* lV, int idx, u32x4 v) {
     const int row = idx / NVV, vc = idx - row * NVV;
-    if (VT && ESZ == 2) {  // 136-byte rows: two 8-byte stores keep natural alignment
-      u32x2* dst = reinterpret_cast<u32x2*>(lV + row * RSV + vc * 16);
+    if (VPERM) {  // vector vc = keys 8 vc .. 8 vc + 7: its halves go to 8-byte slots (vc & 1) and 2 + (vc & 1) of key group vc >> 1
+      u32x2* dst = reinterpret_cast<u32x2*>(lV + row * RSV + (vc >> 1) * 32 + (vc & 1) * 8);
       dst[0] = (u32x2){v[0], v[1]};
-      dst[1] = (u32x2){v[2], v[3]};
+      dst[2] = (u32x2){v[2], v[3]};
     } else {
       *reinterpret_cast<u32x4*>(lV + row * RSV + vc * 16) = v;
     }
@@ -405,10 +401,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
           if (VT) {
             const T* vp = reinterpret_cast<const T*>(lV + d * RSV) + kbase;
             if (ESZ == 2) {
-              const u32x2 lo = *reinterpret_cast<const u32x2*>(vp);
-              const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + 8);
-              union { u32x4 u; Frag<T> f; } cv;
-              cv.u = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+              union { u32x4 u; Frag<T> f; } cv;    // the lane's 8 keys are 16 contiguous bytes of the permuted row
+              cv.u = *reinterpret_cast<const u32x4*>(lV + d * RSV + (sub * 2 + s2) * 32 + lh * 16);
               vf = cv.f;
             } else {
               const f32x4 lo = *reinterpret_cast<const f32x4*>(vp);
@@ -470,6 +464,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
 
 template <typename T, int HD>
 int launch_hd(AttnParams p, int batch, int heads, int vt, hipStream_t s) {
+
   // Short sequences (temporal attention, <= 32 frames) use one wave per workgroup; spatial sequences four.
   p.heads = heads;
   p.npairs = batch * heads;

@@ -41,6 +41,10 @@ def parse_args():
     p.add_argument("--synthetic", action="store_true")
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-decode", action="store_true")
+    p.add_argument("--clip-parallel", action="store_true",
+                   help="BASELINE config 4: one clip per rank of a torch.distributed.run launch.  Rank 0 builds the weights and "
+                        "broadcasts them (RCCL, a few large buckets), rank r samples clip r (seed + r), the uint8 frames are "
+                        "gathered on rank 0; no collective inside the sampling loop (SURVEY 8e)")
     p.add_argument("--window-parallel", action="store_true",
                    help="one long video over all ranks of a torch.distributed.run launch: the windows of every DDIM step are "
                         "dealt to the ranks, one RCCL all-gather per round (SURVEY 8e, config 5)")
@@ -52,6 +56,39 @@ def build_synthetic(dev, dtype):
     return build_synthetic_pipeline(dev, dtype)
 
 
+def build_synthetic_broadcast(dev, dtype, rank):
+    """--clip-parallel: rank 0 holds the checkpoint (here: the hash-seeded synthetic one), every other rank receives it through
+    mmgt_amd.parallel.broadcast_state_dict -- the north-star's "broadcast weights" -- and packs it locally."""
+    from mmgt_amd import parallel
+    from mmgt_amd.clip_vision import CLIPVisionModelWithProjection, clip_vision_spec
+    from mmgt_amd.pipeline import Pose2VideoPipeline
+    from mmgt_amd.reference_unet import UNet2DConditionModel
+    from mmgt_amd.scheduler import DDIMScheduler
+    from mmgt_amd.side_models import PoseGuider
+    from mmgt_amd.synthetic import synth_state_dict
+    from mmgt_amd.unet3d import UNet3DConditionModel
+    from mmgt_amd.unet3d_spec import unet2d_reference_spec, unet3d_spec
+    from mmgt_amd.vae import AutoencoderKL, vae_decoder_spec, vae_encoder_spec
+    pg = PoseGuider(320, block_out_channels=(16, 32, 96, 256), device=dev, dtype=dtype)
+    vspec = vae_decoder_spec()
+    vspec.update(vae_encoder_spec())
+    parts = [("unet", unet3d_spec(), "", UNet3DConditionModel(device=dev, dtype=dtype)),
+             ("refnet", unet2d_reference_spec(), "refnet.", UNet2DConditionModel(device=dev, dtype=dtype)),
+             ("pose", dict(pg.spec), "pose_guider.", pg),
+             ("vae", vspec, "vae.", AutoencoderKL(device=dev, dtype=dtype)),
+             ("clip", clip_vision_spec(), "clip.", CLIPVisionModelWithProjection(device=dev, dtype=dtype))]
+    mods = {}
+    for name, spec, prefix, mod in parts:
+        sd = synth_state_dict(spec, prefix=prefix, device=dev) if rank == 0 else None
+        sd = parallel.broadcast_state_dict(sd, spec, src=0, device=dev, dtype=torch.float32)
+        mod.load_state_dict(sd)
+        mods[name] = mod
+        del sd
+    mods["unet"].enable_gradient_checkpointing()
+    return Pose2VideoPipeline(vae=mods["vae"], image_encoder=mods["clip"], reference_unet=mods["refnet"], denoising_unet=mods["unet"],
+                              pose_guider=mods["pose"], scheduler=DDIMScheduler())
+
+
 def main():
     a = parse_args()
     if not torch.cuda.is_available():
@@ -60,7 +97,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     rank = 0
-    if a.window_parallel:
+    if a.window_parallel or a.clip_parallel:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)        # RANK / WORLD_SIZE / MASTER_* from torch.distributed.run
         rank = dist.get_rank()
@@ -70,13 +107,15 @@ def main():
                          "build does not include; see INTEGRATION.md for wiring mmgt_amd into the reference's own script")
     from mmgt_amd.synthetic import hash_uniform, synth_masks
     t0 = time.time()
-    pipe = build_synthetic(dev, dtype)                   # same hash-seeded weights on every rank
+    # window-parallel: the same hash-seeded weights are built on every rank; clip-parallel: rank 0 broadcasts them
+    pipe = build_synthetic_broadcast(dev, dtype, rank) if a.clip_parallel else build_synthetic(dev, dtype)
     t_build = time.time() - t0
     lat = a.H // 8
-    gen = torch.manual_seed(a.seed)                           # :171
+    clip_id = rank if a.clip_parallel else 0                  # clip-parallel: rank r samples its own clip
+    gen = torch.manual_seed(a.seed + clip_id)                 # :171
     lips, face = synth_masks("p2v.lips", a.L, lat), synth_masks("p2v.face", a.L, lat)
     full = [1 + l for l in lips]                              # audio2vid convention (scripts/audio2vid.py:470-476)
-    pose = hash_uniform("p2v.pose", (1, 3, a.L, a.H, a.W), 0.5) + 0.5
+    pose = hash_uniform(f"p2v.pose{clip_id or ''}", (1, 3, a.L, a.H, a.W), 0.5) + 0.5
     audio = torch.zeros(1, a.L, 32, 768)                      # pose2vid runs with null audio (:279)
     from PIL import Image
     ref_img = Image.fromarray(((hash_uniform("p2v.ref", (a.H, a.W, 3), 0.5) + 0.5) * 255).clamp(0, 255).to(torch.uint8).numpy())
@@ -88,6 +127,16 @@ def main():
                window_group=True if a.window_parallel else None)
     torch.cuda.synchronize()
     dt = time.time() - t0
+    if a.clip_parallel:
+        from mmgt_amd import parallel
+        mine = torch.as_tensor(out.videos).to(dev)            # gather the decoded clips on rank 0 ("gather frames")
+        clips = parallel.gather_frames(mine, dst=0)
+        world = dist.get_world_size()
+        dist.destroy_process_group()
+        if rank != 0:
+            return
+        out.videos = torch.cat([c.cpu() for c in clips], dim=0)
+        print(json.dumps({"clip_parallel_ranks": world, "clips": int(out.videos.shape[0])}))
     if a.window_parallel:
         dist.destroy_process_group()
         if rank != 0:                                         # every rank holds the same video; rank 0 writes it

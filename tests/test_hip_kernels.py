@@ -297,7 +297,7 @@ def _ref_attn(q, k, v, scale):
 
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("hd,nq,nk2", [(40, 64, 64), (40, 200, 200), (80, 16, 16), (160, 4, 4), (160, 1, 1),
-                                       (80, 300, 0), (40, 1024, 1024)])
+                                       (80, 300, 0), (40, 1024, 1024), (80, 512, 256), (40, 256, 0), (40, 512, 64)])
 @pytest.mark.parametrize("vt", [False, True])
 def test_attention_spatial_with_bank(dt, hd, nq, nk2, vt):
     """Self-attention over nq tokens; the second half of the batch also attends to a per-CFG-row bank of nk2 keys."""
@@ -338,6 +338,42 @@ def test_attention_spatial_with_bank(dt, hd, nq, nk2, vt):
                   seg2_first_batch=frames)
     hip.attention(q, k, vv, out, batch=B, heads=heads, hd=hd, nq=nq, nk=nq, scale=scale, q_str=(nq * inner, 0, inner),
                   k_str=(nq * inner, 0, inner), v_str=v_str, o_str=(nq * inner, 0, inner), v_transposed=vt, **kw)
+    torch.testing.assert_close(out.double(), ref, **tol(dt))
+
+
+@pytest.mark.parametrize("hd", [40, 80])
+def test_attention_online_softmax_rescale_branch_is_forced(hd):
+    """The rare, data-dependent branch of the online softmax (guide rule 26): one key row per later tile is spiked against one query
+    so that query's running maximum jumps mid-sequence (own keys and bank keys); full-tensor check against fp64, bf16, V transposed,
+    whole 64-key tiles -- the production configuration of the spatial self-attention."""
+    from mmgt_amd import hip
+    dt = torch.bfloat16
+    heads, B, nq, nk2 = 2, 4, 512, 256
+    inner = heads * hd
+    q = rnd("q2", (B, nq, inner), 1.0, dt)
+    k = rnd("k2", (B, nq, inner), 1.0, dt)
+    v = rnd("v2", (B, nq, inner), 1.0, dt)
+    kb = rnd("kb2", (2, nk2, inner), 1.0, dt)
+    vb = rnd("vb2", (2, nk2, inner), 1.0, dt)
+    for tile, qrow in ((1, 5), (3, 77), (6, 300)):          # spike: key 64 * tile + 9 aligned with query qrow, x 6
+        k[:, 64 * tile + 9] = (q[:, qrow].float() * 6).to(dt)
+    kb[:, 130] = (q[2, 411].float() * 8).to(dt)
+    scale = hd ** -0.5
+    split = lambda t: t.double().reshape(t.shape[0], t.shape[1], heads, hd).permute(0, 2, 1, 3)
+    refs = []
+    for b in range(B):
+        kk, vv = k[b:b + 1], v[b:b + 1]
+        if b >= 2:
+            kk = torch.cat([kk, kb[(b - 0) // 2][None]], 1)
+            vv = torch.cat([vv, vb[(b - 0) // 2][None]], 1)
+        refs.append(_ref_attn(split(q[b:b + 1]), split(kk), split(vv), scale))
+    ref = torch.cat(refs).permute(0, 2, 1, 3).reshape(B, nq, inner)
+    vT, vbT = v.transpose(1, 2).contiguous(), vb.transpose(1, 2).contiguous()
+    out = torch.empty_like(q)
+    hip.attention(q, k, vT, out, batch=B, heads=heads, hd=hd, nq=nq, nk=nq, scale=scale, q_str=(nq * inner, 0, inner),
+                  k_str=(nq * inner, 0, inner), v_str=(vT.stride(0), 0, vT.stride(1)), o_str=(nq * inner, 0, inner),
+                  v_transposed=True, k2=kb, v2=vbT, k2_str=(kb.stride(0), inner), v2_str=(vbT.stride(0), vbT.stride(1)),
+                  k2_bdiv=2, nk2=nk2, seg2_first_batch=2)
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
 

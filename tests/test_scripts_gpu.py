@@ -32,3 +32,16 @@ def test_audio2vid_synthetic_chain_smga_into_stage2(tmp_path):
 def test_pose2vid_synthetic(tmp_path):
     rec = _run("pose2vid.py", "--synthetic", "-W", "64", "-H", "64", "-L", "8", "--steps", "2", "--out_dir", str(tmp_path))
     assert rec["video"] == [1, 3, 8, 64, 64] and rec["finite"]
+
+
+def test_pose2vid_clip_parallel_single_rank_launch(tmp_path):
+    """BASELINE config 4 plumbing on the one GPU of the test box: torch.distributed.run with one rank -- weights broadcast
+    (RCCL), the rank's clip sampled, frames gathered on rank 0.  More ranks only add independent clips."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "scripts", "pose2vid.py"), "--synthetic",
+                        "--clip-parallel", "-W", "64", "-H", "64", "-L", "8", "--steps", "2", "--out_dir", str(tmp_path)],
+                       capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [json.loads(l) for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert lines[0] == {"clip_parallel_ranks": 1, "clips": 1} and lines[-1]["video"] == [1, 3, 8, 64, 64] and lines[-1]["finite"]
