@@ -27,25 +27,27 @@ def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]], spec: Dict[str, 
     out: Dict[str, torch.Tensor] = {}
     i = 0
     esz = torch.empty((), dtype=dtype).element_size()
+    al = max(1, 16 // esz)                        # every tensor starts 16-byte aligned inside its bucket (the kernels' vector width)
+    slot = lambda n: (_numel(spec[n]) + al - 1) // al * al
     while i < len(names):
         j, nbytes = i, 0
-        while j < len(names) and (j == i or nbytes + _numel(spec[names[j]]) * esz <= bucket_bytes):
-            nbytes += _numel(spec[names[j]]) * esz
+        while j < len(names) and (j == i or nbytes + slot(names[j]) * esz <= bucket_bytes):
+            nbytes += slot(names[j]) * esz
             j += 1
-        total = sum(_numel(spec[n]) for n in names[i:j])
-        flat = torch.empty((total,), device=device, dtype=dtype)
+        total = sum(slot(n) for n in names[i:j])
+        flat = torch.zeros((total,), device=device, dtype=dtype)
         if rank == src:
             off = 0
             for n in names[i:j]:
                 k = _numel(spec[n])
                 flat[off:off + k] = sd[n].reshape(-1).to(device=device, dtype=dtype)
-                off += k
+                off += slot(n)
         dist.broadcast(flat, src=src)
         off = 0
         for n in names[i:j]:
             k = _numel(spec[n])
             out[n] = flat[off:off + k].view(tuple(spec[n]))
-            off += k
+            off += slot(n)
         i = j
     return out
 
