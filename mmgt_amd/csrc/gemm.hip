@@ -786,7 +786,7 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
   if (geglu && (cfg == 3 || cfg == 12)) cfg = 1;   // GEGLU pairs need 64-column wave tiles
   if (cfg == 16 || cfg == 17) {   // gemm16.hip, 256 / 320 columns: bf16, plain vectorised epilogue only (GEGLU: 256); else fall back
     if (std::is_same<T, bf16_t>::value && ep.fast && ep.act <= (cfg == 16 ? 1 : 0) && !ep.row_scale && ep.alpha == 1.f &&
-        !ep.bias_post)
+        !ep.bias_post && (((uintptr_t)ep.bias | (uintptr_t)ep.bias2) & 15) == 0 && N % 4 == 0)   // (bias vectors travel by 16-byte DMA)
       return mmgt_gemm16_launch(MODE, cfg == 16 ? 256 : 320, &ad, W, bsw, &ep, M, N, K, batch, s);
     cfg = cfg == 16 ? 9 : geglu ? 1 : 12;   // (GEGLU pairs need 64-column wave tiles: not the 320-column tile)
   }

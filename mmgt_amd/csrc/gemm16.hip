@@ -45,7 +45,7 @@ __device__ __forceinline__ acc4 mma16(s16x8 a, s16x8 b, acc4 c) {
 
 template <int MODE, int BN>
 __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __restrict__ W, long bsw, Epi ep, int M, int N,
-                                                        int K, int tiles_m, int tiles_n) {
+                                                        int K, int tiles_m, int tiles_n, unsigned long long* trace) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   typedef bf16_t T;
   static_assert(BN == 256 || BN == 320, "BN");
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
   constexpr int CPR = 8, RPD = 8;               // 16-byte chunks per row; rows per 1-KiB DMA piece
   constexpr int GA = BM / RPD / NW, GB = BN / RPD / NW;   // pieces per wave and chunk: 4 x A + 4 or 5 x W
   constexpr int NPH = BN / 64, NT = BN / 32;    // phases per chunk; accumulator tiles per row tile
+  constexpr int BIAS_OFF = 2 * STAGE_BYTES, BIAS_ARR = 2048, NBP = BN == 256 ? 1 : 2;   // bias | bias2 row 0 | bias2 row 1: 512 floats each, NBP pieces
   auto swz = [](int row) { return (row >> 1) & 7; };
 
   const int nwg = tiles_m * tiles_n;
@@ -62,6 +63,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
   const int wr = wid >> 2;                      // wave group: waves 0-3 / 4-7 (SIMD partners w, w + 4 are in different groups)
   const int wm = wid >> 1, wn = wid & 1;        // 4 x 2 wave grid: 64 rows x BN / 2 columns per wave
   const int lm = lane & 15, lq = lane >> 4;
+  int trace_n = 0;
+  auto stamp = [&](int k) {   // debug: wave 0 / 4 of every workgroup log the 100-MHz clock at tile phase k
+    if (trace && (wid & 3) == 0 && lane == 0 && trace_n < 32) trace[(((long)blockIdx.x * 32 + trace_n) * 2 + wr) * 4 + k] = wall_clock64();
+  };
 
   auto decode = [&](int v, int& tm, int& tn) {  // XCD-aware virtual tile order (see gemm.hip)
     const int q = nwg >> 3, r = nwg & 7, x = v & 7;
@@ -150,6 +155,32 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
     constexpr int I = decltype(Ic)::value;
     blds16(rW, RPD * I < limW ? woff[I & 1] : DMA_POISON, ch * ROWB + I * w_step, smem + stage * STAGE_BYTES + A_BYTES + (wid * GB + I) * 1024);
   };
+  // Bias.  The accumulators of a tile START from bias[n] + bias2[batch row of m][n] instead of zero, read from an LDS copy of the
+  // tile's bias vectors (bias | the at most two bias2 rows a tile touches: 512 floats each).  The copy of the NEXT tile is
+  // fetched by DMA pieces of 256 floats that wave group 0 issues in phase 1 of a tile's first chunk: by then every wave has
+  // initialised its accumulators from the current copy (group 1 has arrived at its phase-0 barrier), and the pieces are older
+  // than the chunk's counted A pieces, so they have landed behind that chunk's last barrier.  (Columns >= N read as zeros.)
+  const bool has_bias = ep.bias != nullptr || ep.bias2 != nullptr;
+  const int b2div = ep.bias2 ? ep.bias2_rows : 0x7fffffff;
+  auto issue_bias = [&](int v) {
+    int tm, tn;
+    decode(v, tm, tn);
+    int mlast = tm * BM + BM - 1;
+    if (mlast >= M) mlast = M - 1;
+    const int r0 = (tm * BM) / b2div, r1 = mlast / b2div;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = wid + 4 * u;
+      if (q < 3 * NBP) {
+        const int arr = q / NBP, pc = q - arr * NBP;
+        const float* src = arr == 0 ? ep.bias : ep.bias2 ? ep.bias2 + (long)(arr == 1 ? r0 : r1) * N : nullptr;
+        if (src) {
+          const int col = tn * BN + pc * 256 + lane * 4;
+          blds16(dma_rsrc(src), col < N ? (unsigned)col * 4u : DMA_POISON, 0, smem + BIAS_OFF + arr * BIAS_ARR + pc * 1024);
+        }
+      }
+    }
+  };
   using std::integral_constant;
 
   // ---- fragment read addressing: lane (lm, lq) reads row base + 16 t + lm, 16-byte chunk (4 ks + lq) ^ swz; the swizzle
@@ -203,6 +234,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
   };
   // prologue: chunk 0 whole, the A half of chunk 1 (the A stream runs two chunks ahead of the MFMAs, the W stream one)
   if (total > 0) {
+    if (wr == 0 && has_bias) issue_bias(blockIdx.x);
     prepA(ichA);
     for_n(integral_constant<int, GA>{}, [&](auto i) { issueA(0, i); });
     advanceA();
@@ -226,17 +258,36 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
     const int row0 = tm * BM + wm * 64, col0 = tn * BN + wn * (BN / 2);
 
     acc4 acc[4][NT];
+    if (has_bias) {
+      const acc4* lb = reinterpret_cast<const acc4*>(smem + BIAS_OFF) + wn * (BN / 8) + lq;   // this lane's columns 16 j + 4 lq + r
+      const int b2r0 = (tm * BM) / b2div;
+      bool second[4];                      // row 16 i + lm of the wave belongs to the tile's second bias2 row
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        int m = row0 + 16 * i + lm;
+        if (m >= M) m = M - 1;
+        second[i] = ep.bias2 && m / b2div != b2r0;
+      }
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = (acc4)(0.f);
+      for (int j = 0; j < NT; ++j) {
+        const acc4 b = ep.bias ? lb[4 * j] : (acc4)(0.f);
+        if (ep.bias2) {
+          const acc4 r0v = lb[BIAS_ARR / 16 + 4 * j], r1v = lb[2 * BIAS_ARR / 16 + 4 * j];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i][j] = b + (second[i] ? r1v : r0v);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i][j] = b;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (acc4)(0.f);
+    }
 
-    const int b2div = ep.bias2 ? ep.bias2_rows : 0x7fffffff;
-    const int b2r0 = (tm * BM) / b2div;
-    int mlast = tm * BM + BM - 1;
-    if (mlast >= M) mlast = M - 1;
-    const bool b2two = mlast / b2div > b2r0;
-
+    stamp(0);
     s16x8 fa[4][2], fb[2][2];   // [tile][ks]
     for (int ch = 0; ch < nchunks; ++ch) {
       const char* st = smem + sc * STAGE_BYTES;
@@ -260,6 +311,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
             fa[t][1] = *reinterpret_cast<const s16x8*>(pa + roff1);
           }
         }
+        if (P == 1 && ch == 0 && wr == 0 && has_bias && vt + G < nwg) issue_bias(vt + G);
         for_n(integral_constant<int, 2>{}, [&](auto Uc) {     // pieces 2 P, 2 P + 1 of [W 0 .. W GB-1 | A 0 .. A GA-1]
           constexpr int S = 2 * P + decltype(Uc)::value;
           if constexpr (S < GB) {
@@ -299,56 +351,37 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
     // (where it would only lengthen live ranges: the loop runs at the register limit)
     int lme = lm, lqe = lq;
     asm volatile("" : "+v"(lme), "+v"(lqe));
-    // ---- bias[n] + bias2[batch row][n] as one more MFMA: D[n][m] += sum_c bsum[c][n] * sel[c][m] (two bias2 rows at most per
-    // tile; values split into a bf16 head + tail so the sum is exact to ~2^-17 relative)
-    if (ep.bias || ep.bias2) {
-      s16x8 fsel[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int m = row0 + 16 * i + lme;
-        if (m >= M) m = M - 1;
-        const int c = m / b2div - b2r0;
-        const short one = (short)0x3F80;
-        const short s0 = (lqe == 0 && c == 0) ? one : (short)0, s1 = (lqe == 0 && c == 1) ? one : (short)0;
-        fsel[i] = (s16x8){s0, s0, s1, s1, 0, 0, 0, 0};
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = col0 + 16 * j + lme;
-        const bool ok = n < N && lqe == 0;
-        const float b = (ok && ep.bias) ? ep.bias[n] : 0.f;
-        const float b0 = b + ((ok && ep.bias2) ? ep.bias2[(long)b2r0 * N + n] : 0.f);
-        const float b1 = b + ((ok && ep.bias2 && b2two) ? ep.bias2[(long)(b2r0 + 1) * N + n] : 0.f);
-        const bf16_t h0 = f32_to_bf16(b0), h1 = f32_to_bf16(b1);
-        const s16x8 fbias = (s16x8){(short)h0, (short)f32_to_bf16(b0 - bf16_to_f32(h0)), (short)h1,
-                                    (short)f32_to_bf16(b1 - bf16_to_f32(h1)), 0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = mma16(fbias, fsel[i], acc[i][j]);
-      }
-    }
-
-    // ---- epilogue from registers.  D = W_frag x A_frag: lane (lm, lq) holds output row m = 16 i + lm and, per accumulator
-    // tile j, the four columns 16 j + 4 lq + r.  v_permlane16_swap exchanges the odd 16-lane rows of tile j with the even rows
-    // of tile j + 1, after which the lane owns 8 consecutive columns 16 j + 16 (lq & 1) + 8 (lq >> 1) .. + 7: one 16-byte
-    // store per lane and tile pair, 64 contiguous bytes per output row and instruction.
+    stamp(1);
     T* out = reinterpret_cast<T*>(ep.out) + (long)bz * ep.bso;
     const T* res = ep.residual ? reinterpret_cast<const T*>(ep.residual) + (long)bz * ep.bsr : nullptr;
     const bool geglu = ep.act == 1;              // BN = 256 only (host): a wave's 128 columns = two packed [32 h | 32 gate] groups
     const int cofs = 16 * (lqe & 1) + 8 * (lqe >> 1);
     constexpr int NPAIR = NT / 2;
+    // Residual vectors (clamped addresses, no branches around the loads).  256 columns: row tile 0's are requested here, in
+    // front of the bias loads, and row tile i + 1's before row tile i is worked: the tile end exposes one memory round trip.
+    // 320 columns: no registers to spare (more pressure here spills main-loop state), each row tile waits for its own vectors.
+    u32x4 rv[BN == 256 ? 2 : 1][NPAIR];
+    auto load_res = [&](int i, u32x4* dst) {
+      const int m = row0 + 16 * i + lme;
+      const int mc = m < M ? m : M - 1;
+#pragma unroll
+      for (int jp = 0; jp < NPAIR; ++jp) {
+        int nc = col0 + 32 * jp + cofs;
+        nc = nc < N ? nc : N - 8;
+        dst[jp] = *reinterpret_cast<const u32x4*>(res + (long)mc * ep.ldr + nc);
+      }
+    };
+    if (BN == 256 && res) load_res(0, rv[0]);
+    stamp(2);
+    // ---- epilogue from registers.  D = W_frag x A_frag: lane (lm, lq) holds output row m = 16 i + lm and, per accumulator
+    // tile j, the four columns 16 j + 4 lq + r.  v_permlane16_swap exchanges the odd 16-lane rows of tile j with the even rows
+    // of tile j + 1, after which the lane owns 8 consecutive columns 16 j + 16 (lq & 1) + 8 (lq >> 1) .. + 7: one 16-byte
+    // store per lane and tile pair, 64 contiguous bytes per output row and instruction.
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = row0 + 16 * i + lme;
-      // the row tile's residual vectors are requested together (clamped addresses, no branches around the loads)
-      u32x4 rv[NPAIR];
       if (res) {
-        const int mc = m < M ? m : M - 1;
-#pragma unroll
-        for (int jp = 0; jp < NPAIR; ++jp) {
-          int nc = col0 + 32 * jp + cofs;
-          nc = nc < N ? nc : N - 8;
-          rv[jp] = *reinterpret_cast<const u32x4*>(res + (long)mc * ep.ldr + nc);
-        }
+        if (BN == 256 ? i < 3 : true) load_res(BN == 256 ? i + 1 : i, rv[BN == 256 ? (i + 1) & 1 : 0]);
       }
 #pragma unroll
       for (int jp = 0; jp < NPAIR; ++jp) {
@@ -372,7 +405,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
         const long ocol = geglu ? (long)(col0 >> 1) + 16 * jp + cofs : (long)nacc;
         if (res) {
           union { u32x4 u; bf16_t e[8]; } r8;
-          r8.u = rv[jp];
+          r8.u = rv[BN == 256 ? i & 1 : 0][jp];
 #pragma unroll
           for (int e = 0; e < 8; ++e) o8[e] += bf16_to_f32(r8.e[e]);
         }
@@ -381,15 +414,19 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
               (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])};
       }
     }
+    stamp(3);
+    ++trace_n;
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();   // group 0 meets group 1's last barrier
 }
+
+unsigned long long* g_trace = nullptr;
 
 template <int MODE, int BN>
 int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
   constexpr int BM = 256;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const size_t lds = (size_t)2 * (BM + BN) * 128;
+  const size_t lds = (size_t)2 * (BM + BN) * 128 + 3 * 2048;
   auto kern = gemm16_kernel<MODE, BN>;
   static int resident = 0;
   if (!resident) {
@@ -410,12 +447,15 @@ int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int
   gx = (gx + 7) / 8 * 8;
   if (gx > (long)tiles_m * tiles_n) gx = (long)tiles_m * tiles_n;
   dim3 grid((unsigned)gx, 1, batch);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, ad, reinterpret_cast<const char*>(W), bsw, ep, M, N, K, tiles_m, tiles_n);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, ad, reinterpret_cast<const char*>(W), bsw, ep, M, N, K, tiles_m, tiles_n, g_trace);
   MMGT_LAUNCH_CHECK();
   return 0;
 }
 
 }  // namespace
+
+// Debug (tools/trace_gemm16.py): a device buffer of [grid][32 tiles][2 groups][4 stamps] u64 receives 100-MHz time stamps.
+extern "C" void mmgt_gemm16_set_trace(void* p) { g_trace = reinterpret_cast<unsigned long long*>(p); }
 
 // Entry for gemm.hip's dispatcher.  Preconditions (checked there): bf16, vectorised epilogue (ep.fast), act in {none, GEGLU}
 // (GEGLU with bn = 256 only), no row scale / alpha / post-scale bias, K % 64 == 0.

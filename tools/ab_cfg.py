@@ -55,6 +55,8 @@ def conv_case(nb, h, cin, cout, up=False):
 
 
 SETS = {
+    "geglu": lambda: [gemm_case(196608, 2560, 320, act=1), gemm_case(196608, 1280, 320), gemm_case(196608, 2560, 320),
+                      gemm_case(196608, 2560, 640, act=1), gemm_case(196608, 2560, 1280, act=1), gemm_case(196608, 1280, 640)],
     "big": lambda: [gemm_case(8192, 8192, 8192, bias=False), gemm_case(4096, 4096, 4096, bias=False)],
     "step": lambda: [
         gemm_case(196608, 2560, 320, act=1), gemm_case(49152, 5120, 640, act=1), gemm_case(12288, 10240, 1280, act=1),

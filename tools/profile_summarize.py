@@ -44,7 +44,7 @@ if os.path.exists(log):
         if line.startswith('{"metric"'):
             bench_line = line.strip()
 with open(os.path.join(out, f"bench_steps3_summary_{tag}.md"), "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline  (round 1, build {tag})\n\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline  (build {tag})\n\n")
     f.write(f"{steps_total} denoise steps (1 warm-up + 3 timed) at 512x512x24 bf16 on one MI355X; per-step = total / {steps_total}. "
             f"Raw stats: bench_steps3_kernel_stats_{tag}.csv; HBM-side traffic from PMC: pmc_traffic_{tag}.json.\n\n")
     f.write("| kernel | launches/step | ms/step | avg us |\n|---|---|---|---|\n")
