@@ -769,16 +769,19 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     // cfg 16 (gemm16.hip: 256x256, 16x16x32 MFMAs, two wave groups in ping-pong; bf16 only) replaces cfg 9 wherever that ran and
     // takes the convs whose width fills 256-column tiles: measured (tools/ab_cfg.py, one process) -17..-19% on the 16x16-level
     // convs and the 16 -> 32 up-conv, -7..-10% on the long-K / wide dense shapes, -7% on the 32 -> 64 up-conv (N = 640: three
-    // tiles with 17% padding still beat the 128x320 tile); it loses on K = 320 GEGLU (epilogue-bound) and on N = 320 / 640.
+    // tiles with 17% padding still beat the 128x320 tile); K = 320 GEGLU too since the two wave groups run their epilogues side by
+    // side (-9%); it loses on N = 320 / 640.
     // cfg 17 = the same core with a 256x320 tile (every width of the UNet is a multiple of 320): the L0 / L1 convs and the
-    // 32 -> 64 / 16 -> 32 up-convs (-2..-22%), and the dense N = 320 / 640 / 960 shapes of the 64x64 level (-6..-27%).
+    // 32 -> 64 / 16 -> 32 up-convs (-2..-22%), the dense N = 320 / 640 / 960 shapes of the 64x64 level (-6..-27%) and the long-K,
+    // residual or N = 1280 shapes of the 32x32 level (-5..-8%).
     const bool b16 = std::is_same<T, bf16_t>::value;
     if (MODE == 1) {
       if (b16 && N % 320 == 0 && M >= 49152) cfg = 17;
       else if (b16 && N % 256 == 0 && tiles256sq >= 192) cfg = 16;
       else cfg = (N % 320 == 0 && M >= 49152) ? 12 : big_ok ? 9 : tiles128 < 512 ? 3 : 1;
     } else if (b16 && !geglu && N % 320 == 0 && N <= 960 && M >= 131072) cfg = 17;
-    else if (sq_ok) cfg = (b16 && !(geglu && K < 640)) ? 16 : 9;
+    else if (b16 && !geglu && N % 320 == 0 && N <= 1280 && M >= 49152 && (K >= 1280 || ep.residual || N == 1280)) cfg = 17;   // 32x32 level
+    else if (sq_ok) cfg = b16 ? 16 : 9;
     else if (geglu || K >= 1280) cfg = tiles256 >= 256 ? 6 : 1;
     else if (M >= 131072 && N >= 640) cfg = 6;
     else cfg = 1;

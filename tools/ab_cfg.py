@@ -55,6 +55,13 @@ def conv_case(nb, h, cin, cout, up=False):
 
 
 SETS = {
+    "step2": lambda: [
+        gemm_case(196608, 2560, 320, act=1), gemm_case(49152, 640, 2560, res=True), gemm_case(49152, 640, 640, res=True),
+        gemm_case(49152, 640, 640), gemm_case(49152, 1280, 640), gemm_case(49152, 1920, 640, bias=False),
+        gemm_case(12288, 1280, 1280), gemm_case(12288, 2560, 1280), gemm_case(12288, 1280, 1280, res=True),
+        gemm_case(3072, 10240, 1280, act=1), gemm_case(3072, 1280, 1280, res=True), gemm_case(3072, 3840, 1280, bias=False),
+        gemm_case(3072, 1280, 5120, res=True), gemm_case(196608, 320, 320), gemm_case(196608, 320, 640), gemm_case(196608, 640, 320, bias=False),
+        conv_case(48, 8, 1280, 1280), conv_case(48, 16, 640, 1280), conv_case(48, 32, 320, 640)],
     "geglu": lambda: [gemm_case(196608, 2560, 320, act=1), gemm_case(196608, 1280, 320), gemm_case(196608, 2560, 320),
                       gemm_case(196608, 2560, 640, act=1), gemm_case(196608, 2560, 1280, act=1), gemm_case(196608, 1280, 640)],
     "big": lambda: [gemm_case(8192, 8192, 8192, bias=False), gemm_case(4096, 4096, 4096, bias=False)],
