@@ -175,7 +175,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
         const int arr = q / NBP, pc = q - arr * NBP;
         const float* src = arr == 0 ? ep.bias : ep.bias2 ? ep.bias2 + (long)(arr == 1 ? r0 : r1) * N : nullptr;
         if (src) {
-          const int col = tn * BN + pc * 256 + lane * 4;
+          const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // lane id afresh: nothing kept live (or spilled) for this
+          const int col = tn * BN + pc * 256 + ln * 4;
           blds16(dma_rsrc(src), col < N ? (unsigned)col * 4u : DMA_POISON, 0, smem + BIAS_OFF + arr * BIAS_ARR + pc * 1024);
         }
       }
@@ -376,67 +377,77 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
     int lme = lm, lqe = lq;
     asm volatile("" : "+v"(lme), "+v"(lqe));
     stamp(1);
-    T* out = reinterpret_cast<T*>(ep.out) + (long)bz * ep.bso;
-    const T* res = ep.residual ? reinterpret_cast<const T*>(ep.residual) + (long)bz * ep.bsr : nullptr;
-    const bool geglu = ep.act == 1;              // BN = 256 only (host): a wave's 128 columns = two packed [32 h | 32 gate] groups
-    const int cofs = 16 * (lqe & 1) + 8 * (lqe >> 1);
-    constexpr int NPAIR = NT / 2;
-    // Residual vectors (clamped addresses, no branches around the loads).  256 columns: row tile 0's are requested here, in
-    // front of the bias loads, and row tile i + 1's before row tile i is worked: the tile end exposes one memory round trip.
-    // 320 columns: no registers to spare (more pressure here spills main-loop state), each row tile waits for its own vectors.
-    u32x4 rv[BN == 256 ? 2 : 1][NPAIR];
-    auto load_res = [&](int i, u32x4* dst) {
-      const int m = row0 + 16 * i + lme;
-      const int mc = m < M ? m : M - 1;
-#pragma unroll
-      for (int jp = 0; jp < NPAIR; ++jp) {
-        int nc = col0 + 32 * jp + cofs;
-        nc = nc < N ? nc : N - 8;
-        dst[jp] = *reinterpret_cast<const u32x4*>(res + (long)mc * ep.ldr + nc);
-      }
-    };
-    if (BN == 256 && res) load_res(0, rv[0]);
-    stamp(2);
     // ---- epilogue from registers.  D = W_frag x A_frag: lane (lm, lq) holds output row m = 16 i + lm and, per accumulator
     // tile j, the four columns 16 j + 4 lq + r.  v_permlane16_swap exchanges the odd 16-lane rows of tile j with the even rows
     // of tile j + 1, after which the lane owns 8 consecutive columns 16 j + 16 (lq & 1) + 8 (lq >> 1) .. + 7: one 16-byte
     // store per lane and tile pair, 64 contiguous bytes per output row and instruction.
+    // One instantiation per mode (GEGLU / residual are compile-time here): a row tile's addresses are one 64-bit base per
+    // operand plus constant column offsets, and no branch sits between the steps of the unrolled loops.
+    // Residual vectors (clamped addresses).  256 columns: row tile i + 1's are requested before row tile i is worked, so the
+    // tile end exposes one memory round trip; 320 columns: no registers to spare (more pressure here spills main-loop
+    // state), each row tile waits for its own vectors.
+    constexpr int NPAIR = NT / 2;
+    stamp(2);
+    auto epilogue = [&](auto Gc, auto Rc) {
+      constexpr bool GEGLU = decltype(Gc)::value, RES = decltype(Rc)::value;   // GEGLU: BN = 256 only (host): a wave's 128 columns = two packed [32 h | 32 gate] groups
+      constexpr int NBUF = (BN == 256 || MODE == 0) ? 2 : 1;   // (the 320-column conv has no registers to spare)
+      const int cofs = 16 * (lqe & 1) + 8 * (lqe >> 1);
+      const int ncol = N - (col0 + cofs);                   // accumulator columns left of N from this lane's first one
+      T* obase = reinterpret_cast<T*>(ep.out) + (long)bz * ep.bso + (GEGLU ? (col0 >> 1) + cofs : col0 + cofs);
+      const T* rbase = RES ? reinterpret_cast<const T*>(ep.residual) + (long)bz * ep.bsr + col0 + cofs : nullptr;
+      u32x4 rv[RES ? NBUF : 1][RES ? NPAIR : 1];
+      auto load_res = [&](int i, u32x4* dst) {
+        const int m = row0 + 16 * i + lme;
+        const T* rrow = rbase + (long)(m < M ? m : M - 1) * ep.ldr;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = row0 + 16 * i + lme;
-      if (res) {
-        if (BN == 256 ? i < 3 : true) load_res(BN == 256 ? i + 1 : i, rv[BN == 256 ? (i + 1) & 1 : 0]);
+        for (int jp = 0; jp < NPAIR; ++jp) dst[jp] = *reinterpret_cast<const u32x4*>(rrow + (32 * jp < ncol ? 32 * jp : ncol - 8));   // (beyond N: column N - 8)
+      };
+      if (RES && NBUF == 2) load_res(0, rv[0]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = row0 + 16 * i + lme;
+        T* orow = obase + (long)m * ep.ldo;
+        if (RES) {
+          if (NBUF == 2 ? i < 3 : true) load_res(NBUF == 2 ? i + 1 : i, rv[NBUF == 2 ? (i + 1) & 1 : 0]);
+        }
+#pragma unroll
+        for (int jp = 0; jp < NPAIR; ++jp) {
+          if (GEGLU && (jp & 1)) continue;         // tile pairs 1, 3 are the gates of pairs 0, 2
+          acc4 x = acc[i][2 * jp], y = acc[i][2 * jp + 1];
+          if (GEGLU) {
+            const acc4 gx = acc[i][(2 * jp + 2) % NT], gy = acc[i][(2 * jp + 3) % NT];
+            const f32x2 g0 = gelu_erf_f2((f32x2){gx[0], gx[1]}), g1 = gelu_erf_f2((f32x2){gx[2], gx[3]});
+            const f32x2 g2 = gelu_erf_f2((f32x2){gy[0], gy[1]}), g3 = gelu_erf_f2((f32x2){gy[2], gy[3]});
+            x[0] *= g0[0]; x[1] *= g0[1]; x[2] *= g1[0]; x[3] *= g1[1];
+            y[0] *= g2[0]; y[1] *= g2[1]; y[2] *= g3[0]; y[3] *= g3[1];
+          }
+          float o8[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const auto sw2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[r]), __float_as_uint(y[r]), false, false);
+            o8[r] = __uint_as_float(sw2[0]);
+            o8[4 + r] = __uint_as_float(sw2[1]);
+          }
+          if (RES) {
+            union { u32x4 u; bf16_t e[8]; } r8;
+            r8.u = rv[NBUF == 2 ? i & 1 : 0][jp];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] += bf16_to_f32(r8.e[e]);
+          }
+          if (m < M && 32 * jp < ncol)
+            *reinterpret_cast<u32x4*>(orow + (GEGLU ? 16 * jp : 32 * jp)) =
+                (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])};
+        }
       }
-#pragma unroll
-      for (int jp = 0; jp < NPAIR; ++jp) {
-        if (geglu && (jp & 1)) continue;         // tile pairs 1, 3 are the gates of pairs 0, 2
-        acc4 x = acc[i][2 * jp], y = acc[i][2 * jp + 1];
-        if (BN == 256 && geglu) {
-          const acc4 gx = acc[i][(2 * jp + 2) % NT], gy = acc[i][(2 * jp + 3) % NT];
-          const f32x2 g0 = gelu_erf_f2((f32x2){gx[0], gx[1]}), g1 = gelu_erf_f2((f32x2){gx[2], gx[3]});
-          const f32x2 g2 = gelu_erf_f2((f32x2){gy[0], gy[1]}), g3 = gelu_erf_f2((f32x2){gy[2], gy[3]});
-          x[0] *= g0[0]; x[1] *= g0[1]; x[2] *= g1[0]; x[3] *= g1[1];
-          y[0] *= g2[0]; y[1] *= g2[1]; y[2] *= g3[0]; y[3] *= g3[1];
-        }
-        float o8[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const auto sw2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[r]), __float_as_uint(y[r]), false, false);
-          o8[r] = __uint_as_float(sw2[0]);
-          o8[4 + r] = __uint_as_float(sw2[1]);
-        }
-        const int nacc = col0 + 32 * jp + cofs;                       // column in the accumulator's N space
-        const long ocol = geglu ? (long)(col0 >> 1) + 16 * jp + cofs : (long)nacc;
-        if (res) {
-          union { u32x4 u; bf16_t e[8]; } r8;
-          r8.u = rv[BN == 256 ? i & 1 : 0][jp];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o8[e] += bf16_to_f32(r8.e[e]);
-        }
-        if (m < M && nacc < N)
-          *reinterpret_cast<u32x4*>(out + (long)m * ep.ldo + ocol) =
-              (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])};
-      }
+    };
+    using std::true_type;
+    using std::false_type;
+    if (BN == 256 && ep.act == 1) {
+      if constexpr (BN == 256) { if (ep.residual) epilogue(true_type{}, true_type{}); else epilogue(true_type{}, false_type{}); }
+    } else if (ep.residual) {
+      epilogue(false_type{}, true_type{});
+    } else {
+      epilogue(false_type{}, false_type{});
     }
     stamp(3);
     ++trace_n;
