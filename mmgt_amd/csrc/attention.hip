@@ -348,7 +348,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
       mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
-    if (it == 0 || __any(mt > 0.f)) {
+    // Lazy rescale: the reference M of a row may lag its true maximum by up to RESCALE_LAG (log2 units): p = 2^(s - M) <= 2^LAG
+    // is exact business for the fp32 row sums / accumulators and for the bf16 P operand alike (relative precision does not depend
+    // on the scale), and the o *= alpha / s -= delta pass (80 vector instructions of a tile's ~130) runs on the few tiles where
+    // some row's maximum jumps instead of on every tile in which any of the wave's 32 rows sets a new record (about half).
+    constexpr float RESCALE_LAG = 8.f;
+    if (it == 0 || __any(mt > RESCALE_LAG)) {
       // the first tile fixes M at the tile maximum (either sign); later tiles only ever raise it
       float delta = it == 0 ? mt : fmaxf(mt, 0.f);
       if (MFOLD) {
