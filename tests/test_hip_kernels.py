@@ -149,6 +149,55 @@ def _nhwc(x):
 
 
 @pytest.mark.parametrize("cfg", [16, 17])
+def test_gemm16_persistent_workgroups_exact(cfg):
+    """Several tiles per persistent workgroup (more tiles than CUs): the tile-boundary machinery of gemm16 -- bias vectors
+    fetched one tile ahead into LDS, the next W chunk issued in front of the epilogue stores with a counted wait that leaves
+    those stores in flight, group 1's deferred barrier, residual prefetch -- on exact small-integer problems (sparse -1/0/1
+    operands, integer bias / per-batch bias / residual): any stale stage, late bias copy or mixed-up tile shows as a wrong
+    integer.  K = 64 is the one-chunk tile (no second chunk to cover the relaxed wait), M is ragged."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_conv3x3
+    dt = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(1234 + cfg)
+
+    def sparse(*shape):
+        v = torch.randint(-1, 2, shape, generator=g) * (torch.rand(shape, generator=g) < 0.5)
+        return v.to(dev()).to(dt)
+
+    def ints(*shape, dtype=torch.float32):
+        return torch.randint(-3, 4, shape, generator=g).to(dev()).to(dtype)
+    try:
+        hip.tune("gemm_cfg", cfg)
+        for M, N, K, use_b2 in [(66000, 1280, 320, False), (140100, 320, 64, False), (70000, 640, 128, True), (66000, 960, 320, False)]:
+            a, w = sparse(M, K), sparse(N, K)
+            bias = ints(N) if N != 960 else None
+            res = ints(M, N, dtype=dt) if N <= 640 else None
+            b2 = ints((M + 4095) // 4096, N) if use_b2 else None
+            ref = a.float() @ w.float().t()
+            if bias is not None:
+                ref += bias
+            if b2 is not None:
+                ref += b2.repeat_interleave(4096, 0)[:M]
+            if res is not None:
+                ref += res.float()
+            assert ref.abs().max() < 256
+            for rep in range(2):
+                out = hip.gemm(a, w, bias, residual=res, bias2=b2, bias2_rows=4096 if use_b2 else 0)
+                bad = (out.float() != ref)
+                assert not bad.any(), (cfg, M, N, K, rep, int(bad.sum()), bad.nonzero()[:4].tolist())
+        nb, cin, cout = 20, 64, 640 if cfg == 16 else 320                      # 81920 output pixels: 320 row tiles
+        x = sparse(nb, 64, 64, cin)
+        wc = (torch.randint(-1, 2, (cout, cin, 3, 3), generator=g) * (torch.rand((cout, cin, 3, 3), generator=g) < 0.5)).float()
+        bias, res = ints(cout), ints(nb, 64, 64, cout, dtype=dt)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), wc.to(dev()), bias, padding=1).permute(0, 2, 3, 1) + res.float()
+        assert ref.abs().max() < 256
+        out = hip.conv3x3(x, pack_conv3x3(wc).to(dev()).to(dt), bias, residual=res)
+        assert torch.equal(out.float(), ref), (cfg, "conv", int((out.float() != ref).sum()))
+    finally:
+        hip.tune("gemm_cfg", 0)
+
+
+@pytest.mark.parametrize("cfg", [16, 17])
 def test_gemm16_core_exact_integers_and_geglu(cfg):
     """The 16x16x32 ping-pong core (cfg 16: 256 x 256 tile, cfg 17: 256 x 320; bf16 only; GEGLU runs on cfg 16 only): (a) exact small-integer operands with an ASYMMETRIC weight matrix --
     any row/column or k-order mix-up in the fragment maps, the permlane16 epilogue or the swizzle shows as a wrong integer;
