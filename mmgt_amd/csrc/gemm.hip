@@ -765,7 +765,8 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     // dense: the 256x256 tile wherever N fills its columns to within 7% (N = 960, 1280, 1920, 2560, 3840, 5120, 10240) and
     // the grid still covers the chip -- with the slim common epilogue it no longer spills: GEGLU ff1 -11..-13%, q/k/v
     // projections of the motion modules -13%, the N = 1280 family -5..-10%.
-    const bool sq_ok = ((N + 255) / 256) * 256l * 100 <= (long)N * 107 && tiles256sq >= 192;
+    // (and M: the batched W.X^T projections have M = 320 / 640 rows per problem, 62 / 83 % of two / three 256-row tiles: -13..-17 % on the 128x128 tile)
+    const bool sq_ok = ((N + 255) / 256) * 256l * 100 <= (long)N * 107 && ((M + 255) / 256) * 256l * 100 <= (long)M * 115 && tiles256sq >= 192;
     // cfg 16 (gemm16.hip: 256x256, 16x16x32 MFMAs, two wave groups in ping-pong; bf16 only) replaces cfg 9 wherever that ran and
     // takes the convs whose width fills 256-column tiles: measured (tools/ab_cfg.py, one process) -17..-19% on the 16x16-level
     // convs and the 16 -> 32 up-conv, -7..-10% on the long-K / wide dense shapes, -7% on the 32 -> 64 up-conv (N = 640: three
@@ -788,8 +789,9 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
   }
   if (geglu && (cfg == 3 || cfg == 12)) cfg = 1;   // GEGLU pairs need 64-column wave tiles
   if (cfg == 16 || cfg == 17) {   // gemm16.hip, 256 / 320 columns: bf16, plain vectorised epilogue only (GEGLU: 256); else fall back
-    if (std::is_same<T, bf16_t>::value && ep.fast && ep.act <= (cfg == 16 ? 1 : 0) && !ep.row_scale && ep.alpha == 1.f &&
-        !ep.bias_post && (((uintptr_t)ep.bias | (uintptr_t)ep.bias2) & 15) == 0 && N % 4 == 0)   // (bias vectors travel by 16-byte DMA)
+    const bool post = ep.row_scale || ep.alpha != 1.f || ep.bias_post;   // row scale / alpha / post-scale bias: without GEGLU only
+    if (std::is_same<T, bf16_t>::value && ep.fast && ep.act <= (cfg == 16 && !post ? 1 : 0) &&
+        (((uintptr_t)ep.bias | (uintptr_t)ep.bias2 | (uintptr_t)ep.bias_post) & 15) == 0 && N % 4 == 0)   // (bias vectors travel by 16-byte DMA)
       return mmgt_gemm16_launch(MODE, cfg == 16 ? 256 : 320, &ad, W, bsw, &ep, M, N, K, batch, s);
     cfg = cfg == 16 ? 9 : geglu ? 1 : 12;   // (GEGLU pairs need 64-column wave tiles: not the 320-column tile)
   }

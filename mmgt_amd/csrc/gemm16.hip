@@ -54,7 +54,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
   constexpr int CPR = 8, RPD = 8;               // 16-byte chunks per row; rows per 1-KiB DMA piece
   constexpr int GA = BM / RPD / NW, GB = BN / RPD / NW;   // pieces per wave and chunk: 4 x A + 4 or 5 x W
   constexpr int NPH = BN / 64, NT = BN / 32;    // phases per chunk; accumulator tiles per row tile
-  constexpr int BIAS_OFF = 2 * STAGE_BYTES, BIAS_ARR = 2048, NBP = BN == 256 ? 1 : 2;   // bias | bias2 row 0 | bias2 row 1: 512 floats each, NBP pieces
+  constexpr int BIAS_OFF = 2 * STAGE_BYTES, BIAS_ARR = 2048, NBP = BN == 256 ? 1 : 2;   // bias | bias2 row 0 | bias2 row 1 | post-scale bias: 512 floats each, NBP pieces
   auto swz = [](int row) { return (row >> 1) & 7; };
 
   const int nwg = tiles_m * tiles_n;
@@ -162,18 +162,22 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
   // than the chunk's counted A pieces, so they have landed behind that chunk's last barrier.  (Columns >= N read as zeros.)
   const bool has_bias = ep.bias != nullptr || ep.bias2 != nullptr;
   const int b2div = ep.bias2 ? ep.bias2_rows : 0x7fffffff;
-  auto issue_bias = [&](int v) {
-    int tm, tn;
-    decode(v, tm, tn);
+  // A fourth vector, the post-scale bias (added after the row scale: MM-HAA's merged out-projections), is consumed at the END of
+  // a tile, so it is the CURRENT tile's (`vc`) that goes out at the same point.
+  auto issue_bias = [&](int v, int vc) {
+    int tm = 0, tn = 0, tnc;
+    if (v >= 0) decode(v, tm, tn);
+    { int tmc; decode(vc, tmc, tnc); }
     int mlast = tm * BM + BM - 1;
     if (mlast >= M) mlast = M - 1;
     const int r0 = (tm * BM) / b2div, r1 = mlast / b2div;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int q = wid + 4 * u;
-      if (q < 3 * NBP) {
+      if (q < 4 * NBP) {
         const int arr = q / NBP, pc = q - arr * NBP;
-        const float* src = arr == 0 ? ep.bias : ep.bias2 ? ep.bias2 + (long)(arr == 1 ? r0 : r1) * N : nullptr;
+        const float* src = arr == 3 ? ep.bias_post : v < 0 ? nullptr : arr == 0 ? ep.bias : ep.bias2 ? ep.bias2 + (long)(arr == 1 ? r0 : r1) * N : nullptr;
+        if (arr == 3) tn = tnc;
         if (src) {
           const int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // lane id afresh: nothing kept live (or spilled) for this
           const int col = tn * BN + pc * 256 + ln * 4;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
   };
   // prologue: chunk 0 whole, the A half of chunk 1 (the A stream runs two chunks ahead of the MFMAs, the W stream one)
   if (total > 0) {
-    if (wr == 0 && has_bias) issue_bias(blockIdx.x);
+    if (wr == 0 && has_bias) issue_bias(blockIdx.x, blockIdx.x);   // (the post-scale bias of the first tile is issued again in its first chunk: harmless)
     prepA(ichA);
     for_n(integral_constant<int, GA>{}, [&](auto i) { issueA(0, i); });
     advanceA();
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
             fa[t][1] = *reinterpret_cast<const s16x8*>(pa + roff1);
           }
         }
-        if (P == 1 && ch == 0 && wr == 0 && has_bias && vt + G < nwg) issue_bias(vt + G);
+        if (P == 1 && ch == 0 && wr == 0 && (ep.bias_post || (has_bias && vt + G < nwg))) issue_bias(has_bias && vt + G < nwg ? vt + G : -1, vt);
         for_n(integral_constant<int, 2>{}, [&](auto Uc) {     // pieces 2 P, 2 P + 1 of [W 0 .. W GB-1 | A 0 .. A GA-1]
           constexpr int S = 2 * P + decltype(Uc)::value;
           if constexpr (S < GB) {
@@ -388,9 +392,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
     // state), each row tile waits for its own vectors.
     constexpr int NPAIR = NT / 2;
     stamp(2);
-    auto epilogue = [&](auto Gc, auto Rc) {
-      constexpr bool GEGLU = decltype(Gc)::value, RES = decltype(Rc)::value;   // GEGLU: BN = 256 only (host): a wave's 128 columns = two packed [32 h | 32 gate] groups
-      constexpr int NBUF = (BN == 256 || MODE == 0) ? 2 : 1;   // (the 320-column conv has no registers to spare)
+    auto epilogue = [&](auto Gc, auto Rc, auto Pc) {
+      constexpr bool GEGLU = decltype(Gc)::value, RES = decltype(Rc)::value, POST = decltype(Pc)::value;   // POST: x * row_scale[m] * alpha + bias_post[n]   // GEGLU: BN = 256 only (host): a wave's 128 columns = two packed [32 h | 32 gate] groups
+      constexpr int NBUF = (BN == 256 || (MODE == 0 && !POST)) ? 2 : 1;   // (the 320-column conv / row-scaled variants have no registers to spare)
       const int cofs = 16 * (lqe & 1) + 8 * (lqe >> 1);
       const int ncol = N - (col0 + cofs);                   // accumulator columns left of N from this lane's first one
       T* obase = reinterpret_cast<T*>(ep.out) + (long)bz * ep.bso + (GEGLU ? (col0 >> 1) + cofs : col0 + cofs);
@@ -403,6 +407,15 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
         for (int jp = 0; jp < NPAIR; ++jp) dst[jp] = *reinterpret_cast<const u32x4*>(rrow + (32 * jp < ncol ? 32 * jp : ncol - 8));   // (beyond N: column N - 8)
       };
       if (RES && NBUF == 2) load_res(0, rv[0]);
+      float rsv[POST ? 4 : 1];
+      const acc4* lpost = reinterpret_cast<const acc4*>(smem + BIAS_OFF + 3 * BIAS_ARR) + ((wn * (BN / 2) + cofs) >> 2);
+      if (POST) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = row0 + 16 * i + lme;
+          rsv[i] = (ep.row_scale ? ep.row_scale[m < M ? m : M - 1] : 1.f) * ep.alpha;
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int m = row0 + 16 * i + lme;
@@ -428,6 +441,14 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
             o8[r] = __uint_as_float(sw2[0]);
             o8[4 + r] = __uint_as_float(sw2[1]);
           }
+          if (POST) {
+            const acc4 pa = ep.bias_post ? lpost[8 * jp] : (acc4)(0.f), pb = ep.bias_post ? lpost[8 * jp + 1] : (acc4)(0.f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o8[e] = fmaf(o8[e], rsv[i], pa[e]);
+              o8[4 + e] = fmaf(o8[4 + e], rsv[i], pb[e]);
+            }
+          }
           if (RES) {
             union { u32x4 u; bf16_t e[8]; } r8;
             r8.u = rv[NBUF == 2 ? i & 1 : 0][jp];
@@ -442,12 +463,17 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
     };
     using std::true_type;
     using std::false_type;
+    const bool post = ep.row_scale != nullptr || ep.alpha != 1.f || ep.bias_post != nullptr;
     if (BN == 256 && ep.act == 1) {
-      if constexpr (BN == 256) { if (ep.residual) epilogue(true_type{}, true_type{}); else epilogue(true_type{}, false_type{}); }
+      if constexpr (BN == 256) {
+        if (ep.residual) epilogue(true_type{}, true_type{}, false_type{}); else epilogue(true_type{}, false_type{}, false_type{});
+      }
+    } else if (post) {
+      if (ep.residual) epilogue(false_type{}, true_type{}, true_type{}); else epilogue(false_type{}, false_type{}, true_type{});
     } else if (ep.residual) {
-      epilogue(false_type{}, true_type{});
+      epilogue(false_type{}, true_type{}, false_type{});
     } else {
-      epilogue(false_type{}, false_type{});
+      epilogue(false_type{}, false_type{}, false_type{});
     }
     stamp(3);
     ++trace_n;
@@ -462,7 +488,7 @@ template <int MODE, int BN>
 int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
   constexpr int BM = 256;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const size_t lds = (size_t)2 * (BM + BN) * 128 + 3 * 2048;
+  const size_t lds = (size_t)2 * (BM + BN) * 128 + 4 * 2048;   // stages + the four bias vectors
   auto kern = gemm16_kernel<MODE, BN>;
   static int resident = 0;
   if (!resident) {

@@ -53,9 +53,11 @@ def test_gemm_plain_and_epilogue(dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("cfg", [0, 16, 17])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (4100, 640, 640), (77, 1280, 1280)])
-def test_gemm_post_scale_bias(dt, M, N, K):
-    """mmgt_gemm_post: (a W^T + bias) * row_scale * alpha + bias_post + residual, on a strided A view (MM-HAA branch)."""
+def test_gemm_post_scale_bias(dt, M, N, K, cfg):
+    """mmgt_gemm_post: (a W^T + bias) * row_scale * alpha + bias_post + residual, on a strided A view (MM-HAA branch); the
+    dispatcher's choice and the two gemm16 tiles (bf16) forced."""
     from mmgt_amd import hip
     big = rnd("a3", (M, 3 * K), 1.0, dt)
     a = big[:, K:2 * K]
@@ -63,7 +65,11 @@ def test_gemm_post_scale_bias(dt, M, N, K):
     b, bp = rnd("b", (N,), 0.5), rnd("bp", (N,), 0.5)
     rs = rnd("rs", (M,), 1.0) + 1.0
     res = rnd("r", (M, N), 1.0, dt)
-    out = hip.gemm_post(a, w, b, rs, 0.75, bp, res)
+    try:
+        hip.tune("gemm_cfg", cfg)
+        out = hip.gemm_post(a, w, b, rs, 0.75, bp, res)
+    finally:
+        hip.tune("gemm_cfg", 0)
     ref = (ref_gemm(a, w) + b.double()) * rs.double()[:, None] * 0.75 + bp.double() + res.double()
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
@@ -185,6 +191,15 @@ def test_gemm16_persistent_workgroups_exact(cfg):
                 out = hip.gemm(a, w, bias, residual=res, bias2=b2, bias2_rows=4096 if use_b2 else 0)
                 bad = (out.float() != ref)
                 assert not bad.any(), (cfg, M, N, K, rep, int(bad.sum()), bad.nonzero()[:4].tolist())
+        for M, N, K in [(70000, 1280 if cfg == 16 else 640, 320), (140100, 320, 128)]:     # row scale + post-scale bias (MM-HAA form)
+            a, w = sparse(M, K), sparse(N, K)
+            bias, bp, res = ints(N), ints(N), ints(M, N, dtype=dt)
+            rs = (2 * torch.randint(1, 3, (M,), generator=g)).float().to(dev())          # x alpha 0.5 = 1 or 2
+            ref = (a.float() @ w.float().t() + bias) * rs[:, None] * 0.5 + bp + res.float()
+            assert ref.abs().max() < 256 and torch.equal(ref, ref.round())
+            out = hip.gemm_post(a, w, bias, rs, 0.5, bp, res)
+            bad = out.float() != ref
+            assert not bad.any(), (cfg, "post", M, N, K, int(bad.sum()), bad.nonzero()[:4].tolist())
         nb, cin, cout = 20, 64, 640 if cfg == 16 else 320                      # 81920 output pixels: 320 row tiles
         x = sparse(nb, 64, 64, cin)
         wc = (torch.randint(-1, 2, (cout, cin, 3, 3), generator=g) * (torch.rand((cout, cin, 3, 3), generator=g) < 0.5)).float()

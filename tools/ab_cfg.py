@@ -54,7 +54,14 @@ def conv_case(nb, h, cin, cout, up=False):
             (lambda: hip.conv3x3(x, w, b, out=o, upsample=up)), 2.0 * nb * ho * ho * cout * 9 * cin, o)
 
 
+def wx_case(B, R, ntok, K):
+    w, x = rnd(R, K, s=1 / math.sqrt(K)), rnd(B, ntok, K)
+    o = torch.empty((B, R, ntok), device=dev, dtype=torch.bfloat16)
+    return f"gemm_wx B={B} R={R} ntok={ntok} K={K}", (lambda: hip.gemm_batched_wx(w, x, out=o)), 2.0 * B * R * ntok * K, o
+
+
 SETS = {
+    "wx": lambda: [wx_case(48, 320, 4096, 320), wx_case(48, 640, 1024, 640), wx_case(48, 1280, 256, 1280)],
     "step2": lambda: [
         gemm_case(196608, 2560, 320, act=1), gemm_case(49152, 640, 2560, res=True), gemm_case(49152, 640, 640, res=True),
         gemm_case(49152, 640, 640), gemm_case(49152, 1280, 640), gemm_case(49152, 1920, 640, bias=False),
