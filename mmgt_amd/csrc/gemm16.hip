@@ -434,6 +434,13 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
             x[0] *= g0[0]; x[1] *= g0[1]; x[2] *= g1[0]; x[3] *= g1[1];
             y[0] *= g2[0]; y[1] *= g2[1]; y[2] *= g3[0]; y[3] *= g3[1];
           }
+          if (!RES && !POST) {   // nothing is added in the store layout: pack first, swap the two packed dwords per tile (half the swaps)
+            const auto s01 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[0], x[1]), pack_bf16x2(y[0], y[1]), false, false);
+            const auto s23 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[2], x[3]), pack_bf16x2(y[2], y[3]), false, false);
+            if (m < M && 32 * jp < ncol)
+              *reinterpret_cast<u32x4*>(orow + (GEGLU ? 16 * jp : 32 * jp)) = (u32x4){s01[0], s23[0], s01[1], s23[1]};
+            continue;
+          }
           float o8[8];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
