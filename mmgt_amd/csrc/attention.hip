@@ -7,6 +7,8 @@
 // and the exponentiated accumulator registers are directly the B operand of the second product
 // O^T[d][q] += V^T[d][key] . P^T[key][q] (guide section 3, "an accumulator tile as the next MFMA's operand").
 // K and V tiles (64 keys) are staged through LDS and shared by the workgroup's waves.
+#include <type_traits>
+
 #include "common.h"
 #include "attn_common.h"
 #include "mmgt_hip.h"
@@ -467,6 +469,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
   }
 }
 
+int g_attn64 = 1;   // mmgt_tune("attn64", 0 / 1): the 64-queries-per-wave kernel of attn64.hip (A/B switch)
+
+}  // namespace
+int mmgt_attn64_launch(const void* params, int batch, int heads, void* stream);
+void mmgt_attn_set64(int v) { g_attn64 = v; }
+namespace {
+
 template <typename T, int HD>
 int launch_hd(AttnParams p, int batch, int heads, int vt, hipStream_t s) {
 
@@ -484,6 +493,8 @@ int launch_hd(AttnParams p, int batch, int heads, int vt, hipStream_t s) {
     p.nqb = (p.nq + 127) / 128;
     dim3 grid((unsigned)((long)p.nqb * batch * heads));
     const bool whole = p.nk % 64 == 0 && p.nk2 % 64 == 0;
+    if (std::is_same<T, bf16_t>::value && HD == 40 && vt && whole && p.nq % 256 == 0 && g_attn64)
+      return mmgt_attn64_launch(&p, batch, heads, s);
     if (vt && whole) hipLaunchKernelGGL((attn_kernel<T, HD, 4, true, 64, false>), grid, dim3(256), 0, s, p);
     else if (vt) hipLaunchKernelGGL((attn_kernel<T, HD, 4, true, 64>), grid, dim3(256), 0, s, p);
     else if (short_keys) hipLaunchKernelGGL((attn_kernel<T, HD, 4, false, 32>), grid, dim3(256), 0, s, p);

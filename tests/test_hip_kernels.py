@@ -405,9 +405,10 @@ def test_attention_spatial_with_bank(dt, hd, nq, nk2, vt):
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
 
-@pytest.mark.parametrize("hd", [40, 80])
-def test_attention_online_softmax_rescale_branch_is_forced(hd):
-    """The rare, data-dependent branch of the online softmax (guide rule 26): one key row per later tile is spiked against one query
+@pytest.mark.parametrize("hd,a64", [(40, 1), (40, 0), (80, 1)])
+def test_attention_online_softmax_rescale_branch_is_forced(hd, a64):
+    """(a64: the 64-queries-per-wave kernel of attn64.hip, the production path at head_dim 40, on / off.)
+    The rare, data-dependent branch of the online softmax (guide rule 26): one key row per later tile is spiked against one query
     so that query's running maximum jumps mid-sequence (own keys and bank keys); full-tensor check against fp64, bf16, V transposed,
     whole 64-key tiles -- the production configuration of the spatial self-attention."""
     from mmgt_amd import hip
@@ -434,10 +435,14 @@ def test_attention_online_softmax_rescale_branch_is_forced(hd):
     ref = torch.cat(refs).permute(0, 2, 1, 3).reshape(B, nq, inner)
     vT, vbT = v.transpose(1, 2).contiguous(), vb.transpose(1, 2).contiguous()
     out = torch.empty_like(q)
-    hip.attention(q, k, vT, out, batch=B, heads=heads, hd=hd, nq=nq, nk=nq, scale=scale, q_str=(nq * inner, 0, inner),
-                  k_str=(nq * inner, 0, inner), v_str=(vT.stride(0), 0, vT.stride(1)), o_str=(nq * inner, 0, inner),
-                  v_transposed=True, k2=kb, v2=vbT, k2_str=(kb.stride(0), inner), v2_str=(vbT.stride(0), vbT.stride(1)),
-                  k2_bdiv=2, nk2=nk2, seg2_first_batch=2)
+    try:
+        hip.tune("attn64", a64)
+        hip.attention(q, k, vT, out, batch=B, heads=heads, hd=hd, nq=nq, nk=nq, scale=scale, q_str=(nq * inner, 0, inner),
+                      k_str=(nq * inner, 0, inner), v_str=(vT.stride(0), 0, vT.stride(1)), o_str=(nq * inner, 0, inner),
+                      v_transposed=True, k2=kb, v2=vbT, k2_str=(kb.stride(0), inner), v2_str=(vbT.stride(0), vbT.stride(1)),
+                      k2_bdiv=2, nk2=nk2, seg2_first_batch=2)
+    finally:
+        hip.tune("attn64", 1)
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
 
