@@ -846,9 +846,11 @@ int check_common(int dtype, int M, int N, int K, int act) {
 }  // namespace
 
 void mmgt_attn_set64(int v);
+void mmgt_gn_set_rows(int v);
 extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return 0; }
   if (key && !strcmp(key, "attn64")) { mmgt_attn_set64(value); return 0; }
+  if (key && !strcmp(key, "gn_rows")) { mmgt_gn_set_rows(value); return 0; }
   mmgt_set_error("tune: unknown key");
   return 1;
 }

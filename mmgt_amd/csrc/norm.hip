@@ -8,11 +8,21 @@ namespace {
 
 constexpr int GN_MAXC = 2560;
 
-__host__ __device__ inline int gn_chunks(int HW) {
-  // >= 128 rows per workgroup on large images (amortises the per-workgroup scale/shift table), 32 on small ones so that
-  // the grid still fills the chip
+int g_gn_rows = 0;   // mmgt_tune("gn_rows", v): force the rows per workgroup (0 = the measured choice below; benchmarking only)
+// Upper bound of the chunk count for an image of HW pixels: what callers size the workspace with (mmgt_groupnorm_chunks).
+inline int gn_chunks(int HW) {
   int c = HW >= 2048 ? (HW + 127) / 128 : (HW + 31) / 32;
   return c < 1 ? 1 : (c > 256 ? 256 : c);
+}
+// Rows per workgroup actually used.  A workgroup's fixed cost (pivot table, the xor tree over its 2 x 40 accumulators, four
+// barriers) is as long as ~8 row steps of its loop, so more rows per workgroup amortise it until the grid no longer covers
+// the chip -- measured (48 images, tools/bench_norm.py): 4096 x 320: 256 rows 84 us / 128 rows 92 / 64 rows 131 / 512 rows 119;
+// 4096 x 640 and x 960: 128 rows best; 1024 x 640: 64 rows 51 us against 60 at 32.
+inline int gn_chunks_used(int HW, int C) {
+  const int rows = g_gn_rows > 0 ? g_gn_rows : HW >= 2048 ? (C <= 320 ? 256 : 128) : 64;
+  int c = (HW + rows - 1) / rows;
+  const int cap = gn_chunks(HW);
+  return c < 1 ? 1 : (c > cap ? cap : c);
 }
 
 template <typename T>
@@ -341,6 +351,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long l
 
 }  // namespace
 
+void mmgt_gn_set_rows(int v) { g_gn_rows = v; }
 extern "C" int mmgt_groupnorm_chunks(int HW) { return gn_chunks(HW); }
 
 extern "C" int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta,
@@ -370,7 +381,7 @@ extern "C" int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C
       return 0;
     }
   }
-  const int chunks = gn_chunks(HW);
+  const int chunks = gn_chunks_used(HW, C);
   dim3 grid(chunks, NB);
   const int nvec = C / vec;
   // lanes per pixel row: the fewest of 8 / 16 / 32 / 64 whose lanes x MAXS vectors tile the row exactly, so that every lane

@@ -27,8 +27,11 @@ for nb, hw, c in [(48, 4096, 320), (48, 4096, 640), (48, 1024, 640), (48, 256, 1
     x = torch.randn(nb, hw, c, device=dev).bfloat16()
     g, b = torch.ones(c, device=dev), torch.zeros(c, device=dev)
     o = torch.empty_like(x)
-    us = t_us(lambda: hip.groupnorm(x, g, b, 32, 1e-5, silu=True, out=o))
-    print(f"groupnorm nb={nb} hw={hw} c={c}: {us:7.1f} us  {3 * x.numel() * 2 / us / 1e6:6.2f} TB/s (3 passes)")
+    for rows in [int(v) for v in os.environ.get("GN_ROWS", "0").split(",")]:
+        hip.tune("gn_rows", rows)
+        us = t_us(lambda: hip.groupnorm(x, g, b, 32, 1e-5, silu=True, out=o))
+        print(f"groupnorm nb={nb} hw={hw} c={c} rows/wg={rows}: {us:7.1f} us  {3 * x.numel() * 2 / us / 1e6:6.2f} TB/s (3 passes)")
+hip.tune("gn_rows", 0)
 for rows, c in [(196608, 320), (49152, 640), (12288, 1280)]:
     x = torch.randn(rows, c, device=dev).bfloat16()
     g, b = torch.ones(c, device=dev), torch.zeros(c, device=dev)

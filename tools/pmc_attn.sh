@@ -12,7 +12,7 @@ for d in sorted(glob.glob("$R/gpurun_out/pmca_${TAG}_*")):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(float); n = collections.Counter()
         for row in csv.DictReader(open(f)):
-            if "attn_kernel" in row["Kernel_Name"]:
+            if "attn" in row["Kernel_Name"]:
                 acc[row["Counter_Name"]] += float(row["Counter_Value"]); n[row["Counter_Name"]] += 1
         for k, v in acc.items():
             print(f"{k:32s} per launch {v / max(n[k],1):16.6g}   launches {n[k]}")
