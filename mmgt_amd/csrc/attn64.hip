@@ -38,6 +38,9 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
       qblk = id - pair * nqb;
     }
   }
+  // longest first: the batches that also attend to the bank (b >= seg2_first_batch, twice the keys) are the LAST pairs, so the
+  // grid is walked backwards and the tail of the launch is made of short workgroups
+  pair = p.npairs - 1 - pair;
   const int b = pair / p.heads, head = pair - b * p.heads;
   const int bo = b / p.bdiv, bi = b - bo * p.bdiv;
   const int q0 = (qblk * NW + wid) * (32 * QB);
