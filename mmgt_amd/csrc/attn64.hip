@@ -181,22 +181,24 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) mma32(s[qb][sub], kf[sub][ks], qf[qb][ks]);
     }
-    // ---- per query block: tile maximum, (rare) rescale, exponentials ----
+    // ---- tile maxima of both query blocks, one (rare) rescale branch for the wave ----
+    float mt[QB];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-      float mt = fmaxf(s[qb][0][0], s[qb][1][0]), mt2 = fmaxf(s[qb][0][1], s[qb][1][1]);
+      float m1 = fmaxf(s[qb][0][0], s[qb][1][0]), m2 = fmaxf(s[qb][0][1], s[qb][1][1]);
 #pragma unroll
       for (int r = 2; r < 16; r += 2) {
-        mt = fmaxf(fmaxf(mt, s[qb][0][r]), s[qb][1][r]);
-        mt2 = fmaxf(fmaxf(mt2, s[qb][0][r + 1]), s[qb][1][r + 1]);
+        m1 = fmaxf(fmaxf(m1, s[qb][0][r]), s[qb][1][r]);
+        m2 = fmaxf(fmaxf(m2, s[qb][0][r + 1]), s[qb][1][r + 1]);
       }
-      mt = fmaxf(mt, mt2);
-      {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mt), __float_as_uint(mt), false, false);
-        mt = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-      }
-      if (it == 0 || __any(mt > RESCALE_LAG)) {
-        float delta = it == 0 ? mt : fmaxf(mt, 0.f);
+      m1 = fmaxf(m1, m2);
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m1), __float_as_uint(m1), false, false);
+      mt[qb] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    if (it == 0 || __any(fmaxf(mt[0], mt[1]) > RESCALE_LAG)) {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        float delta = it == 0 ? mt[qb] : fmaxf(mt[qb], 0.f);
         const float m_new = m_run[qb] + delta;
         const float hi = Elem<T>::cvt(m_new), lo = Elem<T>::cvt(m_new - hi);
         delta = (hi + lo) - m_run[qb];
@@ -211,12 +213,9 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) s[qb][sub] -= delta;
       }
-#pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[qb][sub][r] = __builtin_amdgcn_exp2f(s[qb][sub][r]);
     }
-    // ---- O^T += V^T . P^T: each V^T fragment is read once and multiplies both blocks' probabilities ----
+    // ---- O^T += V^T . P^T, 16 keys at a time: exponentials of the group -> P fragments of both blocks -> one read of each V^T
+    // fragment feeding both.  One basic block: a group's MFMAs can run under the next group's exponentials.
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
         for (int qb = 0; qb < QB; ++qb) {
           float p8[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) p8[j] = s[qb][sub][8 * s2 + j];
+          for (int j = 0; j < 8; ++j) p8[j] = __builtin_amdgcn_exp2f(s[qb][sub][8 * s2 + j]);
           frag_set8(pf[qb], p8);
         }
 #pragma unroll
