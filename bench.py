@@ -140,7 +140,7 @@ def _cpu_name():
     return "unknown"
 
 
-def _time_ms(fn, reps=5, warm=1):
+def _time_ms(fn, reps=20, warm=3):
     """Average device time of fn() in ms, HIP events on the stream the kernels are launched on (torch's current stream)."""
     import torch
     for _ in range(warm):
