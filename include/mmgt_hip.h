@@ -38,7 +38,10 @@ extern "C" {
 
 int mmgt_abi_version(void);
 const char* mmgt_last_error(void);
-/* Benchmark-only knob: "gemm_cfg" = 0 (heuristic tile choice) or 1, 3, 6, 9, 12, 16, 17 (force a tile configuration). */
+/* Benchmark-only knobs (A/B measurements and tests; the defaults are the product):
+ *   "gemm_cfg" = 0 (heuristic tile choice) or 1, 3, 6, 9, 12, 16, 17 (force a GEMM / conv tile configuration);
+ *   "attn64"   = 1 (default) / 0: the 64-queries-per-wave spatial attention kernel at head_dim 40;
+ *   "gn_rows"  = 0 (default: measured choice) or the GroupNorm rows per workgroup. */
 int mmgt_tune(const char* key, int value);
 
 /* out[M,N] = epi(A[M,K] . W[N,K]^T):  v = acc + bias[n] + bias2[m / bias2_rows][n]; v = act(v);
