@@ -446,6 +446,37 @@ def test_attention_online_softmax_rescale_branch_is_forced(hd, a64):
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
 
+@pytest.mark.parametrize("a64", [0, 1])
+def test_attention_run_to_run_deterministic(a64):
+    """Identical launches give bitwise identical results (a data race between the staging writes and the fragment reads of the
+    flash attention kernels would show as a result that changes from launch to launch): spatial shape with bank, head_dim 40,
+    the 64-queries-per-wave kernel (a64 = 1) and the 32-query one."""
+    from mmgt_amd import hip
+    dt = torch.bfloat16
+    heads, hd, B, n = 8, 40, 8, 1024
+    c = heads * hd
+    qk = rnd("det.qk", (B * n, 2 * c), 1.0, dt)
+    vt = rnd("det.vt", (B, c, n), 1.0, dt)
+    kb, vbt = rnd("det.kb", (2, n, c), 1.0, dt), rnd("det.vbt", (2, c, n), 1.0, dt)
+    o = torch.empty((B * n, c), device=dev(), dtype=dt)
+
+    def run():
+        hip.attention(qk, qk[:, c:], vt, o, batch=B, heads=heads, hd=hd, nq=n, nk=n, scale=hd ** -0.5, q_str=(n * 2 * c, 0, 2 * c),
+                      k_str=(n * 2 * c, 0, 2 * c), v_str=(c * n, 0, n), o_str=(n * c, 0, c), v_transposed=True, k2=kb, v2=vbt,
+                      k2_str=(kb.stride(0), kb.stride(1)), v2_str=(vbt.stride(0), vbt.stride(1)), k2_bdiv=B // 2, nk2=n,
+                      seg2_first_batch=B // 2)
+    try:
+        hip.tune("attn64", a64)
+        run()
+        first = o.clone()
+        for _ in range(12):
+            o.zero_()
+            run()
+            assert torch.equal(o, first)
+    finally:
+        hip.tune("attn64", 1)
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("hd,frames,hw", [(40, 24, 16), (80, 8, 9), (160, 24, 4), (40, 32, 1)])
 def test_attention_temporal_layout(dt, hd, frames, hw):
