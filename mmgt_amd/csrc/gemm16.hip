@@ -29,6 +29,11 @@
 // barriers after group 0's phase-0 reads, three after group 1's), the first W piece in phase 0 of the next chunk (two / one
 // barriers after the groups' last-phase reads).  RAW: chunk c + 1 is waited for (counted vmcnt) in the last phase's load part
 // by every issuing wave, in front of a barrier both groups pass before their first read of that chunk.
+// Tile boundary (what the per-tile stamps of tools/trace_gemm16.py showed, profiles/r2/gemm16_tile_trace_r2.txt): the streams roll on
+// into the next tile, group 1 keeps the tile's last barrier for after its epilogue so that both groups' epilogues run side by
+// side, the next tile's second W chunk goes out in front of the epilogue stores (vmcnt retires in order), the tile's bias vectors
+// are fetched one tile ahead into LDS and the accumulators START from them, and the epilogue is instantiated per mode (GEGLU /
+// residual / row scale + post-scale bias) with one base address per row tile.
 #include <type_traits>
 
 #include "common.h"
@@ -527,7 +532,7 @@ int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int
 extern "C" void mmgt_gemm16_set_trace(void* p) { g_trace = reinterpret_cast<unsigned long long*>(p); }
 
 // Entry for gemm.hip's dispatcher.  Preconditions (checked there): bf16, vectorised epilogue (ep.fast), act in {none, GEGLU}
-// (GEGLU with bn = 256 only), no row scale / alpha / post-scale bias, K % 64 == 0.
+// (GEGLU with bn = 256 only and without row scale / alpha / post-scale bias), 16-byte aligned bias vectors, K % 64 == 0.
 int mmgt_gemm16_launch(int mode, int bn, const void* adp, const void* W, long bsw, const void* epp, int M, int N, int K,
                        int batch, void* stream) {
   const ADesc& ad = *reinterpret_cast<const ADesc*>(adp);
