@@ -783,7 +783,7 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     } else if (b16 && !geglu && N % 320 == 0 && N <= 960 && M >= 131072) cfg = 17;
     else if (b16 && !geglu && N % 320 == 0 && N <= 1280 && M >= 49152 && (K >= 1280 || ep.residual || N == 1280)) cfg = 17;   // 32x32 level
     else if (sq_ok) cfg = b16 ? 16 : 9;
-    else if (geglu || K >= 1280) cfg = tiles256 >= 256 ? 6 : 1;
+    else if (geglu || K >= 1280) cfg = tiles256 >= 256 ? 6 : (!geglu && tiles128 <= 256) ? 3 : 1;   // (<= one 128x128 tile per CU: 128x64 tiles, -5..-7 % at M = 3072)
     else if (M >= 131072 && N >= 640) cfg = 6;
     else cfg = 1;
   }
