@@ -84,6 +84,16 @@ def test_unet_fp32_mode_matches_oracle_config1(full_sd):
     torch.testing.assert_close(out, ref, rtol=1e-3, atol=1e-4)
 
 
+def test_unet_bf16_forward_is_bitwise_reproducible(full_sd):
+    """No atomics, fixed-order reductions, deterministic tile schedules: two forwards of the whole UNet on the same inputs are
+    bitwise identical (a race in any kernel's staging would show here as well as in the parity gates)."""
+    sd_gpu, _ = full_sd
+    case = gc.UNET_CASES["full_cfg1"]
+    a = _run_hip(sd_gpu, case, torch.bfloat16)
+    b = _run_hip(sd_gpu, case, torch.bfloat16)
+    assert torch.equal(a, b)
+
+
 def test_unet_fp32_mode_eval_semantics(full_sd):
     """eval() => motion_scale ignored."""
     sd_gpu, sd_cpu = full_sd
