@@ -179,3 +179,5 @@ def test_unet_benchmarked_shape_512x512x24_matches_reference_golden(full_sd, gol
           f"(CPU-bf16 floor {fmax:.3e} / {fmean:.3e})")
     assert torch.isfinite(out16).all()
     assert d16.max() <= FLOOR_SLACK * fmax and d16.mean() <= FLOOR_SLACK * fmean
+    # the production configuration twice: bitwise reproducible (persistent workgroups walking many tiles, 64-query attention)
+    assert torch.equal(_run_hip(sd_gpu, case, torch.bfloat16), out16)
