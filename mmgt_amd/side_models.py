@@ -13,24 +13,36 @@ from . import hip
 from .packing import pack_conv3x3, pad_rows, round_up
 
 
+def pose_guider_layers(conditioning_embedding_channels: int, block_out_channels, conditioning_channels: int = 3):
+    """(name, cin, cout, stride) of PoseGuider's convs (src/models/pose_guider.py:14-52)."""
+    boc = tuple(block_out_channels)
+    layers = [("conv_in", conditioning_channels, boc[0], 1)]
+    k = 0
+    for i in range(len(boc) - 1):
+        layers.append((f"blocks.{k}", boc[i], boc[i], 1))
+        layers.append((f"blocks.{k + 1}", boc[i], boc[i + 1], 2))
+        k += 2
+    layers.append(("conv_out", boc[-1], conditioning_embedding_channels, 1))
+    return layers
+
+
+def pose_guider_spec(conditioning_embedding_channels: int, block_out_channels=(16, 32, 64, 128), conditioning_channels: int = 3):
+    """State-dict keys -> shapes of a PoseGuider (no device needed)."""
+    spec = OrderedDict()
+    for name, cin, cout, _ in pose_guider_layers(conditioning_embedding_channels, block_out_channels, conditioning_channels):
+        spec[name + ".weight"] = (cout, cin, 3, 3)
+        spec[name + ".bias"] = (cout,)
+    return spec
+
+
 class PoseGuider:
     def __init__(self, conditioning_embedding_channels: int, conditioning_channels: int = 3,
                  block_out_channels: Tuple[int] = (16, 32, 64, 128), device="cuda", dtype=torch.bfloat16):
         self._device, self._dtype = torch.device(device), dtype
         hip.dtype_code(dtype)
-        boc = tuple(block_out_channels)
         self.out_channels = conditioning_embedding_channels
-        self.layers = [("conv_in", conditioning_channels, boc[0], 1)]
-        k = 0
-        for i in range(len(boc) - 1):
-            self.layers.append((f"blocks.{k}", boc[i], boc[i], 1))
-            self.layers.append((f"blocks.{k + 1}", boc[i], boc[i + 1], 2))
-            k += 2
-        self.layers.append(("conv_out", boc[-1], conditioning_embedding_channels, 1))
-        self.spec = OrderedDict()
-        for name, cin, cout, _ in self.layers:
-            self.spec[name + ".weight"] = (cout, cin, 3, 3)
-            self.spec[name + ".bias"] = (cout,)
+        self.layers = pose_guider_layers(conditioning_embedding_channels, block_out_channels, conditioning_channels)
+        self.spec = pose_guider_spec(conditioning_embedding_channels, block_out_channels, conditioning_channels)
         self.w = {}
         self._loaded = False
 

@@ -228,3 +228,21 @@ def test_unet2d_reference_spec_matches_reference_keys(golden_dir):
     ref = json.load(open(os.path.join(golden_dir, "unet2d_keys_full.json")))
     mine = unet2d_reference_spec()
     assert len(ref) == 682 and set(ref) == set(mine) and all(tuple(ref[k]) == tuple(mine[k]) for k in ref)
+
+
+def test_oracle_cache_entries_are_current_and_reproduce():
+    """tests/golden/oracle_cache: every committed entry carries the key of the CURRENT oracle / case sources (a stale entry
+    would only make the GPU suite slow again, never wrong: it is recomputed), and one entry is recomputed here and must match
+    bit for bit (the entries are this oracle's outputs, nothing else)."""
+    import glob
+    import os
+    from tests import oracle_cache as oc
+    files = sorted(glob.glob(os.path.join(oc.CACHE_DIR, "*.pt")))
+    assert len(files) >= 6
+    for f in files:
+        name = os.path.splitext(os.path.basename(f))[0]
+        assert torch.load(f, map_location="cpu")["key"] == oc._key(name, ""), f"{name}: regenerate with tools/gen_oracle_cache.py"
+    from tests import test_pipeline_gpu as TP
+    got = TP.oracle_pipeline_fp32(TP.build_weights("cpu"), 8, 12, 4)
+    ref = torch.load(os.path.join(oc.CACHE_DIR, "pipeline_fp32_8_12_4.pt"), map_location="cpu")["value"]
+    assert torch.equal(got["want"], ref["want"]) and all(torch.equal(a, b) for a, b in zip(got["traj"], ref["traj"]))

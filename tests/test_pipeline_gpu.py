@@ -6,6 +6,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from mmgt_amd.synthetic import hash_uniform, synth_masks, synth_state_dict  # noqa: E402
+from tests.oracle_cache import cached  # noqa: E402
 
 
 def _inputs(frames, latent):
@@ -17,18 +18,64 @@ def _inputs(frames, latent):
                 latents=hash_uniform("p.noise", (1, 4, frames, latent, latent), 1.7))
 
 
-@pytest.fixture(scope="module")
-def weights():
-    from mmgt_amd.side_models import PoseGuider
+def build_weights(dev):
+    from mmgt_amd.side_models import pose_guider_spec
     from mmgt_amd.unet3d_spec import unet2d_reference_spec, unet3d_spec
     from mmgt_amd.vae import vae_decoder_spec
-    dev = "cuda:0"
-    pg_spec = PoseGuider(320, block_out_channels=(16, 32, 96, 256), device=dev).spec
-    sds = dict(unet=synth_state_dict(unet3d_spec(), device=dev),
-               refnet=synth_state_dict(unet2d_reference_spec(), prefix="refnet.", device=dev),
-               pose=synth_state_dict(pg_spec, prefix="pose_guider.", device=dev),
-               vae=synth_state_dict(vae_decoder_spec(), prefix="vae.", device=dev))
+    pg_spec = pose_guider_spec(320, (16, 32, 96, 256))
+    return dict(unet=synth_state_dict(unet3d_spec(), device=dev),
+                refnet=synth_state_dict(unet2d_reference_spec(), prefix="refnet.", device=dev),
+                pose=synth_state_dict(pg_spec, prefix="pose_guider.", device=dev),
+                vae=synth_state_dict(vae_decoder_spec(), prefix="vae.", device=dev))
+
+
+@pytest.fixture(scope="module")
+def weights():
+    sds = build_weights("cuda:0")
     return sds, {k: {n: t.cpu() for n, t in v.items()} for k, v in sds.items()}
+
+
+def oracle_pipeline_fp32(sds_cpu, frames, ctx, ov):
+    """(latent trajectory, decoded video) of the oracle pipeline for test_pipeline_fp32_matches_oracle."""
+    from oracle import pipeline_ref
+    inp = _inputs(frames, 8)
+    traj = []
+    with torch.no_grad():
+        want = pipeline_ref.pose2vid(sds_cpu["unet"], sds_cpu["refnet"], sds_cpu["pose"], sds_cpu["vae"],
+                                     clip_image_embeds=inp["clip"], ref_image_latents=inp["ref_lat"], pose_images=inp["pose"],
+                                     audio_tensor=inp["audio"], full_mask=inp["full"], face_mask=inp["face"],
+                                     lip_mask=inp["lips"], latents=inp["latents"], num_inference_steps=4, guidance_scale=3.5,
+                                     motion_scale=[1.0, 1.0, 2.0], context_frames=ctx, context_overlap=ov, trajectory=traj)
+    return {"traj": traj, "want": want}
+
+
+def oracle_pipeline_bf16_floor(sds_cpu):
+    """(fp32 oracle final latents, |CPU-bf16 oracle - fp32 oracle|) for test_pipeline_bf16_within_measured_noise_floor."""
+    from oracle import pipeline_ref
+    inp = _inputs(8, 8)
+    kw = dict(clip_image_embeds=inp["clip"], ref_image_latents=inp["ref_lat"], pose_images=inp["pose"],
+              audio_tensor=inp["audio"], full_mask=inp["full"], face_mask=inp["face"], lip_mask=inp["lips"],
+              latents=inp["latents"], num_inference_steps=4, guidance_scale=3.5, motion_scale=[1.0, 1.0, 2.0], decode=False)
+    with torch.no_grad():
+        want = pipeline_ref.pose2vid(sds_cpu["unet"], sds_cpu["refnet"], sds_cpu["pose"], sds_cpu["vae"], **kw)
+        floor = (pipeline_ref.pose2vid(sds_cpu["unet"], sds_cpu["refnet"], sds_cpu["pose"], sds_cpu["vae"],
+                                       unet_dtype=torch.bfloat16, **kw) - want).abs()
+    return {"want": want, "floor": floor}
+
+
+def oracle_long_video(sds_cpu):
+    """Latent trajectory of the oracle for test_long_video_96_frames_six_wrapping_windows (L = 96, 2 steps)."""
+    from oracle import pipeline_ref
+    inp = _inputs(96, 8)
+    traj = []
+    with torch.no_grad():
+        pipeline_ref.pose2vid(sds_cpu["unet"], sds_cpu["refnet"], sds_cpu["pose"], sds_cpu["vae"],
+                              clip_image_embeds=inp["clip"], ref_image_latents=inp["ref_lat"], pose_images=inp["pose"],
+                              audio_tensor=inp["audio"], full_mask=inp["full"], face_mask=inp["face"], lip_mask=inp["lips"],
+                              latents=inp["latents"], num_inference_steps=2, guidance_scale=3.5,
+                              motion_scale=[1.0, 1.0, 2.0], context_frames=24, context_overlap=8, decode=False,
+                              trajectory=traj)
+    return {"traj": traj}
 
 
 def _build(sds, dtype):
@@ -54,16 +101,10 @@ def _build(sds, dtype):
 
 @pytest.mark.parametrize("frames,ctx,ov", [(8, 12, 4), (14, 8, 2)])
 def test_pipeline_fp32_matches_oracle(weights, frames, ctx, ov):
-    from oracle import pipeline_ref
     sds, sds_cpu = weights
     inp = _inputs(frames, 8)
-    traj = []
-    with torch.no_grad():
-        want = pipeline_ref.pose2vid(sds_cpu["unet"], sds_cpu["refnet"], sds_cpu["pose"], sds_cpu["vae"],
-                                     clip_image_embeds=inp["clip"], ref_image_latents=inp["ref_lat"], pose_images=inp["pose"],
-                                     audio_tensor=inp["audio"], full_mask=inp["full"], face_mask=inp["face"],
-                                     lip_mask=inp["lips"], latents=inp["latents"], num_inference_steps=4, guidance_scale=3.5,
-                                     motion_scale=[1.0, 1.0, 2.0], context_frames=ctx, context_overlap=ov, trajectory=traj)
+    ref = cached(f"pipeline_fp32_{frames}_{ctx}_{ov}", lambda: oracle_pipeline_fp32(sds_cpu, frames, ctx, ov))
+    traj, want = ref["traj"], ref["want"]
     pipe = _build(sds, torch.float32)
     got_traj = []
     out = pipe(None, inp["pose"], inp["audio"], inp["full"], inp["face"], inp["lips"], 64, 64, frames, 4, 3.5,
@@ -80,16 +121,10 @@ def test_pipeline_fp32_matches_oracle(weights, frames, ctx, ov):
 def test_pipeline_bf16_within_measured_noise_floor(weights):
     """bf16 product mode, 4 DDIM steps: final latents against the fp32 oracle, gated at 1.5x the error the SAME oracle makes
     when its denoiser runs under PyTorch CPU bf16 on the same inputs (measured here, not quoted)."""
-    from oracle import pipeline_ref
     sds, sds_cpu = weights
     inp = _inputs(8, 8)
-    kw = dict(clip_image_embeds=inp["clip"], ref_image_latents=inp["ref_lat"], pose_images=inp["pose"],
-              audio_tensor=inp["audio"], full_mask=inp["full"], face_mask=inp["face"], lip_mask=inp["lips"],
-              latents=inp["latents"], num_inference_steps=4, guidance_scale=3.5, motion_scale=[1.0, 1.0, 2.0], decode=False)
-    with torch.no_grad():
-        want = pipeline_ref.pose2vid(sds_cpu["unet"], sds_cpu["refnet"], sds_cpu["pose"], sds_cpu["vae"], **kw)
-        floor = (pipeline_ref.pose2vid(sds_cpu["unet"], sds_cpu["refnet"], sds_cpu["pose"], sds_cpu["vae"],
-                                       unet_dtype=torch.bfloat16, **kw) - want).abs()
+    ref = cached("pipeline_bf16_floor", lambda: oracle_pipeline_bf16_floor(sds_cpu))
+    want, floor = ref["want"], ref["floor"]
     pipe = _build(sds, torch.bfloat16)
     got = pipe(None, inp["pose"], inp["audio"], inp["full"], inp["face"], inp["lips"], 64, 64, 8, 4, 3.5,
                motion_scale=[1.0, 1.0, 2.0], latents=inp["latents"], clip_image_embeds=inp["clip"],
@@ -108,21 +143,13 @@ def test_long_video_96_frames_six_wrapping_windows(weights):
     must agree with it to fp32 rounding."""
     import os
     import torch.distributed as dist
-    from oracle import pipeline_ref
     from mmgt_amd.context import uniform
     sds, sds_cpu = weights
     L = 96
     wins = list(uniform(0, 2, L, 24, 1, 8))
     assert len(wins) == 6 and wins[-1][0] == 80 and wins[-1][-1] == 7
     inp = _inputs(L, 8)
-    traj = []
-    with torch.no_grad():
-        pipeline_ref.pose2vid(sds_cpu["unet"], sds_cpu["refnet"], sds_cpu["pose"], sds_cpu["vae"],
-                              clip_image_embeds=inp["clip"], ref_image_latents=inp["ref_lat"], pose_images=inp["pose"],
-                              audio_tensor=inp["audio"], full_mask=inp["full"], face_mask=inp["face"], lip_mask=inp["lips"],
-                              latents=inp["latents"], num_inference_steps=2, guidance_scale=3.5,
-                              motion_scale=[1.0, 1.0, 2.0], context_frames=24, context_overlap=8, decode=False,
-                              trajectory=traj)
+    traj = cached("long_video_96", lambda: oracle_long_video(sds_cpu))["traj"]
     pipe = _build(sds, torch.float32)
     kw = dict(motion_scale=[1.0, 1.0, 2.0], context_frames=24, context_overlap=8, latents=inp["latents"],
               clip_image_embeds=inp["clip"], ref_image_latents=inp["ref_lat"], decode=False)

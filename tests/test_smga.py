@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.oracle_cache import cached  # noqa: E402
+
 from oracle import smga_ref as R
 from tests import smga_cases as sc
 
@@ -76,6 +78,21 @@ def test_hip_decoder_fp32_matches_reference_golden_and_oracle(gold, spec):
                                    gold[f"guided_{name}"], rtol=1e-3, atol=2e-4)
 
 
+def smga_bf16_floor(spec, gold):
+    """|oracle sampler with bf16 weights / activations (fp32 sampler state: what the HIP bf16 mode does) - reference sample|."""
+    inp = sc.smga_inputs()
+    noises = sc.sampler_noises()
+    sd16 = {k: (v.bfloat16() if v.is_floating_point() else v) for k, v in sc.smga_state_dict(spec).items()}
+    cfg = R.SMGAConfig()
+    orig = R.guided_forward
+    try:
+        R.guided_forward = lambda sd, c, x, cf, ce, tc, w: orig(sd16, c, x.bfloat16(), cf.bfloat16(), ce.bfloat16(), tc, w).float()
+        with torch.no_grad():
+            return (R.ddim_sample(None, cfg, inp["cond_frame"][:1], inp["cond"][:1], noises) - gold["ddim_sample"]).abs()
+    finally:
+        R.guided_forward = orig
+
+
 @pytest.mark.gpu
 def test_hip_ddim_sampler_matches_reference_golden(gold, spec):
     """The whole 50-step guided DDIM sampler (eta = 1, x0 clipped) on the reference's own noise draws: fp32 mode against the
@@ -91,16 +108,7 @@ def test_hip_ddim_sampler_matches_reference_golden(gold, spec):
     m16 = _hip_model(spec, torch.bfloat16)
     out16 = GestureDiffusion(m16, 80, 402).ddim_sample((1, 80, 402), inp["cond_frame"][:1].cuda(), inp["cond"][:1].cuda(), noises=noises)
     d16 = (out16.cpu() - gold["ddim_sample"]).abs()
-    sd16 = {k: (v.bfloat16() if v.is_floating_point() else v) for k, v in sc.smga_state_dict(spec).items()}
-    # floor: the oracle's guided forward with bf16 weights / activations, fp32 sampler state (what the HIP bf16 mode does)
-    cfg = R.SMGAConfig()
-    orig = R.guided_forward
-    try:
-        R.guided_forward = lambda sd, c, x, cf, ce, tc, w: orig(sd16, c, x.bfloat16(), cf.bfloat16(), ce.bfloat16(), tc, w).float()
-        with torch.no_grad():
-            floor = (R.ddim_sample(None, cfg, inp["cond_frame"][:1], inp["cond"][:1], noises) - gold["ddim_sample"]).abs()
-    finally:
-        R.guided_forward = orig
+    floor = cached("smga_sampler_bf16_floor", lambda: smga_bf16_floor(spec, gold))
     print(f"SMGA sampler bf16 mode: HIP max|d| {d16.max().item():.3e} mean {d16.mean().item():.3e}; CPU-bf16 floor max "
           f"{floor.max().item():.3e} mean {floor.mean().item():.3e}")
     assert torch.isfinite(out16).all() and d16.mean() <= 1.5 * floor.mean() + 1e-4

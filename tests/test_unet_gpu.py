@@ -14,6 +14,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.oracle_cache import cached  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 from mmgt_amd.synthetic import synth_state_dict  # noqa: E402
@@ -141,7 +143,7 @@ def test_unet_full_resolution_512x512_six_frames(full_sd, golden_dir):
     at the north-star tolerance, bf16 product mode against the same reference at the bf16 noise floor."""
     sd_gpu, sd_cpu = full_sd
     case = dict(gc.UNET_CASES["full_cfg1"], frames=6, latent=64, timestep=499)
-    ref = _run_oracle(sd_cpu, case)
+    ref = cached("unet_512x512_six_frames", lambda: _run_oracle(sd_cpu, case))
     out = _run_hip(sd_gpu, case, torch.float32)
     d = (out - ref).abs()
     print("512x512x6 fp32 mode: max|d|", d.max().item(), "mean|x|", ref.abs().mean().item())
