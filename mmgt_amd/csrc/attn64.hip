@@ -21,7 +21,8 @@ constexpr float RESCALE_LAG = 8.f;                              // see attention
 
 __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
   typedef bf16_t T;
-  // (Double-buffered tiles -- tile t + 1 written at the end of tile t's work, one barrier per tile -- measured 1 % slower.)
+  // (Double-buffered tiles -- tile t + 1 written at the end of tile t's work, one barrier per tile -- measured 1 % slower;
+  // 128-key staged tiles worked as two 64-key blocks, half the barriers per key: +0.8 %.)
   constexpr int NBUF = 1;
   __shared__ __attribute__((aligned(16))) char smem[NBUF * TILE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
