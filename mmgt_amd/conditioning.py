@@ -5,6 +5,7 @@ define what `Pose2VideoPipeline.__call__` is handed.
   * mask_pyramid        src/dataset/image_processor.py:311-333 (+ transforms :75-102): a 64x64 "L" mask per frame ->
                         four levels (H/8/2^k)^2, ToTensor() range [0,1], flattened to (L, N_k)
   * full_mask_from_lips scripts/audio2vid.py:470-476 convention: full[k] = 1 + lips[k]
+  * full_mask_with_hands scripts/pose2vid.py:266-271: clamp(1 - face + lips + hands, 0, 1) per level
 
 The host functions below (`process_audio_emb`, `mask_pyramid`) are the original plain-torch forms.  The `*_device` functions
 run the same producers on the GPU through libmmgt_hip.so (csrc/conditioning.hip):
@@ -47,6 +48,13 @@ def mask_pyramid(masks: torch.Tensor, img_size: int = 512) -> List[torch.Tensor]
 
 def full_mask_from_lips(lips: List[torch.Tensor]) -> List[torch.Tensor]:
     return [1 + l for l in lips]
+
+
+def full_mask_with_hands(face: List[torch.Tensor], lips: List[torch.Tensor], hands: List[torch.Tensor]) -> List[torch.Tensor]:
+    """`--hands_mask_path` of scripts/pose2vid.py (:239-271): full = clamp(1 - face + lips + hands, 0, 1).  The reference indexes
+    its 4-level lists with the FRAME index there and fails on any real input; this is the evident intent,
+    applied per pyramid level (the hands masks go through the same blur -> pyramid producers as face and lips)."""
+    return [torch.clamp(1.0 - f.float() + l.float() + h.float(), 0.0, 1.0) for f, l, h in zip(face, lips, hands)]
 
 
 # ------------------------------------------------------------------------------------------------ device producers (SURVEY 8f-3)

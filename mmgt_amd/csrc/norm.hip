@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x0,
                                                        T* __restrict__ out, int HW, int G, float eps, int silu) {
   constexpr int VEC = VecIO<T>::VEC;
   __shared__ float part[256 * VEC];
-  __shared__ float chan[GPW * 80];          // per-channel sums of the slab (<= 4 x 80 channels)
+  __shared__ float chan[320];               // per-channel sums of the slab (the dispatch guard admits cw = GPW * C / G <= 320 channels)
   __shared__ float gstat[2][GPW];
   const int C = C0 + C1, cg = C / G, cw = GPW * cg, nvw = cw / VEC;
   const int n = blockIdx.y, c_lo = blockIdx.x * cw;

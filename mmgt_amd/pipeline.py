@@ -88,6 +88,10 @@ class Pose2VideoPipeline:
         f = latents.shape[2]
         per = (f + world - 1) // world                       # equal runs (the last ranks repeat the final frame as padding)
         idx = torch.arange(rank * per, (rank + 1) * per, device=latents.device).clamp_(max=f - 1)
+        if uint8:                                            # (b, per, H, W, 3) uint8 per rank: a quarter of the fp32 bytes on the wire
+            part = self.vae.decode_video_uint8(latents[:, :, idx])
+            parts = parallel.allgather_window_predictions(part, group)
+            return torch.cat(parts, dim=1)[:, :f].cpu().numpy()
         part = self.vae.decode_video(latents[:, :, idx])
         parts = parallel.allgather_window_predictions(part, group)
         return torch.cat(parts, dim=2)[:, :, :f].cpu().float().numpy()

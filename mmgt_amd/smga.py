@@ -31,6 +31,56 @@ def cosine_alphas_cumprod(n_timestep=1000, s=8e-3):
     return torch.cumprod(1.0 - betas.float(), dim=0)
 
 
+def smga_spec(nfeats=402, seq_len=80, latent_dim=512, ff_size=1024, num_layers=8, cond_feature_dim=1059) -> Dict[str, tuple]:
+    """{state-dict key: shape} of the reference's GestureDecoder (src/audio2pose_model/model.py:324-431; 473 keys at the SMGA
+    configuration) in registration order -- what `load_state_dict` expects and what scripts/audio2vid.py --synthetic fills."""
+    d, ff = latent_dim, ff_size
+    spec: Dict[str, tuple] = {}
+
+    def lin(p, n, k):
+        spec[p + ".weight"], spec[p + ".bias"] = (n, k), (n,)
+
+    def ln(p):
+        spec[p + ".weight"], spec[p + ".bias"] = (d,), (d,)
+
+    def mha(p):
+        spec[p + ".in_proj_weight"], spec[p + ".in_proj_bias"] = (3 * d, d), (3 * d,)
+        lin(p + ".out_proj", d, d)
+
+    spec["null_cond_embed"], spec["null_cond_hidden"] = (1, seq_len, d), (1, d)
+    spec["rotary.freqs"] = (d // 2,)
+    lin("time_mlp.1", 4 * d, d)
+    lin("to_time_cond.0", d, 4 * d)
+    lin("to_time_tokens.0", 2 * d, 4 * d)
+    ln("norm_cond")
+    lin("input_projection", d, 2 * nfeats)
+    for i in range(2):
+        p = f"cond_encoder.{i}"
+        mha(p + ".self_attn")
+        lin(p + ".linear1", ff, d)
+        lin(p + ".linear2", d, ff)
+        ln(p + ".norm1")
+        ln(p + ".norm2")
+        spec[p + ".rotary.freqs"] = (d // 2,)
+    lin("cond_projection", d, cond_feature_dim)
+    ln("non_attn_cond_projection.0")
+    lin("non_attn_cond_projection.1", d, d)
+    lin("non_attn_cond_projection.3", d, d)
+    for i in range(num_layers):
+        p = f"seqTransDecoder.stack.{i}"
+        for a in ("face_self_attn", "face_cross_attn", "body_self_attn", "body_cross_attn", "self_attn"):
+            mha(f"{p}.{a}")
+        lin(p + ".linear1", ff, d)
+        lin(p + ".linear2", d, ff)
+        for n in ("face_1", "face_2", "face_3", "body_1", "body_2", "body_3", "final"):
+            ln(f"{p}.norm_{n}")
+        for n in ("face_1", "face_2", "face_3", "body_1", "body_2", "body_3", "final"):
+            lin(f"{p}.film_{n}.block.1", 2 * d, d)
+        spec[p + ".rotary.freqs"] = (d // 2,)
+    lin("final_layer", nfeats, d)
+    return spec
+
+
 class GestureDecoder:
     def __init__(self, nfeats=402, seq_len=80, latent_dim=512, ff_size=1024, num_layers=8, num_heads=8, dropout=0.1,
                  cond_feature_dim=1059, activation=None, use_rotary=True, device="cuda", dtype=torch.bfloat16, **kwargs):
@@ -199,7 +249,9 @@ class GestureDecoder:
         hidden = torch.cat([self.w["null_cond_hidden"].repeat(b, 1), cond_hidden], 0).contiguous()   # :471-473
         mem = torch.empty((2 * b, t + 2, d), device=dev, dtype=dt)
         mem[:, :t] = self._ln("norm_cond", tokens).view(2 * b, t, d)            # norm_cond is per token: the 80 condition tokens once
-        self._prep = dict(b=b, inc=inc, hidden=hidden, mem=mem, key=(cond_frame.data_ptr(), cond_embed.data_ptr()))
+        # `held` keeps the keyed tensors alive, so the allocator cannot hand their addresses to a different condition
+        self._prep = dict(b=b, inc=inc, hidden=hidden, mem=mem, key=self._prep_key(cond_frame, cond_embed),
+                          held=(cond_frame, cond_embed))
         return self._prep
 
     # ------------------------------------------------------------------------------------------ forward
@@ -251,8 +303,14 @@ class GestureDecoder:
             z = self.w["zero_ss"] = torch.zeros((nb, 2 * self.d), device=self._device, dtype=torch.float32)
         return z[:nb]
 
+    @staticmethod
+    def _prep_key(cond_frame, cond_embed):
+        # address alone can alias (a freed tensor's block is recycled; an in-place update keeps it): identity of the storage
+        # AND its version counter, shape and device -- the cached state holds a reference to both tensors (prepare())
+        return tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device), t.dtype) for t in (cond_frame, cond_embed))
+
     def _prep_for(self, cond_frame, cond_embed):
-        key = (cond_frame.data_ptr(), cond_embed.data_ptr())
+        key = self._prep_key(cond_frame, cond_embed)
         if self._prep is None or self._prep["key"] != key:
             self.prepare(cond_frame, cond_embed)
         return self._prep

@@ -105,7 +105,8 @@ def main():
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     timing = {}
     t0 = time.time()
-    keys = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "smga_keys.json")))
+    from mmgt_amd.smga import smga_spec
+    keys = smga_spec(cond_feature_dim=1059 if a.feature_type == "wavlm" else 35)
     smga_sd = {k: (synth_tensor("smga." + k, s) if not k.endswith("rotary.freqs") else torch.zeros(s)) for k, s in keys.items()}
     audio2pose = SMGA(feature_type=a.feature_type, device=dev, dtype=dtype, state_dict=smga_sd)             # :198-200
     pipe = build_synthetic_pipeline(dev, dtype)

@@ -28,7 +28,9 @@ def parse_args():
     p.add_argument("--pose_path", type=str)
     p.add_argument("--face_mask_path", type=str)
     p.add_argument("--lips_mask_path", type=str)
-    p.add_argument("--hands_mask_path", type=str)
+    p.add_argument("--hands_mask_path", type=str,
+                   help="(L, h, w) uint8 .npy of hands masks, or 'synthetic': full = clamp(1 - face + lips + hands, 0, 1) per level "
+                        "(reference :239-271, SURVEY App. C-8); without it full = 1 + lips (the audio2vid convention)")
     p.add_argument("--out_dir", type=str, default="./output")
     p.add_argument("-W", type=int, default=512)
     p.add_argument("-H", type=int, default=512)
@@ -114,7 +116,17 @@ def main():
     clip_id = rank if a.clip_parallel else 0                  # clip-parallel: rank r samples its own clip
     gen = torch.manual_seed(a.seed + clip_id)                 # :171
     lips, face = synth_masks("p2v.lips", a.L, lat), synth_masks("p2v.face", a.L, lat)
-    full = [1 + l for l in lips]                              # audio2vid convention (scripts/audio2vid.py:470-476)
+    if a.hands_mask_path:                                     # blur (21, 21) -> 4-level pyramid, like the lips masks (:249-263)
+        from mmgt_amd import conditioning as C
+        import numpy as np
+        if a.hands_mask_path == "synthetic":
+            hands_u8 = (synth_masks("p2v.hands", a.L, 64)[0].view(a.L, 64, 64) * 255).to(torch.uint8)
+        else:
+            hands_u8 = torch.from_numpy(np.load(a.hands_mask_path))[:a.L].to(torch.uint8)
+        hands = [h.cpu() for h in C.mask_pyramid_device(C.blur_mask_device(hands_u8.to(dev).contiguous(), 21), a.H)]
+        full = C.full_mask_with_hands(face, lips, hands)
+    else:
+        full = [1 + l for l in lips]                          # audio2vid convention (scripts/audio2vid.py:470-476)
     pose = hash_uniform(f"p2v.pose{clip_id or ''}", (1, 3, a.L, a.H, a.W), 0.5) + 0.5
     audio = torch.zeros(1, a.L, 32, 768)                      # pose2vid runs with null audio (:279)
     from PIL import Image
@@ -122,7 +134,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.time()
     out = pipe(ref_img, pose, audio, full, face, lips, a.W, a.H, a.L, a.steps, a.cfg, generator=gen,
-               motion_scale=[1.0, 1.0, 2.0], context_frames=a.num_c,
+               motion_scale=[1.0, 1.0, 2.0], context_frames=a.num_c, output_type="uint8" if a.clip_parallel else "tensor",
                decode=not a.no_decode,                         # CLIP embedding and ref_image_latents: HIP encoders, from ref_img
                window_group=True if a.window_parallel else None)
     torch.cuda.synchronize()

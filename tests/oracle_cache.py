@@ -2,12 +2,15 @@
 
 The oracle's CPU forward is most of those tests' wall time (a 6-window, 2-step sampler run of the CPU UNet takes 1.5 minutes
 even on the GPU box's 128 cores).  An entry holds what `fn()` returned together with a key = SHA-256 over the sources it depends on
-(oracle/*.py, the synthetic-weight generator, the test-case tables) and the entry's parameters: if any of them changes the key no
-longer matches and the test simply recomputes the oracle, so a stale entry can never be compared against.  Entries are written by
+(oracle/*.py, the synthetic-weight generator, the test-case tables), the SOURCE TEXT of the functions that produce the entry
+(`deps`: the oracle drivers of the test modules, their input builders, the spec functions of the side models) and the torch
+version: if any of them changes the key no longer matches and the test simply recomputes the oracle instead of comparing against
+a stale entry.  Entries are written by
 `python tools/gen_oracle_cache.py` (CPU only; it calls the very functions the tests call) and committed; nothing under
 mmgt_amd/ reads them."""
 import glob
 import hashlib
+import inspect
 import os
 
 import torch
@@ -32,10 +35,44 @@ def _key(name, extra):
     return hashlib.sha256((_base + "|" + name + "|" + extra).encode()).hexdigest()
 
 
-def cached(name, fn, extra=""):
+def _deps_digest(deps):
+    h = hashlib.sha256(torch.__version__.encode())
+    for d in deps:
+        h.update(getattr(d, "__qualname__", repr(d)).encode())
+        h.update(inspect.getsource(d).encode())
+    return h.hexdigest()
+
+
+def entry_specs():
+    """name -> (extra, deps) of every entry: the parameters and the callables (outside the always-hashed sources) whose source
+    text the entry depends on.  One table for the tests, tools/gen_oracle_cache.py and the currency check of the CPU suite."""
+    from mmgt_amd.side_models import pose_guider_spec
+    from mmgt_amd.unet3d_spec import unet2d_reference_spec
+    from mmgt_amd.vae import vae_decoder_spec
+    from tests import golden_cases as gc
+    from tests import test_pipeline_gpu as TP
+    from tests import test_smga as TS
+    from tests import test_unet_gpu as TU
+    pipe = (TP._inputs, TP.build_weights, pose_guider_spec, unet2d_reference_spec, vae_decoder_spec)
+    return {
+        "pipeline_fp32_8_12_4": ("8,12,4", pipe + (TP.oracle_pipeline_fp32,)),
+        "pipeline_fp32_14_8_2": ("14,8,2", pipe + (TP.oracle_pipeline_fp32,)),
+        "pipeline_bf16_floor": ("", pipe + (TP.oracle_pipeline_bf16_floor,)),
+        "long_video_96": ("", pipe + (TP.oracle_long_video,)),
+        "unet_512x512_six_frames": (repr(sorted(TU.SIX_FRAME_CASE.items())), (TU._run_oracle,)),
+        "smga_sampler_bf16_floor": ("", (TS.smga_bf16_floor,)),
+    }
+
+
+def entry_key(name):
+    extra, deps = entry_specs()[name]
+    return _key(name, extra + "|" + _deps_digest(deps))
+
+
+def cached(name, fn):
     """fn() -> tensors (or nested lists / dicts of tensors); served from the committed entry when its key matches."""
     path = os.path.join(CACHE_DIR, name + ".pt")
-    key = _key(name, extra)
+    key = entry_key(name)
     if os.path.exists(path):
         d = torch.load(path, map_location="cpu")
         if d.get("key") == key:

@@ -241,7 +241,7 @@ def test_oracle_cache_entries_are_current_and_reproduce():
     assert len(files) >= 6
     for f in files:
         name = os.path.splitext(os.path.basename(f))[0]
-        assert torch.load(f, map_location="cpu")["key"] == oc._key(name, ""), f"{name}: regenerate with tools/gen_oracle_cache.py"
+        assert torch.load(f, map_location="cpu")["key"] == oc.entry_key(name), f"{name}: regenerate with tools/gen_oracle_cache.py"
     from tests import test_pipeline_gpu as TP
     got = TP.oracle_pipeline_fp32(TP.build_weights("cpu"), 8, 12, 4)
     ref = torch.load(os.path.join(oc.CACHE_DIR, "pipeline_fp32_8_12_4.pt"), map_location="cpu")["value"]

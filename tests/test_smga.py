@@ -112,3 +112,30 @@ def test_hip_ddim_sampler_matches_reference_golden(gold, spec):
     print(f"SMGA sampler bf16 mode: HIP max|d| {d16.max().item():.3e} mean {d16.mean().item():.3e}; CPU-bf16 floor max "
           f"{floor.max().item():.3e} mean {floor.mean().item():.3e}")
     assert torch.isfinite(out16).all() and d16.mean() <= 1.5 * floor.mean() + 1e-4
+    # the maximum too: 50 clipped eta = 1 steps saturate a few coordinates at +-1, where one flipped clip decision is a full-range
+    # error in either implementation, so the bound is the floor's own maximum x 1.5 (plus one bf16 ulp at 1.0)
+    assert d16.max() <= 1.5 * floor.max() + 2 ** -7
+
+
+@pytest.mark.gpu
+def test_hip_decoder_forward_does_not_reuse_a_recycled_condition(gold, spec):
+    """forward() caches the condition-only state; a NEW condition allocated at the freed address of the previous one (what the
+    caching allocator does with per-slice `.cuda()` tensors) or updated in place must not hit that cache."""
+    inp = sc.smga_inputs()
+    m = _hip_model(spec, torch.float32)
+    x, times = inp["x"][:1].cuda(), torch.full((1,), 999, dtype=torch.long)
+    cf, ce = inp["cond_frame"][:1].cuda(), inp["cond"][:1].cuda()
+    a = m(x, cf, ce, times).clone()
+    ptrs = (cf.data_ptr(), ce.data_ptr())
+    ce.mul_(-0.5)                                   # in place: same address, new version
+    b_ = m(x, cf, ce, times).clone()
+    assert (a - b_).abs().max() > 1e-4
+    ce2_host = (inp["cond"][:1] * 0.25 + 0.1)
+    del ce
+    torch.cuda.synchronize()
+    ce2 = ce2_host.cuda()                           # very likely the recycled block; either way the result must be the new cond's
+    c = m(x, cf, ce2, times).clone()
+    m._prep = None
+    c_ref = m(x, cf, ce2, times)
+    torch.testing.assert_close(c, c_ref, rtol=0, atol=0)
+    assert (c - b_).abs().max() > 1e-4

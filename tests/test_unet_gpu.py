@@ -136,13 +136,16 @@ def test_unet_wider_geometry_fp32(full_sd):
     torch.testing.assert_close(out, ref, rtol=1e-3, atol=1e-4)
 
 
+SIX_FRAME_CASE = dict(gc.UNET_CASES["full_cfg1"], frames=6, latent=64, timestep=499)
+
+
 def test_unet_full_resolution_512x512_six_frames(full_sd, golden_dir):
     """BASELINE config-2 spatial size (512x512 px = 64x64 latent, 4096 tokens and 4096 bank keys at level 0) on 6 frames:
     the shapes at which the production tile configurations are chosen (128x320 conv tile from 49152 output rows, 256x128
     for the GEGLU / long-K GEMMs, 64-key attention tiles without ragged-tail code).  fp32-I/O mode against the CPU oracle
     at the north-star tolerance, bf16 product mode against the same reference at the bf16 noise floor."""
     sd_gpu, sd_cpu = full_sd
-    case = dict(gc.UNET_CASES["full_cfg1"], frames=6, latent=64, timestep=499)
+    case = SIX_FRAME_CASE
     ref = cached("unet_512x512_six_frames", lambda: _run_oracle(sd_cpu, case))
     out = _run_hip(sd_gpu, case, torch.float32)
     d = (out - ref).abs()

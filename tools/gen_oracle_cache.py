@@ -48,7 +48,7 @@ def main():
         from tests import golden_cases as gc
         from tests import test_unet_gpu as TU
         sd_cpu = synth_state_dict(unet3d_spec(), device="cpu")
-        case = dict(gc.UNET_CASES["full_cfg1"], frames=6, latent=64, timestep=499)
+        case = TU.SIX_FRAME_CASE
         emit("unet_512x512_six_frames", lambda: TU._run_oracle(sd_cpu, case))
         del sd_cpu
     if want("smga_sampler_bf16_floor"):

@@ -77,13 +77,21 @@ def main():
     import contextlib
     # run bench.main() (its own warmup is recorded too: drop those records afterwards)
     buf = io.StringIO()
-    marks = []
-    orig_run = None
+    marks = []                                                  # len(records) at the start of every denoise step
+    from mmgt_amd.unet3d import UNet3DConditionModel
+    orig_dw = UNet3DConditionModel.denoise_window
+
+    def marked(self, *a, **k):
+        marks.append(len(records))
+        return orig_dw(self, *a, **k)
+    UNet3DConditionModel.denoise_window = marked
     with contextlib.redirect_stdout(buf):
         bench.main()
     torch.cuda.synchronize()
-    per = len(records) // (steps + 1)
-    recs = records[per:]                                        # drop the warmup step
+    UNet3DConditionModel.denoise_window = orig_dw
+    # the records in front of marks[0] are once-per-clip set-up (set_banks: 32 projections, ...); marks[1] is the first timed step
+    assert len(marks) >= steps + 1, (len(marks), steps)
+    recs = records[marks[-steps]:]                              # the timed steps only (warm-up and set-up dropped)
     agg = collections.OrderedDict()
     for (k, fl), e0, e1 in recs:
         t = e0.elapsed_time(e1) * 1e3
