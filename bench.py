@@ -233,6 +233,54 @@ def extras(pipe, unet, dev, dtype):
         unet.set_banks(banks)
         return pg(pose)
     res["prologue_ms"] = _time_ms(prologue, reps=2, warm=1)
+    del vae, clip, refnet, pg
+    torch.cuda.empty_cache()
+    res.update(other_configs(pipe, unet, dev, dtype))
+    return res
+
+
+def other_configs(pipe, unet, dev, dtype):
+    """The denoise loop at the other BASELINE geometries, timed like the headline step (HIP events, inputs resident):
+      config5_ms_per_step   one DDIM step of the 96-frame long video: context 24, overlap 8 => 6 windows (pipeline_pose2vid_long.py:522-635)
+      ctx12_ms_per_window   the reference's SHIPPED window length, context_frames = 12 (pipeline_pose2vid_long.py:360-362,
+                            scripts/pose2vid.py:317-321), on the 24-frame clip (overlap 4)
+      smga_ms_per_slice     Stage 1 of config 3: one 80-frame slice of the SMGA sampler (50 DDIM steps x 2 guidance passes)"""
+    import torch
+    from mmgt_amd.context import uniform
+    from mmgt_amd.synthetic import synth_tensor
+    res = {}
+    sched = pipe.scheduler
+    dup = lambda ms: [torch.cat([m] * 2) for m in ms]
+
+    def loop_ms(frames, ctx, ov, tag, nsteps=2):
+        inp = build_inputs(dev, frames=frames, tag=tag)
+        unet.set_banks(inp["banks"])
+        ehs = torch.cat([torch.zeros(1, 1, 768, device=dev), inp["clip"].reshape(1, 1, 768)])
+        audio_pre = torch.cat([torch.zeros_like(inp["audio"]), inp["audio"]])
+        full, face, lips = dup(inp["full"]), dup(inp["face"]), dup(inp["lips"])
+        nwin = len(list(uniform(0, 25, frames, ctx, 1, ov)))
+        fn = lambda: pipe.denoise(inp["latents"], [sched.timesteps[3 + i] for i in range(nsteps)], ehs, inp["pose"], audio_pre, full, face,
+                                  lips, 3.5, inp["motion_scale"], context_frames=ctx, context_stride=1, context_overlap=ov,
+                                  num_inference_steps=25)
+        out = fn()
+        assert torch.isfinite(out).all()
+        return _time_ms(fn, reps=1, warm=0) / nsteps, nwin
+
+    ms, nwin = loop_ms(96, 24, 8, "bench.c5")
+    res["config5_ms_per_step"] = {"ms": ms, "windows_per_step": nwin, "ms_per_window": ms / nwin,
+                                  "what": "512x512x96, context 24, overlap 8, one GPU (BASELINE configs[4] geometry)"}
+    torch.cuda.empty_cache()
+    ms, nwin = loop_ms(FRAMES, 12, 4, "bench.c12")
+    res["ctx12_ms_per_window"] = {"ms": ms / nwin, "windows_per_step": nwin, "ms_per_step": ms,
+                                  "what": "512x512x24 clip sampled with the reference's shipped context_frames=12, overlap 4"}
+    # ---- SMGA (Stage 1): one 3.2-second slice
+    from mmgt_amd.smga import SMGA, smga_spec
+    sd = {k: (synth_tensor("smga." + k, shp) if not k.endswith("rotary.freqs") else torch.zeros(shp)) for k, shp in smga_spec().items()}
+    a2p = SMGA(feature_type="wavlm", device=dev, dtype=dtype, state_dict=sd)
+    from mmgt_amd.synthetic import hash_uniform
+    cond, init = hash_uniform("bench.smga.cond", (1, 80, 1059), 1.0), hash_uniform("bench.smga.init", (1, 402), 0.8)
+    gen = torch.Generator(device=dev).manual_seed(0)
+    res["smga_ms_per_slice"] = _time_ms(lambda: a2p.render_sample(cond_frame=init, cond=cond[0], generator=gen), reps=2, warm=1)
     return res
 
 

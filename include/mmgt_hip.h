@@ -124,6 +124,17 @@ int mmgt_nhwc_to_ncfhw(const void* in, float* out, int B, int C, int F, int H, i
  * Replaces: diffusers Timesteps(flip_sin_to_cos=True, shift 0) at unet_3d.py:496.  timesteps: fp32 [B] device. */
 int mmgt_timestep_features(const float* timesteps, void* out, int B, int dim, int dtype, void* stream);
 
+/* LayerNorm -> FeedForward(GEGLU) -> + residual of a transformer block as ONE launch, 320 channels, bf16 (csrc/ffn.hip):
+ *   out[m] = residual[m] + bias2 + W2 . (h * gelu(g)),  [h | g] = W1 . LN(x[m]) + b1     (ln_gamma == NULL: no LayerNorm)
+ * wimg: the weight image built by mmgt_amd/packing.py: pack_ff_fused (mmgt_ff_fused_image_bytes(C, inner) bytes; -1 if the shape
+ * is not supported).  The hidden activations never reach memory: x is read once, out written once.
+ * Replaces: the norm3 / ff_norm + `self.ff(...) + hidden_states` lines of src/models/attention.py:361,465,642,769 and
+ * src/models/motion_module.py:253-254 (diffusers FeedForward) at the 64x64 level. */
+int mmgt_ff_fused_image_bytes(int C, int inner);
+int mmgt_ff_fused(const void* x, long ldx, const float* ln_gamma, const float* ln_beta, float eps, const void* wimg,
+                  const float* bias2, const void* residual, long ldr, void* out, long ldo, int M, int C, int inner, int dtype,
+                  void* stream);
+
 /* Elementwise x -> silu(x) (time embedding activation, resnet.py:226) over n elements. */
 int mmgt_silu(const void* x, void* out, long n, int dtype, void* stream);
 

@@ -43,6 +43,9 @@ _SIGS = {
     "mmgt_nhwc_to_ncfhw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                    c_int, c_void_p]),
     "mmgt_timestep_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "mmgt_ff_fused_image_bytes": (c_int, [c_int, c_int]),
+    "mmgt_ff_fused": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long,
+                              c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_silu": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "mmgt_cfg_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_float,
                                    c_float, c_float, c_float, c_void_p]),
@@ -135,6 +138,17 @@ def gemm(a, w, bias=None, *, out=None, residual=None, bias2=None, bias2_rows=0, 
     assert out.shape == (M, n_out) and out.stride(1) == 1 and out.dtype == a.dtype
     if residual is not None:
         assert residual.shape == (M, n_out) and residual.stride(1) == 1 and residual.dtype == a.dtype
+    lim = (1 << 31) - 1                # 32-bit LDS-DMA offsets: an operand of 2 GiB or more is worked in runs of rows
+    if M * a.stride(0) * a.element_size() > lim and M > 1:
+        step = max(1, lim // (a.stride(0) * a.element_size()))
+        if bias2 is not None:
+            step = max(bias2_rows, step // bias2_rows * bias2_rows)
+        for m0 in range(0, M, step):
+            m1 = min(M, m0 + step)
+            gemm(a[m0:m1], w, bias, out=out[m0:m1], residual=None if residual is None else residual[m0:m1],
+                 bias2=None if bias2 is None else bias2[m0 // bias2_rows:(m1 + bias2_rows - 1) // bias2_rows], bias2_rows=bias2_rows,
+                 row_scale=None if row_scale is None else row_scale[m0:m1], alpha=alpha, act=act)
+        return out
     _check(lib().mmgt_gemm(_ptr(a), a.stride(0), _ptr(w), _ptr(_f32(bias, "bias")), _ptr(_f32(bias2, "bias2")),
                            bias2_rows, _ptr(_f32(row_scale, "row_scale")), alpha, _ptr(residual),
                            residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), M, N, K, act, 1,
@@ -202,6 +216,24 @@ def conv3x3(x, wp, bias=None, *, stride=1, upsample=False, bias2=None, bias2_row
     assert out.shape == (NB, oh, ow, cout) and out.is_contiguous()
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous()
+    # The kernels address every operand through 32-bit LDS-DMA offsets (2 GiB per tensor).  Larger tensors -- the PoseGuider and
+    # VAE convs of a 96-frame 512 x 512 clip -- are worked in runs of whole images: images are independent in a conv.
+    lim = (1 << 31) - 1
+    per_img = max(t.numel() // NB * t.element_size() for t in (x, out, x1, residual) if t is not None)
+    if per_img * NB > lim and NB > 1:
+        step = max(1, lim // per_img)
+        for n0 in range(0, NB, step):
+            n1 = min(NB, n0 + step)
+            b2 = None
+            if bias2 is not None:
+                m0, m1 = n0 * oh * ow, n1 * oh * ow
+                if m0 % bias2_rows:
+                    raise RuntimeError("conv3x3: a batch split inside a bias2 row group is not supported")
+                b2 = bias2[m0 // bias2_rows:(m1 + bias2_rows - 1) // bias2_rows]
+            conv3x3(x[n0:n1], wp, bias, stride=stride, upsample=upsample, bias2=b2, bias2_rows=bias2_rows,
+                    residual=None if residual is None else residual[n0:n1], act=act, x1=None if x1 is None else x1[n0:n1],
+                    out=out[n0:n1], pad_high_only=pad_high_only)
+        return out
     _check(lib().mmgt_conv3x3_nhwc(_ptr(x), C0, _ptr(x1), C1, NB, IH, IW, -2 if pad_high_only else stride, int(upsample), _ptr(wp),
                                    _ptr(_f32(bias, "bias")), _ptr(_f32(bias2, "bias2")), bias2_rows, _ptr(residual),
                                    _ptr(out), cout, act, dtype_code(x.dtype), _stream()), "mmgt_conv3x3_nhwc")
@@ -243,6 +275,26 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, pe_div=1, pe_mod=1, out=None):
     _check(lib().mmgt_layernorm(_ptr(x), x.stride(0), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), eps,
                                 _ptr(_f32(pe, "pe")), pe_div, pe_mod, _ptr(out), out.stride(0), rows, C,
                                 dtype_code(x.dtype), _stream()), "mmgt_layernorm")
+    return out
+
+
+def ff_fused_supported(C, inner, dtype):
+    return dtype == torch.bfloat16 and lib().mmgt_ff_fused_image_bytes(C, inner) > 0
+
+
+def ff_fused(x, ln_gamma, ln_beta, wimg, bias2, residual, inner, eps=1e-5, out=None):
+    """out = residual + bias2 + W2 . GEGLU(W1 . LN(x) + b1) in one launch (x (M, 320) bf16; wimg = packing.pack_ff_fused(...);
+    ln_gamma None: x is used as it is)."""
+    _dev(x, ln_gamma, ln_beta, wimg, bias2, residual)
+    assert x.dim() == 2 and x.stride(1) == 1 and residual.shape == x.shape and residual.stride(1) == 1 and residual.dtype == x.dtype
+    M, C = x.shape
+    assert wimg.dtype == torch.uint8 and wimg.is_contiguous() and wimg.numel() == lib().mmgt_ff_fused_image_bytes(C, inner)
+    if out is None:
+        out = torch.empty((M, C), device=x.device, dtype=x.dtype)
+    assert out.shape == (M, C) and out.stride(1) == 1 and out.dtype == x.dtype
+    _check(lib().mmgt_ff_fused(_ptr(x), x.stride(0), _ptr(_f32(ln_gamma, "ln_gamma")), _ptr(_f32(ln_beta, "ln_beta")), eps, _ptr(wimg),
+                               _ptr(_f32(bias2, "bias2")), _ptr(residual), residual.stride(0), _ptr(out), out.stride(0), M, C, inner,
+                               dtype_code(x.dtype), _stream()), "mmgt_ff_fused")
     return out
 
 

@@ -42,3 +42,44 @@ def pad_cols(w, k_pad):
 
 def round_up(x, m):
     return (x + m - 1) // m * m
+
+
+FF_STAGE = 61 * 1024      # bytes of one sub-block (32 hidden channels) of the fused FeedForward weight image (csrc/ffn.hip)
+
+
+def pack_ff_fused(w1, b1, w2):
+    """FeedForward(GEGLU) weights -> the LDS image of csrc/ffn.hip (mmgt_ff_fused), a uint8 tensor of inner / 32 sub-blocks of 61 KiB.
+    w1 (2 * inner, C) = ff.net.0.proj.weight (rows [h | gate], `chunk(2, -1)` order), b1 (2 * inner,), w2 (C, inner) = ff.net.2.weight.
+    Per sub-block sb (hidden channels 32 sb .. 32 sb + 31), every 1-KiB fragment lane-linear (lane l = (r = l & 31, hh = l >> 5) owns
+    bytes 16 l .. 16 l + 15):
+      [ks = 0 .. C/16 - 1][t = h, gate]   8 bf16  w1[t * inner + 32 sb + r][16 ks + 8 hh + j]                       (ff1 A fragments)
+      [u = 0 .. C/32 - 1][s = 0, 1]       8 bf16  w2[32 u + r][32 sb + 16 s + 8 (j >> 2) + 4 hh + (j & 3)]          (ff2 A fragments,
+                                          k in the order of the GEGLU'd accumulator registers: ffn.hip header)
+      64 fp32                             b1[32 sb + i] (i < 32) | b1[inner + 32 sb + i]"""
+    inner, C = w2.shape[1], w2.shape[0]
+    assert w1.shape == (2 * inner, C) and b1.shape == (2 * inner,) and inner % 32 == 0 and C % 32 == 0
+    dev = w1.device
+    nsb, ks_n, nu = inner // 32, C // 16, C // 32
+    w1 = w1.to(torch.bfloat16)
+    w2 = w2.to(torch.bfloat16)
+    lane = torch.arange(64, device=dev)
+    r, hh = lane & 31, lane >> 5
+    j = torch.arange(8, device=dev)
+    sb = torch.arange(nsb, device=dev)
+    # ff1: rows (nsb, 2, 64), cols (ks, 64, 8)
+    rows1 = (torch.tensor([0, inner], device=dev)[None, :, None] + 32 * sb[:, None, None] + r[None, None, :])          # (nsb, 2, 64)
+    cols1 = 16 * torch.arange(ks_n, device=dev)[:, None, None] + 8 * hh[None, :, None] + j[None, None, :]             # (ks, 64, 8)
+    img1 = w1[rows1[:, None, :, :, None], cols1[None, :, None, :, :]]                                                 # (nsb, ks, 2, 64, 8)
+    # ff2: rows (nu, 64), cols (nsb, 2, 64, 8)
+    rows2 = 32 * torch.arange(nu, device=dev)[:, None] + r[None, :]                                                   # (nu, 64)
+    kperm = 8 * (j >> 2)[None, :] + 4 * hh[:, None] + (j & 3)[None, :]                                                # (64, 8)
+    cols2 = 32 * sb[:, None, None, None] + 16 * torch.arange(2, device=dev)[None, :, None, None] + kperm[None, None]  # (nsb, 2, 64, 8)
+    img2 = w2[rows2[None, :, None, :, None], cols2[:, None, :, :, :]]                                                 # (nsb, nu, 2, 64, 8)
+    bias = torch.stack([b1[:inner].reshape(nsb, 32), b1[inner:].reshape(nsb, 32)], 1).to(torch.float32)              # (nsb, 2, 32)
+    out = torch.zeros((nsb, FF_STAGE), device=dev, dtype=torch.uint8)
+    n1, n2 = ks_n * 2 * 1024, nu * 2 * 1024
+    assert n1 + n2 + 256 <= FF_STAGE
+    out[:, :n1] = img1.contiguous().view(torch.uint8).reshape(nsb, n1)
+    out[:, n1:n1 + n2] = img2.contiguous().view(torch.uint8).reshape(nsb, n2)
+    out[:, n1 + n2:n1 + n2 + 256] = bias.contiguous().view(torch.uint8).reshape(nsb, 256)
+    return out.reshape(-1)
