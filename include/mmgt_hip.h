@@ -46,6 +46,8 @@ int mmgt_tune(const char* key, int value);
 /* Debug only (tools/trace_gemm16.py): p = device buffer of u64 [grid][32 tiles][2 wave groups][4] that gemm16's workgroups fill
  * with 100-MHz stamps at their tile phases; NULL (the default) switches the stamps off. */
 void mmgt_gemm16_set_trace(void* p);
+/* Debug only (tools/trace_ffn.py): u64 [workgroups][64] shader-clock stamps of mmgt_ff_fused's phases (wave 0); NULL = off. */
+void mmgt_ffn_set_trace(void* p);
 
 /* out[M,N] = epi(A[M,K] . W[N,K]^T):  v = acc + bias[n] + bias2[m / bias2_rows][n]; v = act(v);
  * v *= row_scale[m] * alpha; v += residual[m][n].   Optional batch (grid.z) with element strides bs*.

@@ -22,6 +22,7 @@ _SIGS = {
     "mmgt_last_error": (ctypes.c_char_p, []),
     "mmgt_tune": (c_int, [ctypes.c_char_p, c_int]),
     "mmgt_gemm16_set_trace": (None, [c_void_p]),
+    "mmgt_ffn_set_trace": (None, [c_void_p]),
     "mmgt_gemm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_long,
                           c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_int,
                           c_void_p]),

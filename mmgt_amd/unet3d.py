@@ -13,13 +13,14 @@ Work the reference does and this implementation does not (results identical, SUR
     to_out(to_v(e)) added in the attn1 output epilogue (attention.py:455-462).
 """
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Union
 
 import torch
 
 from . import hip
-from .packing import pack_conv3x3, pack_geglu, pad_cols, pad_rows, round_up
+from .packing import pack_conv3x3, pack_ff_fused, pack_geglu, pad_cols, pad_rows, round_up
 from .unet3d_spec import unet3d_spec
 
 SD15_CONFIG = dict(  # SD-1.5 unet/config.json + unet_3d.py:649-662 + config/prompts/animation.yaml:47-75
@@ -101,6 +102,7 @@ class UNet3DConditionModel:
         hip.dtype_code(dtype)
         self.training = True                 # from_config leaves the module in train() mode
         self.gradient_checkpointing = False
+        self._fuse_ff = os.environ.get("MMGT_NO_FUSED_FF") != "1"     # A/B switch (tools/ab_*.sh): the three-launch FeedForward
         self.spec = unet3d_spec(boc, cfg["cross_attention_dim"], cfg["audio_attention_dim"], self.in_channels,
                                 self.out_channels, cfg["layers_per_block"],
                                 cfg["motion_module_kwargs"].get("temporal_position_encoding_max_len", 32))
@@ -238,6 +240,12 @@ class UNet3DConditionModel:
                 wp, bp = pack_geglu(sd[p + ".net.0.proj.weight"], sd[p + ".net.0.proj.bias"])
                 w[p + ".ff1.w"], w[p + ".ff1.bias"] = self._t(wp), self._f(bp)
             lin(p + ".net.2", p + ".ff2")
+            if has(p + ".net.0.proj.weight") and has(p + ".net.2.weight"):
+                c, inner = sd[p + ".net.2.weight"].shape
+                if self._fuse_ff and hip.ff_fused_supported(c, inner, self._dtype):
+                    # the 320-channel level: LayerNorm -> ff1 -> GEGLU -> ff2 -> + residual as one launch (csrc/ffn.hip)
+                    w[p + ".ffimg"] = pack_ff_fused(sd[p + ".net.0.proj.weight"].to(self._device), self._f(sd[p + ".net.0.proj.bias"]),
+                                                    sd[p + ".net.2.weight"].to(self._device))
 
         def self_attn(p):
             if has(p + ".to_q.weight"):
@@ -402,6 +410,15 @@ class UNet3DConditionModel:
         g = hip.gemm(x, self.w[p + ".ff1.w"], self.w[p + ".ff1.bias"], act=hip.ACT_GEGLU)
         return hip.gemm(g, self.w[p + ".ff2.w"], self.w[p + ".ff2.bias"], residual=residual)
 
+    def _norm_ff(self, p, norm, hid):
+        """hid + FeedForward(LayerNorm(hid)) (attention.py:361,465,642,769; motion_module.py:253-254): one fused launch where the
+        weight image exists (bf16, 320 channels), LayerNorm -> GEMM(GEGLU) -> GEMM(+ residual) otherwise."""
+        img = self.w.get(p + ".ffimg")
+        if img is not None:
+            return hip.ff_fused(hid, self.w[norm + ".g"], self.w[norm + ".b"], img, self.w[p + ".ff2.bias"], hid,
+                                self.w[p + ".ff2.w"].shape[1])
+        return self._ff(p, self._ln(norm, hid), hid)
+
     def _resnet(self, p, x, temb, skip=None):
         """ResnetBlock3D (resnet.py:217-247); `skip` = the UNet skip tensor that the reference concatenates first."""
         nb, h, ww, c0 = x.shape
@@ -481,7 +498,7 @@ class UNet3DConditionModel:
         else:
             hid = hip.gemm(o, self.w[t + ".attn1.o.w"], self.w[t + ".attn1.o.bias"], residual=hid)
             hid = self._cross_attention(t, hid, ehs if cfg_row is None else ehs[cfg_row:cfg_row + 1], nb, n, inner)
-        hid = self._ff(t + ".ff", self._ln(t + ".norm3", hid), hid)
+        hid = self._norm_ff(t + ".ff", t + ".norm3", hid)
         out = hip.gemm(hid, self.w[p + ".proj_out.w"], self.w[p + ".proj_out.bias"], residual=x.view(m, c))
         return out.view(nb, h, ww, c)
 
@@ -546,7 +563,7 @@ class UNet3DConditionModel:
                 self._zbias[key] = (self.w[f"{t}.z{i}.bias"] * s).contiguous()
             hid = hip.gemm_post(a3[:, i * inner:(i + 1) * inner], self.w[f"{t}.oz{i}.w"], self.w[f"{t}.oz{i}.bias"], mask, s,
                                 self._zbias[key], hid)
-        hid = self._ff(t + ".ff", self._ln(t + ".norm3", hid), hid)
+        hid = self._norm_ff(t + ".ff", t + ".norm3", hid)
         out = hip.gemm(hid, self.w[p + ".proj_out.w"], self.w[p + ".proj_out.bias"], residual=x.view(m, c))
         return out.view(nb, h, ww, c)
 
@@ -573,7 +590,7 @@ class UNet3DConditionModel:
             hip.attention(qkv, qkv[:, c:], qkv[:, 2 * c:], o, batch=b * n, heads=self.heads, hd=hd, nq=frames, nk=frames,
                           scale=hd ** -0.5, q_str=st, k_str=st, v_str=st, o_str=(frames * n * c, c, n * c), bdiv=n)
             hid = hip.gemm(o, self.w[a + ".o.w"], self.w[a + ".o.bias"], residual=hid)
-        hid = self._ff(t + ".ff", self._ln(t + ".ff_norm", hid), hid)
+        hid = self._norm_ff(t + ".ff", t + ".ff_norm", hid)
         out = hip.gemm(hid, self.w[q + ".proj_out.w"], self.w[q + ".proj_out.bias"], residual=x.view(m, c))
         return out.view(nb, h, ww, c)
 
