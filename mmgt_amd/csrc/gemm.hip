@@ -852,7 +852,7 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return 0; }
   if (key && !strcmp(key, "attn64")) { mmgt_attn_set64(value); return 0; }
   if (key && !strcmp(key, "gn_rows")) { mmgt_gn_set_rows(value); return 0; }
-  if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 3) { mmgt_ffn_set_dbg(value); return 0; }
+  if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 4) { mmgt_ffn_set_dbg(value); return 0; }
   mmgt_set_error("tune: unknown key");
   return 1;
 }

@@ -46,7 +46,7 @@ def main():
         tf, t3 = t_ms(fused), t_ms(three)
         print(f"round {rnd}: fused {tf * 1e3:7.1f} us = {fl / tf / 1e9:6.0f} TFLOP/s | LN + ff1 + ff2 {t3 * 1e3:7.1f} us = {fl / t3 / 1e9:6.0f} TFLOP/s", flush=True)
     for dbg, what in ((1, "compute stream alone (no weight fetch)"), (2, "weight stream alone (no MFMA / GELU)"),
-                      (3, "no weight DMA instructions at all")):
+                      (3, "no GELU"), (4, "no ff2 MFMAs")):
         hip.lib().mmgt_tune(b"ffn_dbg", dbg)
         print(f"ffn_dbg {dbg}: {t_ms(fused) * 1e3:7.1f} us   {what}", flush=True)
     hip.lib().mmgt_tune(b"ffn_dbg", 0)

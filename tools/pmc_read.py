@@ -14,5 +14,5 @@ for db in sorted(glob.glob(f"gpurun_out/pmc_{tag}_*/p_results.db")):
          f"join {t('rocpd_kernel_dispatch')} k on e.event_id=k.event_id join {t('rocpd_info_kernel_symbol')} s on k.kernel_id=s.id "
          f"group by s.kernel_name, i.name")
     for name, ctr, val in con.execute(q):
-        if "gemm" in name:
+        if "gemm" in name or "ff_fused" in name:
             print(f"{tag:10s} {ctr:45s} {val / nl:14.4g}")

@@ -26,26 +26,31 @@ def main():
     for _ in range(3):
         hip.ff_fused(x, g, b, img, b2, x, INNER, out=out)
     nwg = M // 128
-    buf = torch.zeros((nwg, 64), device=dev, dtype=torch.int64)
+    buf = torch.zeros((nwg, 2, 32), device=dev, dtype=torch.int64)
     hip.lib().mmgt_ffn_set_trace(buf.data_ptr())
     hip.ff_fused(x, g, b, img, b2, x, INNER, out=out)
     torch.cuda.synchronize()
     hip.lib().mmgt_ffn_set_trace(None)
     t = buf.cpu()
-    n = int((t[0] != 0).sum())
-    d = (t[:, 1:n] - t[:, :n - 1]).float()
-    names = ["prologue (x load, LN)", "wait W1(0) + barrier .. iteration 0 start"]
-    for j in range(8):
-        names += [f"it{j} phase A (ff1 || GEGLU)", f"it{j} wait+barrier", f"it{j} phase B (ff2)", f"it{j} -> it{j + 1} wait+barrier"]
-    names[-1] = "iterations 8 .. 39"
-    names += ["epilogue"]
-    tot = (t[:, n - 1] - t[:, 0]).float()
-    print(f"{nwg} workgroups, {n} stamps; whole workgroup: median {tot.median().item():.0f} cycles (min {tot.min().item():.0f}, max {tot.max().item():.0f})")
-    for i in range(n - 1):
-        col = d[:, i]
-        print(f"  {names[i] if i < len(names) else i:45s} median {col.median().item():8.0f}  p10 {col.quantile(0.1).item():8.0f}  p90 {col.quantile(0.9).item():8.0f}")
-    first = t[:, 0].float()
-    print(f"start spread: {(first.max() - first.min()).item():.0f} cycles (s_memtime is per-XCD-consistent only)")
+    namesA = ["x load + tables + LayerNorm", "S(0)", "M(0) + ff1(0) + S(1)"]
+    for i in range(1, 6):
+        namesA += [f"it{i} GEGLU({i - 1})", f"it{i} M + ff1({i})", f"it{i} -> S({i + 1})"]
+    namesA[-1] = "iterations 6 .. nsb - 1"
+    namesA += ["last GEGLU + barriers"]
+    namesB = ["tables + first DMA issue", "S(0) .. iteration 2"]
+    for i in range(2, 8):
+        namesB += [f"it{i} ff2({i - 2})", f"it{i} wait W1 + M", f"it{i} DMA issue + wait W2", f"it{i} S({i + 1})"]
+    namesB[-1] = "iterations 8 .. nsb, last ff2"
+    namesB += ["epilogue"]
+    for role, names in ((0, namesA), (1, namesB)):
+        tr = t[:, role]
+        n = int((tr[0] != 0).sum())
+        d = (tr[:, 1:n] - tr[:, :n - 1]).float()
+        tot = (tr[:, n - 1] - tr[:, 0]).float()
+        print(f"role {'AB'[role]}: {n} stamps; whole wave: median {tot.median().item():.0f} ticks (min {tot.min().item():.0f}, max {tot.max().item():.0f})")
+        for i in range(n - 1):
+            col = d[:, i]
+            print(f"  {names[i] if i < len(names) else str(i):45s} median {col.median().item():8.0f}  p10 {col.quantile(0.1).item():8.0f}  p90 {col.quantile(0.9).item():8.0f}")
 
 
 if __name__ == "__main__":
