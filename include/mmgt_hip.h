@@ -41,7 +41,9 @@ const char* mmgt_last_error(void);
 /* Benchmark-only knobs (A/B measurements and tests; the defaults are the product):
  *   "gemm_cfg" = 0 (heuristic tile choice) or 1, 3, 6, 9, 12, 16, 17 (force a GEMM / conv tile configuration);
  *   "attn64"   = 1 (default) / 0: the 64-queries-per-wave spatial attention kernel at head_dim 40;
- *   "gn_rows"  = 0 (default: measured choice) or the GroupNorm rows per workgroup. */
+ *   "gn_rows"  = 0 (default: measured choice) or the GroupNorm rows per workgroup;
+ *   "splitk"   = 1 (default) / 0: split-K of long reductions on grids of at most half a tile per CU (the 8x8-level convs);
+ *   "ffn_dbg"  = 0 (default) .. 4: ablation builds of mmgt_ff_fused (timing only, results are garbage for v > 0). */
 int mmgt_tune(const char* key, int value);
 /* Debug only (tools/trace_gemm16.py): p = device buffer of u64 [grid][32 tiles][2 wave groups][4] that gemm16's workgroups fill
  * with 100-MHz stamps at their tile phases; NULL (the default) switches the stamps off. */
@@ -136,6 +138,15 @@ int mmgt_ff_fused_image_bytes(int C, int inner);
 int mmgt_ff_fused(const void* x, long ldx, const float* ln_gamma, const float* ln_beta, float eps, const void* wimg,
                   const float* bias2, const void* residual, long ldr, void* out, long ldo, int M, int C, int inner, int dtype,
                   void* stream);
+
+/* wav2vec2 feature extractor, element-wise pieces (csrc/wav2vec.hip; the convs / Linears / attention run on mmgt_gemm, mmgt_layernorm,
+ * mmgt_attention).  x, out: (rows, C) channels-last in `dtype`.
+ *   mmgt_channel_norm_gelu: out = gelu((x - mean_c) * rstd_c * gamma + beta), statistics per CHANNEL over the rows -- GroupNorm(C, C)
+ *     over time + GELU of the first conv layer (transformers Wav2Vec2GroupNormConvLayer; src/models/wav2vec.py:73).
+ *   mmgt_lerp_rows: rows_in -> rows_out frames, F.interpolate(mode="linear", align_corners=True) (src/models/wav2vec.py:196-209). */
+int mmgt_channel_norm_gelu(const void* x, const float* gamma, const float* beta, void* out, int rows, int C, float eps, int dtype,
+                           void* stream);
+int mmgt_lerp_rows(const void* x, void* out, int rows_in, int rows_out, int C, int dtype, void* stream);
 
 /* Elementwise x -> silu(x) (time embedding activation, resnet.py:226) over n elements. */
 int mmgt_silu(const void* x, void* out, long n, int dtype, void* stream);

@@ -736,18 +736,34 @@ int launch_cfg(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, i
   return 0;
 }
 
+int g_splitk = 1;     // mmgt_tune("splitk", 0 / 1): A/B switch of the split-K path
 int g_gemm_cfg = 0;   // 0 = heuristic; 1, 3, 6, 9, 12, 16 force a tile configuration (mmgt_tune("gemm_cfg", v), benchmarking only)
 
 }  // namespace
 // gemm16.hip: the bf16 256x256 8-phase core on 16x16x32 MFMAs (cfg 16)
 int mmgt_gemm16_launch(int mode, int bn, const void* ad, const void* W, long bsw, const void* ep, int M, int N, int K,
                        int batch, void* stream);
+int mmgt_gemm16_splitk(int mode, int bn, const void* ad, const void* W, const void* ep, int M, int N, int K, int S, void* stream);
 namespace {
 
 template <typename T, int MODE>
 int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
   const bool geglu = ep.act == 1;
   int cfg = g_gemm_cfg;
+  // Split-K (gemm16.hip): a long reduction on a grid of at most half a tile per CU -- the 8x8-level convs (3072 rows x 1280 columns,
+  // K = 11 520 / 23 040) and ff2 of that level (K = 5120).  S slices with >= 16 chunks of 64 each, S x tiles <= 256.
+  if ((cfg == 0 || cfg == 18) && g_splitk && std::is_same<T, bf16_t>::value && batch == 1 && ep.act == 0 && ep.fast && !ep.row_scale &&
+      ep.alpha == 1.f && !ep.bias_post && N % 8 == 0 && K >= 2560 && (N % 256 == 0 || N % 320 == 0) &&
+      (((uintptr_t)ep.bias | (uintptr_t)ep.bias2) & 15) == 0) {
+    const int bn = N % 256 == 0 ? 256 : 320;
+    const long tiles = (long)((M + 255) / 256) * (N / bn);
+    const int nch = K / 64;
+    int S = 0;
+    for (int c = 8; c >= 2; --c)
+      if (tiles * c <= 256 && nch % c == 0 && nch / c >= 16) { S = c; break; }
+    if (S >= 2 && tiles <= 128) return mmgt_gemm16_splitk(MODE, bn, &ad, W, &ep, M, N, K, S, s);
+  }
+  if (cfg == 18) cfg = 0;
   if (cfg == 0) {
     // Measured on MI355X with tools/ab_gemm.py / tools/bench_kernels.py (one process, one device; re-swept after the
     // LDS-DMA moved to buffer addressing, which made 128x128 the better small tile for every dense shape):
@@ -852,6 +868,7 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return 0; }
   if (key && !strcmp(key, "attn64")) { mmgt_attn_set64(value); return 0; }
   if (key && !strcmp(key, "gn_rows")) { mmgt_gn_set_rows(value); return 0; }
+  if (key && !strcmp(key, "splitk")) { g_splitk = value; return 0; }
   if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 4) { mmgt_ffn_set_dbg(value); return 0; }
   mmgt_set_error("tune: unknown key");
   return 1;

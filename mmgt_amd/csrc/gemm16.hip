@@ -82,9 +82,13 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
 
   // ---- LDS-DMA source addressing (as gemm.hip): wave `wid` fills the 8-row pieces g = wid * GA + i of each operand
   const int srow = lane / CPR, spos = lane % CPR;
-  const T* a0 = reinterpret_cast<const T*>(ad.src0) + (long)bz * ad.bs0;
-  const T* a1 = ad.src1 ? reinterpret_cast<const T*>(ad.src1) + (long)bz * ad.bs1 : nullptr;
-  const T* wbase = reinterpret_cast<const T*>(W) + (long)bz * bsw;
+  // split-K (ad.ksplit): slice bz of the reduction starts K * bz elements into every W row and, dense, into every A row; the conv
+  // gather starts at that (tap, channel) position instead (setupA)
+  const int ldw = ad.ksplit ? ad.ldw : K;
+  const long kstart = ad.ksplit ? (long)bz * K : 0;
+  const T* a0 = reinterpret_cast<const T*>(ad.src0) + (ad.ksplit ? (MODE == 0 ? kstart : 0) : (long)bz * ad.bs0);
+  const T* a1 = ad.src1 ? reinterpret_cast<const T*>(ad.src1) + (ad.ksplit ? 0 : (long)bz * ad.bs1) : nullptr;
+  const T* wbase = reinterpret_cast<const T*>(W) + (ad.ksplit ? kstart : (long)bz * bsw);
   // The pieces of a wave are 8 rows apart, which goes into the SCALAR offset of the DMA, so the per-lane state of a stream
   // is one offset per piece parity (the swizzled 16-byte chunk of piece i is c0 ^ 4 ((wid G + i) & 1): row = 8 (wid G + i) +
   // srow, so (row >> 1) & 7 = (4 (wid G + i) + (srow >> 1)) & 7 with srow >> 1 in 0..3) plus the number of valid rows from the lane's first row:
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
   unsigned am0 = 0;                    // conv: output row of piece 0 (piece i: + 8 i)
   int a_step = 0, w_step = 0;          // scalar byte distance between consecutive pieces (dense A rows / W rows, 8 apart)
   int p_tap = 0, p_c = 0, a_soff = 0;
-  bool a_second = false;
+  bool a_second = false, a_fresh = true;   // a_fresh: the first chunk of a tile computes its gather offsets wherever the slice starts
   // The A and the W stream run at different distances ahead of the MFMAs (see the schedule above), so each keeps its own
   // position: tile, chunk inside the tile, chunks issued so far.
   auto setupA = [&](int tm) {
@@ -110,28 +114,30 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
     } else {
       am0 = row;
     }
-    p_tap = 0;
-    p_c = 0;
+    p_tap = MODE == 1 ? (int)(kstart / (ad.C0 + ad.C1)) : 0;
+    p_c = MODE == 1 ? (int)(kstart - (long)p_tap * (ad.C0 + ad.C1)) : 0;
+    a_fresh = true;
   };
   auto setupW = [&](int tn) {
     const unsigned row = (unsigned)(tn * BN + wid * GB * RPD + srow);
-    w_step = RPD * K * ESZ;
+    w_step = RPD * ldw * ESZ;
     limW = N - (int)row;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) woff[q] = row * (unsigned)(K * ESZ) + (unsigned)((c0sw ^ (4 * ((q + wid * GB) & 1))) << 4);
+    for (int q = 0; q < 2; ++q) woff[q] = row * (unsigned)(ldw * ESZ) + (unsigned)((c0sw ^ (4 * ((q + wid * GB) & 1))) << 4);
   };
   auto prepA = [&](int ch) {   // source offsets of the A pieces of chunk `ch` of the A stream's tile (chunks come strictly in order)
     if (MODE == 0) {
       a_soff = ch * ROWB;
     } else {
       const int cin = ad.C0 + ad.C1;
-      if (p_c == 0 || p_c == ad.C0) {
+      if (p_c == 0 || p_c == ad.C0 || a_fresh) {
+        a_fresh = false;
         const int ky = p_tap / 3, kx = p_tap - ky * 3;
         const int vh = ad.up ? ad.IH * 2 : ad.IH, vw = ad.up ? ad.IW * 2 : ad.IW;
         const bool second = p_c >= ad.C0 && ad.C1 > 0;
         const unsigned cpb = (unsigned)(second ? ad.C1 : ad.C0) * ESZ;   // bytes per pixel of the source tensor (< 2 GiB in all: host check)
         a_second = second;
-        a_soff = 0;
+        a_soff = (p_c - (second ? ad.C0 : 0)) * ESZ;
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
           const unsigned m = am0 + RPD * i;
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
       for_n(integral_constant<int, GB>{}, [&](auto i) { issueW(giW & 1, ichW, i); });
       advanceW();
     }
-    w_relax = nchunks >= 2 && tm * BM + BM <= M && tn * BN + BN <= N;   // every lane of every wave stores: the count above is exact
+    w_relax = !ad.ksplit && nchunks >= 2 && tm * BM + BM <= M && tn * BN + BN <= N;   // every lane of every wave stores: the count above is exact
     // everything below derives its per-lane addressing from these opaque copies, so none of it is hoisted above the main loop
     // (where it would only lengthen live ranges: the loop runs at the register limit)
     int lme = lm, lqe = lq;
@@ -476,7 +482,18 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
     using std::true_type;
     using std::false_type;
     const bool post = ep.row_scale != nullptr || ep.alpha != 1.f || ep.bias_post != nullptr;
-    if (BN == 256 && ep.act == 1) {
+    if (ad.ksplit) {
+      // split-K: the raw fp32 accumulators go to slab bz of the partial buffer (lane (lm, lq): row 16 i + lm, columns 16 j + 4 lq .. + 3
+      // = one 16-byte store); mmgt_splitk_reduce sums the slabs in slice order and applies the epilogue
+      float* pb = reinterpret_cast<float*>(ep.out) + (long)bz * ep.bso + col0 + 4 * lqe;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = row0 + 16 * i + lme;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          if (m < M && col0 + 16 * j + 4 * lqe < N) *reinterpret_cast<acc4*>(pb + (long)m * ep.ldo + 16 * j) = acc[i][j];
+      }
+    } else if (BN == 256 && ep.act == 1) {
       if constexpr (BN == 256) {
         if (ep.residual) epilogue(true_type{}, true_type{}, false_type{}); else epilogue(true_type{}, false_type{}, false_type{});
       }
@@ -530,6 +547,83 @@ int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int
 
 // Debug (tools/trace_gemm16.py): a device buffer of [grid][32 tiles][2 groups][4 stamps] u64 receives 100-MHz time stamps.
 extern "C" void mmgt_gemm16_set_trace(void* p) { g_trace = reinterpret_cast<unsigned long long*>(p); }
+
+namespace {
+
+// ---- split-K for grids that cannot fill the chip (the 8x8-level convs: 3072 output rows = 60 tiles of 256 x 256 for 256 CUs, with
+// reductions of 11 520 .. 23 040): S slices of the reduction run as S x tiles workgroups writing fp32 partial slabs, and this
+// kernel sums the slabs in slice order (bitwise reproducible) and applies bias / per-batch bias / residual.  8 columns per thread.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, long slab, const float* __restrict__ bias,
+                                                            const float* __restrict__ bias2, int b2rows, const bf16_t* __restrict__ res,
+                                                            long ldr, bf16_t* __restrict__ out, long ldo, int M, int N) {
+  const int nv = N / 8;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)M * nv) return;
+  const int m = (int)(idx / nv), c = (int)(idx - (long)m * nv) * 8;
+  const float* p = part + (long)m * N + c;
+  f32x4 a0 = *reinterpret_cast<const f32x4*>(p), a1 = *reinterpret_cast<const f32x4*>(p + 4);
+  for (int z = 1; z < S; ++z) {
+    a0 += *reinterpret_cast<const f32x4*>(p + z * slab);
+    a1 += *reinterpret_cast<const f32x4*>(p + z * slab + 4);
+  }
+  if (bias) { a0 += *reinterpret_cast<const f32x4*>(bias + c); a1 += *reinterpret_cast<const f32x4*>(bias + c + 4); }
+  if (bias2) {
+    const float* b2 = bias2 + (long)(m / b2rows) * N + c;
+    a0 += *reinterpret_cast<const f32x4*>(b2);
+    a1 += *reinterpret_cast<const f32x4*>(b2 + 4);
+  }
+  if (res) {
+    union { u32x4 u; bf16_t e[8]; } r8;
+    r8.u = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { a0[e] += bf16_to_f32(r8.e[e]); a1[e] += bf16_to_f32(r8.e[4 + e]); }
+  }
+  *reinterpret_cast<u32x4*>(out + (long)m * ldo + c) =
+      (u32x4){pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
+}
+
+float* g_splitk_ws = nullptr;
+size_t g_splitk_bytes = 0;
+
+}  // namespace
+
+// Split-K entry for gemm.hip's dispatcher: bf16, one problem (batch 1), no activation / row scale / post-scale bias, N % 8 == 0,
+// (K / 64) % S == 0.  Returns 0 on success; the partial slabs live in a library-owned device buffer that grows on demand (work on
+// one stream at a time: the buffer is reused by the next call).
+int mmgt_gemm16_splitk(int mode, int bn, const void* adp, const void* W, const void* epp, int M, int N, int K, int S, void* stream) {
+  ADesc ad = *reinterpret_cast<const ADesc*>(adp);
+  const Epi& ep = *reinterpret_cast<const Epi*>(epp);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t need = (size_t)S * M * N * sizeof(float);
+  if (need > g_splitk_bytes) {
+    if (g_splitk_ws) (void)hipFree(g_splitk_ws);       // (synchronises the device: nothing is reading the old buffer afterwards)
+    g_splitk_ws = nullptr;
+    g_splitk_bytes = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&g_splitk_ws), need) != hipSuccess) {
+      mmgt_set_error("gemm16 split-K: cannot allocate %zu bytes of partial sums", need);
+      return 2;
+    }
+    g_splitk_bytes = need;
+  }
+  ad.ksplit = 1;
+  ad.ldw = K;
+  Epi pe{};
+  pe.out = reinterpret_cast<char*>(g_splitk_ws);
+  pe.ldo = N;
+  pe.bso = (long)M * N;
+  pe.alpha = 1.f;
+  pe.fast = 1;
+  const int ks = K / S;
+  int rc;
+  if (bn == 320) rc = mode == 0 ? launch16<0, 320>(ad, W, 0, pe, M, N, ks, S, s) : launch16<1, 320>(ad, W, 0, pe, M, N, ks, S, s);
+  else rc = mode == 0 ? launch16<0, 256>(ad, W, 0, pe, M, N, ks, S, s) : launch16<1, 256>(ad, W, 0, pe, M, N, ks, S, s);
+  if (rc) return rc;
+  const long nthr = (long)M * (N / 8);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, g_splitk_ws, S, (long)M * N, ep.bias, ep.bias2,
+                     ep.bias2 ? ep.bias2_rows : 1, reinterpret_cast<const bf16_t*>(ep.residual), ep.ldr, reinterpret_cast<bf16_t*>(ep.out), ep.ldo, M, N);
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
 
 // Entry for gemm.hip's dispatcher.  Preconditions (checked there): bf16, vectorised epilogue (ep.fast), act in {none, GEGLU}
 // (GEGLU with bn = 256 only and without row scale / alpha / post-scale bias), 16-byte aligned bias vectors, K % 64 == 0.

@@ -15,6 +15,8 @@ struct ADesc {
   int stride, up;     // conv: stride; up = 1 -> the conv sees the nearest-2x upsampled input
   int pad;            // conv: zero rows / columns in front (1; 0 for the VAE encoder's (0, 1) padded downsample)
   unsigned fd_hw[3], fd_ow[3];   // conv: division of an output row index by OH * OW and by OW as multiply-high + shifts (fastdiv)
+  int ksplit;         // gemm16 split-K: grid.z walks slices of the reduction (K = slice length, ldw = the full reduction length = row
+  int ldw;            // stride of W in elements) and the epilogue writes fp32 partial slabs [z][M][N] to ep.out; 0: grid.z = batch
 };
 
 // Unsigned division by a launch-time constant as multiply-high and two shifts (Granlund & Montgomery), exact for every 32-bit

@@ -47,6 +47,8 @@ _SIGS = {
     "mmgt_ff_fused_image_bytes": (c_int, [c_int, c_int]),
     "mmgt_ff_fused": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long,
                               c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_channel_norm_gelu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
+    "mmgt_lerp_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_silu": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
     "mmgt_cfg_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_float,
                                    c_float, c_float, c_float, c_void_p]),
@@ -276,6 +278,25 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, pe_div=1, pe_mod=1, out=None):
     _check(lib().mmgt_layernorm(_ptr(x), x.stride(0), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), eps,
                                 _ptr(_f32(pe, "pe")), pe_div, pe_mod, _ptr(out), out.stride(0), rows, C,
                                 dtype_code(x.dtype), _stream()), "mmgt_layernorm")
+    return out
+
+
+def channel_norm_gelu(x, gamma, beta, eps=1e-5):
+    """(rows, C): per-channel normalisation over the rows + affine + GELU (wav2vec2's first conv layer)."""
+    _dev(x, gamma, beta)
+    assert x.dim() == 2 and x.is_contiguous()
+    out = torch.empty_like(x)
+    _check(lib().mmgt_channel_norm_gelu(_ptr(x), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), _ptr(out), x.shape[0], x.shape[1], eps,
+                                        dtype_code(x.dtype), _stream()), "mmgt_channel_norm_gelu")
+    return out
+
+
+def lerp_rows(x, rows_out):
+    """(rows_in, C) -> (rows_out, C): linear interpolation along the rows, align_corners=True."""
+    _dev(x)
+    assert x.dim() == 2 and x.is_contiguous()
+    out = torch.empty((rows_out, x.shape[1]), device=x.device, dtype=x.dtype)
+    _check(lib().mmgt_lerp_rows(_ptr(x), _ptr(out), x.shape[0], rows_out, x.shape[1], dtype_code(x.dtype), _stream()), "mmgt_lerp_rows")
     return out
 
 

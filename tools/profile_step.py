@@ -50,6 +50,10 @@ def key_of(name, args, kw):
     if name == "layernorm":
         x = args[0]
         return f"layernorm rows={x.shape[0]} c={x.shape[1]} pe={int(kw.get('pe') is not None)}", 0
+    if name == "ff_fused":
+        x = args[0]
+        inner = args[6] if len(args) > 6 else kw["inner"]
+        return f"ff_fused M={x.shape[0]} C={x.shape[1]} inner={inner} (LN + ff1 + GEGLU + ff2 + res)", 2 * x.shape[0] * 3 * inner * x.shape[1]
     t = next((a for a in args if torch.is_tensor(a)), None)
     return f"{name} {tuple(t.shape) if t is not None else ''}", 0
 
@@ -69,7 +73,7 @@ def wrap(name):
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-    for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
+    for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "ff_fused", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
               "ncfhw_to_nhwc", "nhwc_to_ncfhw", "timestep_features", "silu", "cfg_ddim_step", "accumulate_window"]:
         wrap(n)
     sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
