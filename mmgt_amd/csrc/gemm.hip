@@ -880,13 +880,14 @@ static int gemm_entry(const void* A, long lda, const void* W, const float* bias,
                       void* stream) {
   if (check_common(dtype, M, N, K, act)) return 1;
   MMGT_CHECK(A && W && out, "gemm: null pointer");
-  MMGT_CHECK(lda >= K && batch >= 1, "gemm: lda %ld < K %d or batch %d < 1", lda, K, batch);
+  // (lda < K is allowed: A is only read, and overlapping rows are how a 1-D convolution's patches are laid out in a channels-last signal)
+  MMGT_CHECK(lda >= 1 && batch >= 1, "gemm: lda %ld < 1 or batch %d < 1", lda, batch);
   MMGT_CHECK(!bias2 || bias2_rows > 0, "gemm: bias2_rows must be positive");
   const int esz = dtype == MMGT_BF16 ? 2 : 4;
   MMGT_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && (lda * esz) % 16 == 0 && (bsA * esz) % 16 == 0 &&
                  (bsW * esz) % 16 == 0,
              "gemm: A/W must be 16-byte aligned with 16-byte aligned rows");
-  MMGT_CHECK((long)M * lda * esz < (1l << 31) && (long)N * K * esz < (1l << 31),
+  MMGT_CHECK(((long)(M - 1) * lda + K) * esz < (1l << 31) && (long)N * K * esz < (1l << 31),
              "gemm: an operand (per batch entry) exceeds the 2 GiB range of the 32-bit LDS-DMA offsets");
   ADesc ad{};
   ad.src0 = (const char*)A;

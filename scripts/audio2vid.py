@@ -11,12 +11,13 @@ The chain is the reference's (line numbers of its scripts/audio2vid.py):
   2. seam smoothing by cubic splines around every 60th frame (:351-374)   -> host numpy / scipy, as in the reference
   3. key points -> pose / face / lips frames (:386, cv2 drawing of src/dwpose, out of scope) -> a SYNTHETIC disc renderer on the
      device (mmgt_splat_keypoints) stands in, so the masks below are produced from SMGA's own output
-  4. mask blur + 4-level pyramid (:453-476), audio window stack + AudioProjModel (:426,439-441) -> device kernels
+  4. wav2vec2 features of the waveform (:420-426, src/dataset/audio_processor.py:76-131) -> mmgt_amd.wav2vec.Wav2VecModel (HIP);
+     mask blur + 4-level pyramid (:453-476), audio window stack + AudioProjModel (:426,439-441) -> device kernels
   5. Pose2VideoPipeline (:484-498), frames converted to uint8 on the device, written as .npy / .gif.
 
---synthetic: random-init weights of the reference architectures (no checkpoints ship with the reference) and synthetic audio
-features in place of WavLM / wav2vec2 / librosa extraction (host-side feature extractors, out of scope).  Without --synthetic the
-script stops with a clear message: it would need those extractors, cv2 and PyAV.
+--synthetic: random-init weights of the reference architectures (no checkpoints ship with the reference), a synthetic 16-kHz
+waveform for the wav2vec2 leg, and synthetic WavLM + baseline features for SMGA (WavLM / librosa extraction and vocal separation are
+host-side and out of scope).  Without --synthetic the script stops with a clear message: it would need those extractors, cv2 and PyAV.
 """
 import argparse
 import json
@@ -91,7 +92,7 @@ def smooth_seams(tps_origin):
 def main():
     a = parse_args()
     if not a.synthetic:
-        raise SystemExit("non-synthetic runs need WavLM / wav2vec2 / librosa feature extraction, DWPose (onnxruntime, cv2) and PyAV, "
+        raise SystemExit("non-synthetic runs need WavLM / librosa feature extraction, audio decoding, DWPose (onnxruntime, cv2) and PyAV, "
                          "which this build does not include; see INTEGRATION.md for wiring mmgt_amd into the reference's own script")
     if not torch.cuda.is_available():
         raise SystemExit("audio2vid needs an MI355X (the product has no CPU path)")
@@ -150,7 +151,13 @@ def main():
     face = C.mask_pyramid_device(C.blur_mask_device(face_u8, 31), a.H)
     lips = C.mask_pyramid_device(C.blur_mask_device(lips_u8, 21), a.H)
     full = C.full_mask_from_lips(lips)
-    feats = hash_uniform("a2v.wav2vec", (a.L, 12, 768), 1.0).to(dev)                                        # (frames, 12 layers, 768)
+    # wav2vec2 features of the (synthetic) 16-kHz waveform: AudioProcessor.preprocess (src/dataset/audio_processor.py:103-126) on the device
+    from mmgt_amd.wav2vec import Wav2VecModel, wav2vec_spec
+    w2v = Wav2VecModel(device=dev, dtype=dtype)
+    w2v.load_state_dict(synth_state_dict(wav2vec_spec(), prefix="w2v.", device=dev))
+    wave = hash_uniform("a2v.wave", (1, a.L * 16000 // (a.fps or 25)), 1.0)
+    wave = ((wave - wave.mean()) / (wave.var(unbiased=False) + 1e-7).sqrt()).to(dev)                        # Wav2Vec2FeatureExtractor's normalisation
+    feats = w2v.audio_emb(wave, a.L)                                                                        # (frames, 12 layers, 768)
     audio_tensor = audioproj(C.process_audio_emb_device(feats)[None])                                       # (1, L, 32, 768)
     pose = (pose_u8.permute(3, 0, 1, 2)[None].float() / 255.0).contiguous()                                 # ToTensor: (1, 3, L, H, W)
     torch.cuda.synchronize()
