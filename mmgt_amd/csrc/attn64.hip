@@ -19,6 +19,20 @@ constexpr int NVK = HD / 8, NVV = KT / 8;                       // 16-byte vecto
 constexpr int KVEC = (KT * NVK + NT - 1) / NT, VVEC = (HD * NVV + NT - 1) / NT;
 constexpr float RESCALE_LAG = 8.f;                              // see attention.hip
 
+// A wave that presents an MFMA to a busy matrix pipe blocks the SIMD's vector issue port, its partner's VALU included (tools/micro/
+// coexec.hip); ATTN_PACE pads behind MFMAs with s_nop so that the partner's softmax can issue meanwhile (A/B: tools/ab_attn_pace.sh).
+#ifndef ATTN_PACE
+#define ATTN_PACE 0
+#endif
+__device__ __forceinline__ void pace_qk() {
+  if (ATTN_PACE == 1 || ATTN_PACE == 2) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7\n\ts_nop 1"); __builtin_amdgcn_sched_barrier(0); }
+  if (ATTN_PACE == 3 || ATTN_PACE == 4) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7"); __builtin_amdgcn_sched_barrier(0); }
+}
+__device__ __forceinline__ void pace_pv() {
+  if (ATTN_PACE == 2) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7\n\ts_nop 1"); __builtin_amdgcn_sched_barrier(0); }
+  if (ATTN_PACE == 4) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7"); __builtin_amdgcn_sched_barrier(0); }
+}
+
 __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
   typedef bf16_t T;
   // (Double-buffered tiles -- tile t + 1 written at the end of tile t's work, one barrier per tile -- measured 1 % slower;
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
-          for (int qb = 0; qb < QB; ++qb) mma32(s[qb][sub], kf[sub][ks], qf[qb][ks]);
+          for (int qb = 0; qb < QB; ++qb) { mma32(s[qb][sub], kf[sub][ks], qf[qb][ks]); pace_qk(); }
     }
     // ---- tile maxima of both query blocks, one (rare) rescale branch for the wave ----
     float mt[QB];
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
           union { u32x4 u; Frag<T> f; } cv;    // the lane's 8 keys are 16 contiguous bytes of the permuted row
           cv.u = *reinterpret_cast<const u32x4*>(lV + (dt * 32 + lr) * RSV + (sub * 2 + s2) * 32 + lh * 16);
 #pragma unroll
-          for (int qb = 0; qb < QB; ++qb) mma32(o[qb][dt], cv.f, pf[qb]);
+          for (int qb = 0; qb < QB; ++qb) { mma32(o[qb][dt], cv.f, pf[qb]); pace_pv(); }
         }
       }
   }

@@ -92,6 +92,18 @@ __device__ __forceinline__ s16x8 pack8(const float (&v)[8]) {
   return cv.s;
 }
 
+#ifndef MMGT_FFN_PACE
+#define MMGT_FFN_PACE 0
+#endif
+__device__ __forceinline__ void mfma_pace() {     // ~24 cycles in which this wave asks nothing of the vector issue port
+  __builtin_amdgcn_sched_barrier(0);
+  if (MMGT_FFN_PACE == 1) asm volatile("s_nop 7");
+  if (MMGT_FFN_PACE == 2) asm volatile("s_nop 7\n\ts_nop 1");
+  if (MMGT_FFN_PACE == 3) asm volatile("s_nop 7\n\ts_nop 7");
+  if (MMGT_FFN_PACE == 4) asm volatile("s_sleep 1");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 __device__ __forceinline__ void lds_barrier() {   // this wave's LDS traffic has completed, then the workgroup barrier (LDS-DMA is NOT
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // drained here: the loader waves wait vmcnt themselves)
   __builtin_amdgcn_s_barrier();
@@ -283,11 +295,14 @@ void ff_fused_kernel(const bf16_t* __restrict__ x, long ldx, const float* __rest
         if (st + 2 < FF_NU / 2) rd(st + 2, fb[(st + 2) % 3]);
         __builtin_amdgcn_sched_barrier(0);
         if (DBG != 2 && DBG != 4) {
+          // A wave that presents an MFMA to a busy matrix pipe blocks the SIMD's vector issue -- its partner's VALU included (tools/micro/
+          // coexec.hip: a VALU-only wave beside an MFMA-only wave takes the SUM of their times; with ~24 cycles of s_nop behind each MFMA the
+          // VALU wave disappears under the MFMA wave).  These 20 MFMAs run beside the partner's GELU block: pace them at the pipe's rate.
           const int u = 2 * st;
-          oacc[u] = mma32b(fb[st % 3][0], gb[0], oacc[u]);
-          oacc[u + 1] = mma32b(fb[st % 3][2], gb[0], oacc[u + 1]);
-          oacc[u] = mma32b(fb[st % 3][1], gb[1], oacc[u]);
-          oacc[u + 1] = mma32b(fb[st % 3][3], gb[1], oacc[u + 1]);
+          oacc[u] = mma32b(fb[st % 3][0], gb[0], oacc[u]); mfma_pace();
+          oacc[u + 1] = mma32b(fb[st % 3][2], gb[0], oacc[u + 1]); mfma_pace();
+          oacc[u] = mma32b(fb[st % 3][1], gb[1], oacc[u]); mfma_pace();
+          oacc[u + 1] = mma32b(fb[st % 3][3], gb[1], oacc[u + 1]); mfma_pace();
         }
         __builtin_amdgcn_sched_barrier(0);
       }

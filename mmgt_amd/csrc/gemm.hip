@@ -759,8 +759,10 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     const long tiles = (long)((M + 255) / 256) * (N / bn);
     const int nch = K / 64;
     int S = 0;
+    // (measured, tools/ab_cfg.py SET=ctx12 / step: at <= 64 tiles slices of >= 16 chunks pay -- 8x8 convs 126 -> 71 us, 248 -> 101 us, ff2
+    // 59 -> 47 us at 12 frames --; between 65 and 128 tiles only long slices do: the 16x16 convs of a 12-frame window -5 %, their ff2 +10 %)
     for (int c = 8; c >= 2; --c)
-      if (tiles * c <= 256 && nch % c == 0 && nch / c >= 16) { S = c; break; }
+      if (tiles * c <= 256 && nch % c == 0 && nch / c >= (tiles <= 64 ? 16 : 64)) { S = c; break; }
     if (S >= 2 && tiles <= 128) return mmgt_gemm16_splitk(MODE, bn, &ad, W, &ep, M, N, K, S, s);
   }
   if (cfg == 18) cfg = 0;
@@ -793,7 +795,7 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     // residual or N = 1280 shapes of the 32x32 level (-5..-8%).
     const bool b16 = std::is_same<T, bf16_t>::value;
     if (MODE == 1) {
-      if (b16 && N % 320 == 0 && M >= 49152) cfg = 17;
+      if (b16 && N % 320 == 0 && (M >= 49152 || (M >= 24576 && N >= 640))) cfg = 17;   // (12-frame windows: the 32x32-level convs, -7..-9 % against 128x128)
       else if (b16 && N % 256 == 0 && tiles256sq >= 192) cfg = 16;
       else cfg = (N % 320 == 0 && M >= 49152) ? 12 : big_ok ? 9 : tiles128 < 512 ? 3 : 1;
     } else if (b16 && !geglu && N % 320 == 0 && N <= 960 && M >= 131072) cfg = 17;

@@ -85,6 +85,10 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = L
+        for kv in filter(None, os.environ.get("MMGT_TUNE", "").split(",")):     # A/B switches for the tools: MMGT_TUNE="splitk=0,attn64=0"
+            k, v = kv.split("=")
+            if L.mmgt_tune(k.strip().encode(), int(v)) != 0:
+                raise RuntimeError(f"MMGT_TUNE: {L.mmgt_last_error().decode()}")
     return _lib
 
 

@@ -17,7 +17,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CACHE_DIR = os.path.join(ROOT, "tests", "golden", "oracle_cache")
-_SOURCES = sorted(glob.glob(os.path.join(ROOT, "oracle", "*.py"))) + [
+# the oracle modules the cached entries are computed with (an oracle module that is no input of any entry -- wav2vec_ref.py -- is not
+# listed: adding it must not invalidate them; one that becomes an input has to be added here)
+_ORACLE = ("__init__", "clip_ref", "conditioning_ref", "context_ref", "ddim_ref", "pipeline_ref", "smga_ref", "unet3d_ref", "vae_ref")
+_SOURCES = [os.path.join(ROOT, "oracle", n + ".py") for n in _ORACLE] + [
     os.path.join(ROOT, "mmgt_amd", "synthetic.py"), os.path.join(ROOT, "mmgt_amd", "unet3d_spec.py"),
     os.path.join(ROOT, "mmgt_amd", "context.py"), os.path.join(ROOT, "tests", "golden_cases.py"),
     os.path.join(ROOT, "tests", "smga_cases.py")]

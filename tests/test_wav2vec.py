@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests import golden_cases as gc
+from tests import wav2vec_cases as gc
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 

@@ -74,6 +74,14 @@ SETS = {
         conv_case(48, 8, 1280, 1280), conv_case(48, 16, 640, 1280), conv_case(48, 32, 320, 640)],
     "geglu": lambda: [gemm_case(196608, 2560, 320, act=1), gemm_case(196608, 1280, 320), gemm_case(196608, 2560, 320),
                       gemm_case(196608, 2560, 640, act=1), gemm_case(196608, 2560, 1280, act=1), gemm_case(196608, 1280, 640)],
+    # the reference's shipped window: context_frames = 12 (pipeline_pose2vid_long.py:360-362) -> 24 images per CFG forward
+    "ctx12": lambda: [
+        gemm_case(98304, 320, 320, res=True), gemm_case(98304, 320, 320), gemm_case(98304, 960, 320, bias=False), gemm_case(98304, 640, 320, bias=False),
+        gemm_case(24576, 5120, 640, act=1), gemm_case(24576, 640, 2560, res=True), gemm_case(24576, 640, 640, res=True), gemm_case(24576, 1920, 640, bias=False),
+        gemm_case(6144, 10240, 1280, act=1), gemm_case(6144, 1280, 5120, res=True), gemm_case(6144, 1280, 1280, res=True), gemm_case(6144, 3840, 1280, bias=False),
+        gemm_case(1536, 1280, 1280, res=True), gemm_case(1536, 1280, 5120, res=True), gemm_case(1536, 10240, 1280, act=1),
+        conv_case(24, 64, 320, 320), conv_case(24, 64, 640, 320), conv_case(24, 32, 640, 640), conv_case(24, 32, 1920, 640),
+        conv_case(24, 16, 1280, 1280), conv_case(24, 16, 2560, 1280), conv_case(24, 8, 1280, 1280), conv_case(24, 8, 2560, 1280)],
     "big": lambda: [gemm_case(8192, 8192, 8192, bias=False), gemm_case(4096, 4096, 4096, bias=False)],
     "step": lambda: [
         gemm_case(196608, 2560, 320, act=1), gemm_case(49152, 5120, 640, act=1), gemm_case(12288, 10240, 1280, act=1),

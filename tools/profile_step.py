@@ -73,6 +73,9 @@ def wrap(name):
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    if len(sys.argv) > 2:                                       # window length (the reference ships context_frames = 12)
+        bench.FRAMES = int(sys.argv[2])
+        bench.build_inputs.__defaults__ = (bench.FRAMES,) + bench.build_inputs.__defaults__[1:]
     for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "ff_fused", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
               "ncfhw_to_nhwc", "nhwc_to_ncfhw", "timestep_features", "silu", "cfg_ddim_step", "accumulate_window"]:
         wrap(n)

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(1, "/root/reference")
 sys.dont_write_bytecode = True
-from tests import golden_cases as gc  # noqa: E402
+from tests import wav2vec_cases as gc  # noqa: E402
 
 import transformers  # noqa: E402
 from transformers import Wav2Vec2Config  # noqa: E402

@@ -23,6 +23,8 @@ def main():
     b2 = 0.1 * hash_uniform("ffn.b2", (C,), 1.0, dev)
     img = pack_ff_fused(w1, b1, w2)
     out = torch.empty_like(x)
+    if len(sys.argv) > 1:
+        hip.lib().mmgt_tune(b"ffn_dbg", int(sys.argv[1]))
     for _ in range(3):
         hip.ff_fused(x, g, b, img, b2, x, INNER, out=out)
     nwg = M // 128
