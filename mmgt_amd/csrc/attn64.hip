@@ -278,12 +278,16 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
 }  // namespace
 
 // attention.hip's dispatcher: bf16, head_dim 40, V transposed, nq % 256 == 0, nk % 64 == 0, nk2 % 64 == 0
+int g_attn64_lds_pad = 0;   // mmgt_tune("attn64_pad", bytes): extra dynamic LDS per workgroup (experiment: 96 KiB forces one workgroup per CU)
+void mmgt_attn64_set_pad(int v) { g_attn64_lds_pad = v; }
+
 int mmgt_attn64_launch(const void* params, int batch, int heads, void* stream) {
   AttnParams p = *reinterpret_cast<const AttnParams*>(params);
   p.heads = heads;
   p.npairs = batch * heads;
   p.nqb = p.nq / (32 * QB * NW);
-  hipLaunchKernelGGL(attn64_kernel, dim3((unsigned)((long)p.nqb * batch * heads)), dim3(NT), 0, (hipStream_t)stream, p);
+  if (g_attn64_lds_pad > 65536 - 16384) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, g_attn64_lds_pad);
+  hipLaunchKernelGGL(attn64_kernel, dim3((unsigned)((long)p.nqb * batch * heads)), dim3(NT), (size_t)g_attn64_lds_pad, (hipStream_t)stream, p);
   MMGT_LAUNCH_CHECK();
   return 0;
 }
