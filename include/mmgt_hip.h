@@ -43,7 +43,8 @@ const char* mmgt_last_error(void);
  *   "attn64"   = 1 (default) / 0: the 64-queries-per-wave spatial attention kernel at head_dim 40;
  *   "gn_rows"  = 0 (default: measured choice) or the GroupNorm rows per workgroup;
  *   "splitk"   = 1 (default) / 0: split-K of long reductions on grids of at most half a tile per CU (the 8x8-level convs);
- *   "ffn_dbg"  = 0 (default) .. 4: ablation builds of mmgt_ff_fused (timing only, results are garbage for v > 0). */
+ *   "ffn_dbg"  = 0 (default) .. 4: ablation builds of mmgt_ff_fused (timing only, results are garbage for v > 0).
+ *   "ffn_ver"  = 4 (default): single-role kernel of mmgt_ff_fused, 3: the producer / consumer kernel (A/B measurements). */
 int mmgt_tune(const char* key, int value);
 /* Debug only (tools/trace_gemm16.py): p = device buffer of u64 [grid][32 tiles][2 wave groups][4] that gemm16's workgroups fill
  * with 100-MHz stamps at their tile phases; NULL (the default) switches the stamps off. */

@@ -47,6 +47,7 @@
 namespace {
 
 constexpr int FFC = 320, FF_KS = FFC / 16, FF_NU = FFC / 32;
+constexpr int FF_P1 = 10, FF_P2 = 5;      // LDS-DMA pieces per wave and sub-block in the single-role kernel (4 waves): ff1 part, ff2 part
 // weight image per sub-block (61 KiB): [ff1 fragments 40 KiB][ff2 fragments 20 KiB][64 ff1 biases | pad: 1 KiB]
 constexpr int FF_W1 = FF_KS * 2 * 1024, FF_W2 = FF_NU * 2 * 1024, FF_B1 = FF_W1 + FF_W2, FF_IMG = 61 * 1024;
 // LDS: two ff1 slots | two ff2 slots | two G slots (4 row groups x 2 KiB) | gamma, beta, bias2 | the ff1 biases of ALL sub-blocks
@@ -376,12 +377,345 @@ void ff_fused_kernel(const bf16_t* __restrict__ x, long ldx, const float* __rest
   }
 }
 
-int g_ffn_dbg = 0;
+// ===================================================================================================================
+// Single-role variant (mmgt_tune("ffn_ver", 4)): one wave per SIMD (4 waves = 128 rows per workgroup, up to 512 registers) runs the whole
+// chain, and everything that has to overlap is interleaved in that one instruction stream at the granularity of ONE MFMA.
+//
+// What bounds it (in-kernel stamps, tools/trace_ffn.py): a lone wave issues ONE instruction per ~5.5 cycles -- of any kind: MFMA, VALU,
+// ds_read, s_waitcnt and s_nop all cost an issue slot.  A sub-block of 32 hidden channels needs 60 MFMAs = 1920 matrix-pipe cycles, so
+// the stream may carry at most ~5 instructions per MFMA; the first cut of this kernel carried 7.7 (460 per sub-block: 3450 ticks per
+// iteration, no better than the two-role kernel).  This version spends the budget as follows, per sub-block:
+//   60 MFMA | 60 fragment reads, ONE wait per four (the four fragments of the next MFMA group are requested right behind the wait for
+//   the current group) | 15 LDS-DMA pieces, contiguous per wave, so four pieces share one M0 / soffset setting (instruction offsets
+//   0 .. 3072) | GEGLU of 16 values in 160 VALU: the degree-5 polynomial and the final x Phi(x) as v_pk_fma_f32 on value PAIRS, the
+//   ff1 bias added here (v_pk_add_f32) instead of preloading 32 accumulator registers (the first MFMA of a tile takes C = 0) | 8 bias
+//   reads | 4 waits + 2 barriers.
+// Schedule:  iteration j:  phase A: 40 MFMAs of ff1(j+1), behind each ~2.7 VALU of the second part of GEGLU(j), DMA of W2(j+1);
+//                          phase B: 20 MFMAs of ff2(j), behind each ~2.7 VALU of the first part of GEGLU(j+1), DMA of W1(j+3).
+// The hand-over between the phases sits at the START of a phase's last MFMA group: wait for this wave's LDS reads and for the DMA of
+// the next phase's weights, barrier, request the next phase's first fragments -- they arrive behind the last four MFMAs, so neither
+// phase starts with an empty pipe.  That barrier also frees the slot the next phase's DMA overwrites (every wave has completed its
+// reads of it).
+struct GluChain { f32x2 x, z, a; };
+// GEGLU micro-steps of a value pair and their VALU instruction counts; a tile is 8 pairs = 160 instructions, dealt out evenly (by
+// count) over the 60 MFMA slots of ff2 (20) and ff1 (40)
+constexpr int FF_MS = 13, FF_MSW[FF_MS] = {2, 1, 2, 1, 1, 1, 1, 1, 2, 2, 1, 2, 3}, FF_PAIRW = 20, FF_TILEW = 8 * FF_PAIRW, FF_SLOTS = 60;
+constexpr int ff_ms_weight_before(int m) {
+  int w = (m / FF_MS) * FF_PAIRW;
+  for (int k = 0; k < m % FF_MS; ++k) w += FF_MSW[k];
+  return w;
+}
+constexpr int ff_ms_first(int slot) {     // first micro-step of MFMA slot `slot` (0 .. 60): the first one at or beyond the slot's share
+  const int target = slot * FF_TILEW / FF_SLOTS;
+  int m = 0;
+  while (m < 8 * FF_MS && ff_ms_weight_before(m) < target) ++m;
+  return m;
+}
+static_assert(ff_ms_first(0) == 0 && ff_ms_first(FF_SLOTS) == 8 * FF_MS, "micro-step schedule");
+
+template <int DBG, bool TRACE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void ff_fused1_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+                      float eps, const char* __restrict__ wimg, int nsb, const float* __restrict__ bias2,
+                      const bf16_t* __restrict__ res, long ldr, bf16_t* __restrict__ out, long ldo, int M, unsigned long long* trace) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const long row = (long)blockIdx.x * 128 + wid * 32 + r;
+  const long rowc = row < M ? row : M - 1;
+  int trace_n = 0;
+  auto stamp = [&]() {   // TRACE build (tools/trace_ffn.py): shader-clock stamps of wave 0 of every workgroup at its phase boundaries
+    if constexpr (TRACE) {
+      if (trace && wid == 0 && lane == 0 && trace_n < 32) trace[(long)blockIdx.x * 64 + trace_n++] = __builtin_amdgcn_s_memtime();
+    }
+  };
+  stamp();
+  const __amdgpu_buffer_rsrc_t rw = dma_rsrc(wimg);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  // This wave's share of W1(sb) is the 10 contiguous 1-KiB pieces 10 wid .. 10 wid + 9 of the ff1 part, of W2(sb) the 5 pieces 5 wid ..
+  // 5 wid + 4 of the ff2 part.  Sub-blocks beyond the image are "loaded" too, with the poison offset (the range check returns zeros,
+  // nothing is fetched): every iteration issues the same number of pieces and the counted waits are compile-time constants.
+  auto piece = [&](auto Ic, unsigned voff, int src, char* dst) {     // piece i of a run: group i / 4 (one M0 / soffset), instruction offset 1024 (i % 4)
+    constexpr int i = decltype(Ic)::value;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + (i / 4) * 4096), 16, (int)voff,
+                                             src + (i / 4) * 4096, (i % 4) * 1024, 0);
+  };
+  auto issue1 = [&](int sb, auto Ic) {
+    piece(Ic, (DBG != 1 && sb < nsb) ? lane16 : DMA_POISON, sb * FF_IMG + wid * (FF_P1 * 1024), smem + FF_L1 + (sb & 1) * FF_W1 + wid * (FF_P1 * 1024));
+  };
+  auto issue2 = [&](int sb, auto Ic) {
+    piece(Ic, (DBG != 1 && sb < nsb) ? lane16 : DMA_POISON, sb * FF_IMG + FF_W1 + wid * (FF_P2 * 1024), smem + FF_L2 + (sb & 1) * FF_W2 + wid * (FF_P2 * 1024));
+  };
+  using std::integral_constant;
+  constexpr integral_constant<bool, true> T{};
+  constexpr integral_constant<bool, false> F{};
+  auto for_range = [](auto LOc, auto HIc, auto&& fn) {            // fn(integral_constant<int, i>) for i in [lo, hi)
+    constexpr int lo = decltype(LOc)::value, hi = decltype(HIc)::value;
+    [&]<int... I>(std::integer_sequence<int, I...>) { (fn(integral_constant<int, lo + I>{}), ...); }(std::make_integer_sequence<int, (hi > lo ? hi - lo : 0)>{});
+  };
+#define FF_IC(v) integral_constant<int, (v)>{}
+
+  // ---- the wave's 32 rows as ff1 B fragments: lane (r, hh) holds channels 16 ks + 8 hh .. + 7 of row r
+  s16x8 xf[FF_KS];
+  {
+    const bf16_t* xr = x + rowc * ldx + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < FF_KS; ++ks) xf[ks] = *reinterpret_cast<const s16x8*>(xr + 16 * ks);
+    // gamma | beta | bias2 and the ff1 biases go through LDS: with an LDS-DMA in flight hipcc waits vmcnt(0) for every plain global
+    // load, so the weight DMA starts only behind these loads
+    float* lgb = reinterpret_cast<float*>(smem + FF_LG);
+    if (tid < 3 * FFC / 4 && (gamma || tid >= 2 * FFC / 4)) {   // 3 x 80 vectors
+      const float* src = tid < FFC / 4 ? gamma + 4 * tid : tid < 2 * FFC / 4 ? beta + 4 * (tid - FFC / 4) : bias2 + 4 * (tid - 2 * FFC / 4);
+      *reinterpret_cast<f32x4*>(lgb + 4 * tid) = *reinterpret_cast<const f32x4*>(src);
+    }
+    for (int v = tid; v < nsb * 16; v += 256)                    // 16 vectors of 4 biases per sub-block, from the image
+      *reinterpret_cast<f32x4*>(smem + FF_LB + v * 16) = *reinterpret_cast<const f32x4*>(wimg + (long)(v >> 4) * FF_IMG + FF_B1 + (v & 15) * 16);
+    __syncthreads();
+    for_range(FF_IC(0), FF_IC(FF_P1), [&](auto i) { issue1(0, i); });
+    for_range(FF_IC(0), FF_IC(FF_P1), [&](auto i) { issue1(1, i); });
+    if (gamma) {   // LayerNorm (exact two-pass statistics in registers, as ln_kernel): y = (x - mean) * rstd * gamma + beta
+      float sum = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < FF_KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += bf16_to_f32((bf16_t)xf[ks][j]);
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum / (float)FFC;
+      float sq = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < FF_KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = bf16_to_f32((bf16_t)xf[ks][j]) - mean; sq += d * d; }
+      sq += __shfl_xor(sq, 32);
+      const float rstd = rsqrtf(sq / (float)FFC + eps);
+#pragma unroll
+      for (int ks = 0; ks < FF_KS; ++ks) {
+        const int c = 16 * ks + 8 * hh;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(lgb + c), g1 = *reinterpret_cast<const f32x4*>(lgb + c + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(lgb + FFC + c), b1 = *reinterpret_cast<const f32x4*>(lgb + FFC + c + 4);
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          y[j] = (bf16_to_f32((bf16_t)xf[ks][j]) - mean) * rstd * g0[j] + b0[j];
+          y[4 + j] = (bf16_to_f32((bf16_t)xf[ks][4 + j]) - mean) * rstd * g1[j] + b1[j];
+        }
+        xf[ks] = pack8(y);
+      }
+    }
+  }
+  f32x16 oacc[FF_NU];
+#pragma unroll
+  for (int u = 0; u < FF_NU; ++u) oacc[u] = (f32x16)(0.f);
+  stamp();
+
+  // GEGLU micro-step m of the tile (hp, gp): step m % 13 of value pair m / 13 (accumulator registers 2 p, 2 p + 1 = two consecutive hidden
+  // channels); the last step packs the pair into word p & 3 of the ff2 B fragment p >> 2.  The accumulators live in AGPRs (the kernel
+  // needs > 256 registers): their reads are micro-steps of their own -- left to the compiler, all 32 v_accvgpr_read of a tile land in
+  // front of the phase's first MFMA.  bh / bg: the ff1 biases of the tile for this lane (register i <-> hidden 4 hh + (i & 3) + 8 (i >> 2)).
+  GluChain gc;
+  f32x4 bh[4], bg[4];
+  const float seven = 7.f;
+  auto acc_read = [](float a) { float v; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a)); return v; };
+  auto min_abs = [&](float v) { float z; asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(z) : "v"(v), "v"(seven)); return z; };
+  // <2 x float> arithmetic: hipcc emits v_pk_fma_f32 / v_pk_add_f32 only where no MFMA is in flight and scalar pairs behind an MFMA
+  // (its "unpack packed instructions overlapped by MFMAs" pass) -- rightly: forced to v_pk_* by inline asm, a packed instruction waits
+  // for the matrix pipe and the iteration went from 3450 to 4320 ticks.
+  auto pk_fma_vs = [](f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); };
+  auto pk_nfma = [](f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(-a, b, c); };
+  auto pk_add = [](f32x2 a, f32x2 b) { return a + b; };
+  auto pk_mul = [](f32x2 a, f32x2 b) { return a * b; };
+  const f32x2 g5v = (f32x2)(FF_G5);
+  auto glu_ms = [&](auto Mc, const f32x16& hp, const f32x16& gp, u32x4 (&gbx)[2]) {
+    constexpr int m = decltype(Mc)::value, p = m / FF_MS, k = m % FF_MS, e0 = 2 * p, e1 = 2 * p + 1;
+    if constexpr (k == 0) gc.x = (f32x2){acc_read(gp[e0]), acc_read(gp[e1])};
+    if constexpr (k == 1) gc.x = pk_add(gc.x, __builtin_shufflevector(bg[e0 >> 2], bg[e0 >> 2], e0 & 3, e1 & 3));
+    if constexpr (k == 2) gc.z = (f32x2){min_abs(gc.x[0]), min_abs(gc.x[1])};
+    if constexpr (k == 3) gc.a = pk_fma_vs(g5v, gc.z, (f32x2)(FF_G4));
+    if constexpr (k == 4) gc.a = pk_fma_vs(gc.a, gc.z, (f32x2)(FF_G3));
+    if constexpr (k == 5) gc.a = pk_fma_vs(gc.a, gc.z, (f32x2)(FF_G2));
+    if constexpr (k == 6) gc.a = pk_fma_vs(gc.a, gc.z, (f32x2)(FF_G1));
+    if constexpr (k == 7) gc.a = pk_fma_vs(gc.a, gc.z, (f32x2)(FF_G0));
+    if constexpr (k == 8) gc.a = (f32x2){__builtin_amdgcn_exp2f(gc.a[0]), __builtin_amdgcn_exp2f(gc.a[1])};     // Phi(-|x|)
+    if constexpr (k == 9) gc.x = (f32x2){relu1(gc.x[0]), relu1(gc.x[1])};
+    if constexpr (k == 10) gc.a = pk_nfma(gc.z, gc.a, gc.x);        // x Phi(x) = max(x, 0) - |x| Phi(-|x|)   (|x| clamped at 7: Phi(-7) = 1.3e-12)
+    if constexpr (k == 11) gc.z = (f32x2){acc_read(hp[e0]), acc_read(hp[e1])};
+    if constexpr (k == 12) {
+      const f32x2 o = pk_mul(pk_add(gc.z, __builtin_shufflevector(bh[e0 >> 2], bh[e0 >> 2], e0 & 3, e1 & 3)), gc.a);
+      gbx[p >> 2][p & 3] = pack_bf16x2(o[0], o[1]);
+    }
+  };
+  auto glu_slot = [&](auto Sc, const f32x16& hp, const f32x16& gp, u32x4 (&gbx)[2]) {      // the micro-steps that ride behind MFMA slot s (0 .. 59)
+    constexpr int s = decltype(Sc)::value;
+    for_range(FF_IC(ff_ms_first(s)), FF_IC(ff_ms_first(s + 1)), [&](auto mc) { glu_ms(mc, hp, gp, gbx); });
+  };
+  auto read_bias = [&](int sb) {
+    const float* bl = reinterpret_cast<const float*>(smem + FF_LB + sb * 256) + 4 * hh;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) { bh[g4] = *reinterpret_cast<const f32x4*>(bl + 8 * g4); bg[g4] = *reinterpret_cast<const f32x4*>(bl + 32 + 8 * g4); }
+  };
+  auto as_frag = [](const u32x4& v) { union { u32x4 u; s16x8 s; } cv; cv.u = v; return cv.s; };
+
+  s16x8 fa[2][4], fb[2][4];              // fragment rings of the two phases: [group parity][MFMA of the group]
+  auto read_a = [&](int sb, auto Gc) {   // ff1 fragments of MFMA group g (k-steps 2 g, 2 g + 1: h, gate, h, gate) of sub-block sb
+    constexpr int g = decltype(Gc)::value;
+    const char* s1 = smem + FF_L1 + (sb & 1) * FF_W1 + lane * 16 + g * 4096;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fa[g & 1][q] = *reinterpret_cast<const s16x8*>(s1 + q * 1024);
+  };
+  auto read_b = [&](int sb, auto STc) {  // ff2 fragments of step st: (tile 2 st, k 0) (2 st, k 1) (2 st + 1, k 0) (2 st + 1, k 1)
+    constexpr int st = decltype(STc)::value;
+    const char* s2 = smem + FF_L2 + (sb & 1) * FF_W2 + lane * 16 + st * 4096;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fb[st & 1][q] = *reinterpret_cast<const s16x8*>(s2 + q * 1024);
+  };
+  // ONE wait per MFMA group: all fragment reads but the N youngest (the next group's, requested just before) have returned.  (The
+  // builtin, not inline asm: the compiler's own wait insertion sees it and adds nothing per MFMA.)  gfx9 encoding: lgkmcnt in bits 11:8,
+  // vmcnt / expcnt fields left at their maxima.
+  auto group_wait = [](auto Nc) { __builtin_amdgcn_s_waitcnt(0xC07F | (decltype(Nc)::value << 8)); };
+  // hand-over at the start of a phase's last group: this wave's LDS reads are complete and its share of the next phase's weights has
+  // landed (`Younger` DMA pieces may stay in flight), then the workgroup barrier
+  auto hand_over = [&](auto Yc) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_vmcnt<decltype(Yc)::value>();
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // Phase A.  FF1: ff1 of sub-block sbn into (hn, gn) (the first MFMA of each takes C = 0; the bias is added by the GEGLU), one DMA piece
+  // per group (an LDS-DMA piece occupies the CU's one texture-address unit for >= 16 cycles and the four waves issue theirs at the same
+  // time: bursts stall the wave): the second half of W1(sbn + 1) on groups 0 .. 4, W2(sbn) on groups 5 .. 9; GLU: the micro-steps of slots 20 .. 59 of the GEGLU of (hp, gp) into gbx; NEXT: the hand-over
+  // to phase B of sub-block sbn - 1 in front of the last group (its first fragments are requested there).
+  auto phaseA = [&](int sbn, auto FF1c, auto GLUc, auto NEXTc, auto DMA1c, f32x16& hn, f32x16& gn, const f32x16& hp, const f32x16& gp, u32x4 (&gbx)[2]) {
+    constexpr bool FF1 = decltype(FF1c)::value, GLU = decltype(GLUc)::value && DBG != 2, NEXT = decltype(NEXTc)::value, DMA1 = decltype(DMA1c)::value;
+    for_range(FF_IC(0), FF_IC(FF_KS / 2), [&](auto gcn) {
+      constexpr int g = decltype(gcn)::value;
+      if constexpr (NEXT && g == FF_KS / 2 - 1) {
+        hand_over(FF_IC(FF_P1 + FF_P2 - 1));
+        read_b(sbn - 1, FF_IC(0));
+      }
+      if constexpr (FF1 && g + 1 < FF_KS / 2) read_a(sbn, FF_IC(g + 1));
+      if constexpr (FF1) group_wait(FF_IC((g + 1 < FF_KS / 2 ? 4 : 0) + (NEXT && g == FF_KS / 2 - 1 ? 4 : 0)));
+      if constexpr (FF1 && DMA1 && g < 5) issue1(sbn + 1, FF_IC(5 + g));      // one DMA piece per group: W1(sbn + 1) second half, then W2(sbn)
+      if constexpr (FF1 && g >= 5) issue2(sbn, FF_IC(g - 5));
+      for_range(FF_IC(0), FF_IC(4), [&](auto qc) {
+        constexpr int q = decltype(qc)::value, ks = 2 * g + (q >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FF1) {
+          if (DBG != 2) {
+            f32x16& acc = (q & 1) ? gn : hn;
+            acc = mma32b(fa[g & 1][q], xf[ks], ks == 0 ? (f32x16)(0.f) : acc);
+          }
+        }
+        if constexpr (GLU) glu_slot(FF_IC(20 + 4 * g + q), hp, gp, gbx);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  // Phase B.  MM: ff2 of sub-block sb from the B fragments gbc, channel tiles in the order (u, k0) (u+1, k0) (u, k1) (u+1, k1) -- the two
+  // k-steps of a tile accumulate into the same registers, back to back they would run at the MFMA's latency, not its issue rate; DMA:
+  // the first half of W1(sb + 3), five pieces on steps 0 .. 3; GLU: the micro-steps of slots 0 .. 19 of the GEGLU of (hp, gp) into gbx (its biases
+  // are read at the start); NEXT: the hand-over to phase A of sub-block sb + 2 in front of the last step.
+  auto phaseB = [&](int sb, auto MMc, auto DMAc, auto GLUc, auto NEXTc, const u32x4 (&gbc)[2], const f32x16& hp, const f32x16& gp, u32x4 (&gbx)[2]) {
+    constexpr bool MM = decltype(MMc)::value, DMA = decltype(DMAc)::value, GLU = decltype(GLUc)::value && DBG != 2, NEXT = decltype(NEXTc)::value;
+    s16x8 g0, g1;
+    if constexpr (MM) { g0 = as_frag(gbc[0]); g1 = as_frag(gbc[1]); }
+    if constexpr (GLU) read_bias(sb + 1);
+    for_range(FF_IC(0), FF_IC(FF_NU / 2), [&](auto stc) {
+      constexpr int st = decltype(stc)::value, u = 2 * st;
+      if constexpr (NEXT && st == FF_NU / 2 - 1) {
+        hand_over(FF_IC(2 * FF_P2));
+        read_a(sb + 2, FF_IC(0));
+      }
+      if constexpr (MM && st + 1 < FF_NU / 2) read_b(sb, FF_IC(st + 1));
+      if constexpr (MM) group_wait(FF_IC((st + 1 < FF_NU / 2 ? 4 : 0) + (NEXT && st == FF_NU / 2 - 1 ? 4 : 0)));
+      for_range(FF_IC(0), FF_IC(4), [&](auto qc) {
+        constexpr int q = decltype(qc)::value;      // MFMA q of the step: tile u + (q & 1), k-step q >> 1  (fragment 2 (q & 1) + (q >> 1))
+        if constexpr (DMA && st < 4 && (q == 0 || (st == 0 && q == 2))) issue1(sb + 3, FF_IC(st == 0 ? q / 2 : st + 1));     // W1(sb + 3) first half
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MM) {
+          if (DBG != 2) oacc[u + (q & 1)] = mma32b(fb[st & 1][2 * (q & 1) + (q >> 1)], (q >> 1) ? g1 : g0, oacc[u + (q & 1)]);
+        }
+        if constexpr (GLU) glu_slot(FF_IC(4 * st + q), hp, gp, gbx);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  f32x16 hA, gA, hB, gB;
+  u32x4 gbA[2] = {}, gbB[2] = {};
+  // iteration -1: ff1(0) alone (W2(0) goes out with it), then the first part of GEGLU(0) alone with W1(2) going out
+  wait_vmcnt<FF_P1>();                       // W1(0) has landed; W1(1) in flight
+  __builtin_amdgcn_s_barrier();
+  read_a(0, FF_IC(0));
+  phaseA(0, T, F, F, F, hA, gA, hA, gA, gbA);
+  __builtin_amdgcn_s_barrier();              // every wave is through ff1(0): its slot takes W1(2)
+  phaseB(-1, F, T, T, T, gbA, hA, gA, gbA);  // ... and in front of its last step: W1(1) has landed (younger: W2(0), half of W1(2)), first fragments of ff1(1)
+  // iteration j < nsb - 1:   A: ff1(j+1) || GEGLU(j) 2nd part || W1(j+2) 2nd half, W2(j+1) out; hand-over in front of the last group: W2(j)
+  //                             landed (younger: both halves of W1(j+2), 4 pieces of W2(j+1))
+  //                          B: ff2(j) || GEGLU(j+1) 1st part || W1(j+3) 1st half out; hand-over: W1(j+2) landed (younger: W2(j+1), half W1(j+3))
+  // last iteration:          GEGLU 2nd part, drain, ff2.
+  auto iteration = [&](int j, f32x16& hp, f32x16& gp, f32x16& hn, f32x16& gn, u32x4 (&gbp)[2], u32x4 (&gbn)[2]) {
+    if (j < 6) stamp();
+    phaseA(j + 1, T, T, T, T, hn, gn, hp, gp, gbp);
+    if (j < 6) stamp();
+    phaseB(j, T, T, T, T, gbp, hn, gn, gbn);
+  };
+  auto last_iteration = [&](int j, f32x16& hp, f32x16& gp, u32x4 (&gbp)[2]) {
+    hand_over(FF_IC(0));
+    read_b(j, FF_IC(0));
+    phaseA(j + 1, F, T, F, F, hp, gp, hp, gp, gbp);
+    phaseB(j, T, F, F, F, gbp, hp, gp, gbp);
+  };
+  int j = 0;
+  for (; j + 2 < nsb; j += 2) {
+    iteration(j, hA, gA, hB, gB, gbA, gbB);
+    iteration(j + 1, hB, gB, hA, gA, gbB, gbA);
+  }
+  if (nsb - j == 2) {
+    iteration(j, hA, gA, hB, gB, gbA, gbB);
+    last_iteration(j + 1, hB, gB, gbB);
+  } else {
+    last_iteration(j, hA, gA, gbA);
+  }
+  stamp();
+  // ---- epilogue (as the two-role kernel's): + b2 + residual, bf16, 16-byte stores through a buffer resource sized to the M valid rows
+  {
+    const bf16_t* rr = res + rowc * ldr + 8 * hh;
+    u32x4 rv[2 * FF_NU];
+#pragma unroll
+    for (int i = 0; i < 2 * FF_NU; ++i) rv[i] = *reinterpret_cast<const u32x4*>(rr + 16 * i);   // channels 16 i + 8 hh .. + 7
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((long)M * ldo * 2), 0x00020000);
+    const unsigned obase = (unsigned)(row * ldo + 8 * hh) * 2u;          // (rows >= M: beyond num_records -> dropped)
+    const float* lb2 = reinterpret_cast<const float*>(smem + FF_LG) + 2 * FFC + 8 * hh;
+#pragma unroll
+    for (int u = 0; u < FF_NU; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; k += 2) {
+        const int c = 32 * u + 8 * k;          // + 8 hh in the bases
+        union { u32x4 q; bf16_t e[8]; } r8;
+        r8.q = rv[2 * u + k / 2];
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(lb2 + c), b1 = *reinterpret_cast<const f32x4*>(lb2 + c + 4);
+        float o8[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(oacc[u][4 * k + e]), __float_as_uint(oacc[u][4 * k + 4 + e]), false, false);
+          o8[e] = __uint_as_float(sw[0]) + b0[e] + bf16_to_f32(r8.e[e]);
+          o8[4 + e] = __uint_as_float(sw[1]) + b1[e] + bf16_to_f32(r8.e[4 + e]);
+        }
+        const u32x4 pk = (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])};
+        __builtin_amdgcn_raw_buffer_store_b128(pk, ro, (int)(obase + 2u * c), 0, 0);
+      }
+  }
+  stamp();
+#undef FF_IC
+}
+
+int g_ffn_dbg = 0, g_ffn_ver = 4;      // 4: single-role kernel (483 us at the level-0 shape), 3: producer / consumer kernel (520 us)
 unsigned long long* g_ffn_trace = nullptr;
 
 }  // namespace
 
 void mmgt_ffn_set_dbg(int v) { g_ffn_dbg = v; }
+void mmgt_ffn_set_ver(int v) { g_ffn_ver = v; }
 // Debug (tools/trace_ffn.py): device buffer of u64 [workgroups][2 roles][32] for the shader-clock stamps of waves 0 and 4; NULL = off.
 extern "C" void mmgt_ffn_set_trace(void* p) { g_ffn_trace = reinterpret_cast<unsigned long long*>(p); }
 
@@ -404,17 +738,22 @@ extern "C" int mmgt_ff_fused(const void* x, long ldx, const float* ln_gamma, con
                  (!ln_gamma || (((uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) == 0),
              "ff_fused: pointers must be 16-byte aligned");
   const size_t lds = FF_LB + (size_t)(inner / 32) * 256;
-  auto kern = g_ffn_dbg == 1 ? ff_fused_kernel<1> : g_ffn_dbg == 2 ? ff_fused_kernel<2> : g_ffn_dbg == 3 ? ff_fused_kernel<3> : g_ffn_dbg == 4 ? ff_fused_kernel<4> : ff_fused_kernel<0>;
-  static bool attr[5] = {false, false, false, false, false};
-  if (!attr[g_ffn_dbg]) {
+  const bool one = g_ffn_ver == 4;
+  auto kern = one ? (g_ffn_dbg == 1 ? ff_fused1_kernel<1, false> : g_ffn_dbg == 2 ? ff_fused1_kernel<2, false>
+                     : g_ffn_trace ? ff_fused1_kernel<0, true> : ff_fused1_kernel<0, false>)
+                  : (g_ffn_dbg == 1 ? ff_fused_kernel<1> : g_ffn_dbg == 2 ? ff_fused_kernel<2> : g_ffn_dbg == 3 ? ff_fused_kernel<3>
+                     : g_ffn_dbg == 4 ? ff_fused_kernel<4> : ff_fused_kernel<0>);
+  static bool attr[2][6] = {};
+  const int ai = one && g_ffn_trace ? 5 : g_ffn_dbg;
+  if (!attr[one][ai]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LB + FF_MAXSB * 256) != hipSuccess) {
       mmgt_set_error("ff_fused: cannot reserve %d bytes of LDS", FF_LB + FF_MAXSB * 256);
       return 2;
     }
-    attr[g_ffn_dbg] = true;
+    attr[one][ai] = true;
   }
   const unsigned grid = (unsigned)((M + 127) / 128);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)x, ldx, ln_gamma, ln_beta, eps,
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(one ? 256 : 512), lds, (hipStream_t)stream, (const bf16_t*)x, ldx, ln_gamma, ln_beta, eps,
                      (const char*)wimg, inner / 32, bias2, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, M, g_ffn_trace);
   MMGT_LAUNCH_CHECK();
   return 0;

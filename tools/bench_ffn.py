@@ -42,14 +42,19 @@ def main():
     fused = lambda: hip.ff_fused(x, g, b, img, b2, x, INNER, out=out)
     three = lambda: hip.gemm(hip.gemm(hip.layernorm(x, g, b, 1e-5), wp, bp, act=hip.ACT_GEGLU), w2, b2, residual=x)
     fl = 2.0 * M * (2 * INNER * C + C * INNER)
+    def ver(v):
+        hip.lib().mmgt_tune(b"ffn_ver", v)
+        return t_ms(fused)
     for rnd in range(3):
-        tf, t3 = t_ms(fused), t_ms(three)
-        print(f"round {rnd}: fused {tf * 1e3:7.1f} us = {fl / tf / 1e9:6.0f} TFLOP/s | LN + ff1 + ff2 {t3 * 1e3:7.1f} us = {fl / t3 / 1e9:6.0f} TFLOP/s", flush=True)
-    for dbg, what in ((1, "compute stream alone (no weight fetch)"), (2, "weight stream alone (no MFMA / GELU)"),
-                      (3, "no GELU"), (4, "no ff2 MFMAs")):
-        hip.lib().mmgt_tune(b"ffn_dbg", dbg)
-        print(f"ffn_dbg {dbg}: {t_ms(fused) * 1e3:7.1f} us   {what}", flush=True)
-    hip.lib().mmgt_tune(b"ffn_dbg", 0)
+        t3v, t4v, t3 = ver(3), ver(4), t_ms(three)
+        print(f"round {rnd}: fused two-role {t3v * 1e3:7.1f} us = {fl / t3v / 1e9:6.0f} TFLOP/s | single-role {t4v * 1e3:7.1f} us = "
+              f"{fl / t4v / 1e9:6.0f} TFLOP/s | LN + ff1 + ff2 {t3 * 1e3:7.1f} us = {fl / t3 / 1e9:6.0f} TFLOP/s", flush=True)
+    for v in (3, 4):
+        hip.lib().mmgt_tune(b"ffn_ver", v)
+        for dbg, what in ((1, "compute stream alone (no weight fetch)"), (2, "weight stream alone (no MFMA / GELU)")):
+            hip.lib().mmgt_tune(b"ffn_dbg", dbg)
+            print(f"ver {v} ffn_dbg {dbg}: {t_ms(fused) * 1e3:7.1f} us   {what}", flush=True)
+        hip.lib().mmgt_tune(b"ffn_dbg", 0)
 
 
 if __name__ == "__main__":

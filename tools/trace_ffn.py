@@ -25,6 +25,8 @@ def main():
     out = torch.empty_like(x)
     if len(sys.argv) > 1:
         hip.lib().mmgt_tune(b"ffn_dbg", int(sys.argv[1]))
+    ver = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    hip.lib().mmgt_tune(b"ffn_ver", ver)
     for _ in range(3):
         hip.ff_fused(x, g, b, img, b2, x, INNER, out=out)
     nwg = M // 128
@@ -44,7 +46,14 @@ def main():
         namesB += [f"it{i} ff2({i - 2})", f"it{i} wait W1 + M", f"it{i} DMA issue + wait W2", f"it{i} S({i + 1})"]
     namesB[-1] = "iterations 8 .. nsb, last ff2"
     namesB += ["epilogue"]
-    for role, names in ((0, namesA), (1, namesB)):
+    if ver == 4:     # single-role kernel: one stamp stream
+        namesA = ["x load + tables + LayerNorm", "wait W1(0), ff1(0), GEGLU(0) 1st half, wait W1(1)"]
+        for j in range(6):
+            namesA += [f"it{j} A: ff1({j + 1}) || GEGLU({j}) 2nd part (+ hand-over)", f"it{j} B: ff2({j}) || GEGLU({j + 1}) 1st part (+ hand-over)"]
+        namesA += ["-"]
+        namesA[-1] = "iterations 6 .. nsb - 1"
+        namesA += ["epilogue"]
+    for role, names in ((0, namesA), (1, namesB))[:1 if ver == 4 else 2]:
         tr = t[:, role]
         n = int((tr[0] != 0).sum())
         d = (tr[:, 1:n] - tr[:, :n - 1]).float()
