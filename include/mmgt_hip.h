@@ -140,6 +140,21 @@ int mmgt_ff_fused(const void* x, long ldx, const float* ln_gamma, const float* l
                   const float* bias2, const void* residual, long ldr, void* out, long ldo, int M, int C, int inner, int dtype,
                   void* stream);
 
+/* [LayerNorm ->] Linear(s) of the 320-channel level with the rows stationary in registers (csrc/rowgemm.hip), bf16:
+ *   y[m, :] = [LN](x[m, :]) . W^T + bias [+ bias2[m / bias2_rows]] [+ residual[m, :]],   K = 320, N % 32 == 0, N <= 1920
+ * Columns [0, n1) are written row-major to out[m * ldo + c]; columns [n1, N) TRANSPOSED per batch of n_tok rows to
+ * out_t[(m / n_tok) * (N - n1) * npad + (c - n1) * npad + m % n_tok] (the V^T operand of mmgt_attention with v_transposed = 1), so the
+ * q | k GEMM and the W . X^T GEMM of a self-attention and the LayerNorm in front of both are one launch that reads x once.
+ * ln_gamma == NULL: no LayerNorm; ln_beta: [pe_mod][320], row (m / pe_div) % pe_mod (pe_mod <= 1: one row) -- the motion module's
+ * positional encoding folded into beta as in mmgt_layernorm.  A residual needs n1 == N.  wimg: mmgt_amd/packing.py: pack_rowgemm
+ * (mmgt_rowgemm320_image_bytes(N) bytes; -1 if N is not supported).
+ * Replaces: norm1 / norm2 + to_q / to_k / to_v, and to_out[0] + residual, of src/models/attention.py:346-360,440-462,700-760
+ * (diffusers Attention) and of src/models/motion_module.py:294-330 at the 64x64 level. */
+long mmgt_rowgemm320_image_bytes(int N);
+int mmgt_rowgemm320(const void* x, long ldx, const float* ln_gamma, const float* ln_beta, int pe_div, int pe_mod, float eps,
+                    const void* wimg, const float* bias, const float* bias2, int bias2_rows, const void* residual, long ldr,
+                    void* out, long ldo, int n1, void* out_t, int n_tok, int npad, int M, int N, int dtype, void* stream);
+
 /* wav2vec2 feature extractor, element-wise pieces (csrc/wav2vec.hip; the convs / Linears / attention run on mmgt_gemm, mmgt_layernorm,
  * mmgt_attention).  x, out: (rows, C) channels-last in `dtype`.
  *   mmgt_channel_norm_gelu: out = gelu((x - mean_c) * rstd_c * gamma + beta), statistics per CHANNEL over the rows -- GroupNorm(C, C)

@@ -867,6 +867,7 @@ void mmgt_attn_set64(int v);
 void mmgt_gn_set_rows(int v);
 void mmgt_ffn_set_dbg(int v);
 void mmgt_ffn_set_ver(int v);
+void mmgt_rowgemm_set_dbg(int v);
 void mmgt_attn64_set_pad(int v);
 extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return 0; }
@@ -875,6 +876,7 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "splitk")) { g_splitk = value; return 0; }
   if (key && !strcmp(key, "attn64_pad")) { mmgt_attn64_set_pad(value); return 0; }
   if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 4) { mmgt_ffn_set_dbg(value); return 0; }
+  if (key && !strcmp(key, "rowgemm_dbg") && value >= 0 && value <= 4) { mmgt_rowgemm_set_dbg(value); return 0; }
   if (key && !strcmp(key, "ffn_ver") && (value == 3 || value == 4)) { mmgt_ffn_set_ver(value); return 0; }
   mmgt_set_error("tune: unknown key");
   return 1;

@@ -47,6 +47,9 @@ _SIGS = {
     "mmgt_ff_fused_image_bytes": (c_int, [c_int, c_int]),
     "mmgt_ff_fused": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long,
                               c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_rowgemm320_image_bytes": (c_long, [c_int]),
+    "mmgt_rowgemm320": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                c_long, c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_channel_norm_gelu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
     "mmgt_lerp_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_silu": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
@@ -322,6 +325,45 @@ def ff_fused(x, ln_gamma, ln_beta, wimg, bias2, residual, inner, eps=1e-5, out=N
                                _ptr(_f32(bias2, "bias2")), _ptr(residual), residual.stride(0), _ptr(out), out.stride(0), M, C, inner,
                                dtype_code(x.dtype), _stream()), "mmgt_ff_fused")
     return out
+
+
+def rowgemm320_supported(dtype, K, N):
+    return dtype == torch.bfloat16 and K == 320 and lib().mmgt_rowgemm320_image_bytes(N) > 0
+
+
+def rowgemm320(x, wimg, N, bias=None, *, ln_gamma=None, ln_beta=None, pe_div=0, pe_mod=0, eps=1e-5, residual=None, bias2=None,
+               bias2_rows=0, n1=None, out=None, out_t=None, n_tok=0):
+    """[LayerNorm ->] Linear of the 320-channel level in one launch that reads x once (csrc/rowgemm.hip).  x (M, 320) bf16, wimg =
+    packing.pack_rowgemm(W (N, 320)).  Columns [0, n1) -> out (M, n1) row-major (+ residual, n1 == N only), columns [n1, N) ->
+    out_t (M / n_tok, N - n1, npad) transposed per batch of n_tok rows (the V^T operand of `attention(v_transposed=True)`).
+    ln_beta (pe_mod, 320) fp32: row (m / pe_div) % pe_mod.  Returns (out, out_t)."""
+    _dev(x, wimg, bias, ln_gamma, ln_beta, residual, bias2, out, out_t)
+    assert x.dim() == 2 and x.shape[1] == 320 and x.stride(1) == 1 and x.dtype == torch.bfloat16
+    M = x.shape[0]
+    n1 = N if n1 is None else n1
+    assert wimg.dtype == torch.uint8 and wimg.is_contiguous() and wimg.numel() == lib().mmgt_rowgemm320_image_bytes(N)
+    if n1 and out is None:
+        out = torch.empty((M, n1), device=x.device, dtype=x.dtype)
+    npad = 0
+    if n1 < N:
+        assert n_tok > 0 and M % n_tok == 0
+        if out_t is None:
+            out_t = torch.empty((M // n_tok, N - n1, (n_tok + 7) // 8 * 8), device=x.device, dtype=x.dtype)
+        assert out_t.dtype == x.dtype and out_t.is_contiguous() and out_t.shape[:2] == (M // n_tok, N - n1)
+        npad = out_t.shape[2]
+    if out is not None:
+        assert out.shape == (M, n1) and out.stride(1) == 1 and out.dtype == x.dtype
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.stride(1) == 1 and residual.dtype == x.dtype
+    if ln_beta is not None:
+        assert ln_beta.is_contiguous() and ln_beta.numel() >= 320 * max(pe_mod, 1)
+    if bias2 is not None:
+        assert bias2.dim() == 2 and bias2.shape[1] == N and bias2.is_contiguous() and (M + bias2_rows - 1) // bias2_rows <= bias2.shape[0]
+    _check(lib().mmgt_rowgemm320(_ptr(x), x.stride(0), _ptr(_f32(ln_gamma, "ln_gamma")), _ptr(_f32(ln_beta, "ln_beta")), pe_div, pe_mod,
+                                 eps, _ptr(wimg), _ptr(_f32(bias, "bias")), _ptr(_f32(bias2, "bias2")), bias2_rows, _ptr(residual),
+                                 0 if residual is None else residual.stride(0), _ptr(out), 0 if out is None else out.stride(0), n1,
+                                 _ptr(out_t), n_tok, npad, M, N, dtype_code(x.dtype), _stream()), "mmgt_rowgemm320")
+    return out, out_t
 
 
 # ------------------------------------------------------------------------------------------------------------ attention

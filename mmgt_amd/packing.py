@@ -83,3 +83,13 @@ def pack_ff_fused(w1, b1, w2):
     out[:, n1:n1 + n2] = img2.contiguous().view(torch.uint8).reshape(nsb, n2)
     out[:, n1 + n2:n1 + n2 + 256] = bias.contiguous().view(torch.uint8).reshape(nsb, 256)
     return out.reshape(-1)
+
+
+def pack_rowgemm(w):
+    """Linear weight(s) (N, 320) -> the fragment-major image of csrc/rowgemm.hip (mmgt_rowgemm320), a uint8 tensor of N / 32 column tiles
+    of 20 KiB: [tile nt][k-step ks = 0 .. 19] 1-KiB fragments, lane l = (c = l & 31, hh = l >> 5) owns bytes 16 l .. 16 l + 15 =
+    8 bf16 w[32 nt + c][16 ks + 8 hh + j].  Several Linears that share their input are stacked along N before packing (q | k | v)."""
+    N, K = w.shape
+    assert K == 320 and N % 32 == 0
+    img = w.to(torch.bfloat16).reshape(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()   # (nt, ks, hh, c, 8)
+    return img.view(torch.uint8).reshape(-1)

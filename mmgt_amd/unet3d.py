@@ -20,7 +20,7 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from . import hip
-from .packing import pack_conv3x3, pack_ff_fused, pack_geglu, pad_cols, pad_rows, round_up
+from .packing import pack_conv3x3, pack_ff_fused, pack_geglu, pack_rowgemm, pad_cols, pad_rows, round_up
 from .unet3d_spec import unet3d_spec
 
 SD15_CONFIG = dict(  # SD-1.5 unet/config.json + unet_3d.py:649-662 + config/prompts/animation.yaml:47-75
@@ -103,6 +103,7 @@ class UNet3DConditionModel:
         self.training = True                 # from_config leaves the module in train() mode
         self.gradient_checkpointing = False
         self._fuse_ff = os.environ.get("MMGT_NO_FUSED_FF") != "1"     # A/B switch (tools/ab_*.sh): the three-launch FeedForward
+        self._fuse_ln = os.environ.get("MMGT_NO_ROWGEMM") != "1"      # A/B switch: LayerNorm and q / k / v GEMMs as separate launches
         self.spec = unet3d_spec(boc, cfg["cross_attention_dim"], cfg["audio_attention_dim"], self.in_channels,
                                 self.out_channels, cfg["layers_per_block"],
                                 cfg["motion_module_kwargs"].get("temporal_position_encoding_max_len", 32))
@@ -247,11 +248,18 @@ class UNet3DConditionModel:
                     w[p + ".ffimg"] = pack_ff_fused(sd[p + ".net.0.proj.weight"].to(self._device), self._f(sd[p + ".net.0.proj.bias"]),
                                                     sd[p + ".net.2.weight"].to(self._device))
 
+        def rowimg(key, ws):
+            """The 320-channel level: LayerNorm -> Linear(s) as one launch that keeps the rows in registers (csrc/rowgemm.hip)."""
+            wcat = torch.cat(ws, 0)
+            if self._fuse_ln and hip.rowgemm320_supported(self._dtype, wcat.shape[1], wcat.shape[0]):
+                w[key] = pack_rowgemm(wcat.to(self._device))
+
         def self_attn(p):
             if has(p + ".to_q.weight"):
                 w[p + ".qk.w"] = self._t(torch.cat([sd[p + ".to_q.weight"], sd[p + ".to_k.weight"]], 0))
                 w[p + ".k.w"] = self._t(sd[p + ".to_k.weight"])
                 w[p + ".v.w"] = self._t(sd[p + ".to_v.weight"])
+                rowimg(p + ".qkv_img", [sd[p + ".to_q.weight"], sd[p + ".to_k.weight"], sd[p + ".to_v.weight"]])
             lin(p + ".to_out.0", p + ".o")
 
         def conv(p, cin_pad=None, cout_pad=None):
@@ -322,6 +330,7 @@ class UNet3DConditionModel:
             self_attn(t + ".attn1")
             if has(f"{t}.attn2_0.to_q.weight"):
                 w[t + ".q3.w"] = self._t(torch.cat([sd[f"{t}.attn2_{i}.to_q.weight"] for i in range(3)], 0))
+                rowimg(t + ".q3_img", [sd[f"{t}.attn2_{i}.to_q.weight"] for i in range(3)])
                 w[t + ".kv3.w"] = self._t(torch.cat([sd[f"{t}.attn2_{i}.to_k.weight"] for i in range(3)] +
                                                     [sd[f"{t}.attn2_{i}.to_v.weight"] for i in range(3)], 0))
             for i, z in enumerate(("zero_conv_full", "zero_conv_face", "zero_conv_lip")):
@@ -351,6 +360,7 @@ class UNet3DConditionModel:
                 if has(a + ".to_q.weight"):
                     w[a + ".qkv.w"] = self._t(torch.cat([sd[a + ".to_q.weight"], sd[a + ".to_k.weight"],
                                                          sd[a + ".to_v.weight"]], 0))
+                    rowimg(a + ".qkv_img", [sd[a + ".to_q.weight"], sd[a + ".to_k.weight"], sd[a + ".to_v.weight"]])
                 lin(a + ".to_out.0", a + ".o")
                 if has(a + ".pos_encoder.pe"):
                     w[a + ".pe"] = self._f(sd[a + ".pos_encoder.pe"][0])
@@ -450,15 +460,21 @@ class UNet3DConditionModel:
             self.w[f"{p}.sc.w.1"] = wsc[:, c0:].contiguous()
         return self.w[key]
 
-    def _self_attention(self, t, n1, nb, n, inner, bank=None, frames=1, cfg_row=None):
+    def _self_attention(self, t, n1, nb, n, inner, bank=None, frames=1, cfg_row=None, norm=None):
         """attn1: q,k from one GEMM, V^T from a batched W.X^T GEMM, flash attention, returns (nb*n, inner).
         cfg_row: None = both CFG rows batched (the bank is read by the second half of the batch only); 0 / 1 = the batch
-        holds the unconditional / conditional row alone (window-parallel sampling splits them over ranks)."""
+        holds the unconditional / conditional row alone (window-parallel sampling splits them over ranks).
+        norm: `n1` is the UN-normalised hidden state and `norm` the key of the LayerNorm in front of the attention: LayerNorm, q | k
+        and V^T come out of one launch (the 320-channel level, csrc/rowgemm.hip)."""
         hd = inner // self.heads
-        qk = hip.gemm(n1, self.w[t + ".qk.w"])
         npad = round_up(n, 8)
         vt = torch.empty((nb, inner, npad), device=self._device, dtype=self._dtype)
-        hip.gemm_batched_wx(self.w[t + ".v.w"], n1.view(nb, n, inner), out=vt)
+        if norm is not None:
+            qk, _ = hip.rowgemm320(n1, self.w[t + ".qkv_img"], 3 * inner, ln_gamma=self.w[norm + ".g"], ln_beta=self.w[norm + ".b"],
+                                   n1=2 * inner, n_tok=n, out_t=vt)
+        else:
+            qk = hip.gemm(n1, self.w[t + ".qk.w"])
+            hip.gemm_batched_wx(self.w[t + ".v.w"], n1.view(nb, n, inner), out=vt)
         o = torch.empty((nb * n, inner), device=self._device, dtype=self._dtype)
         kw = {}
         if bank is not None and cfg_row != 0:
@@ -482,11 +498,12 @@ class UNet3DConditionModel:
         xn = self._gn(p + ".norm", x, 1e-6)
         hid = self._lin(p + ".proj_in", xn.view(m, c))
         inner = hid.shape[1]
-        n1 = self._ln(t + ".norm1", hid)
+        fuse = write is None and (t + ".attn1.qkv_img") in self.w and n % 128 == 0
+        n1 = hid if fuse else self._ln(t + ".norm1", hid)
         if write is not None:            # ReferenceNet "write" mode: bank.append(norm_hidden_states) (mutual_self_attention.py:139-148)
             write[p] = n1.view(nb, n, inner).float()
         o = self._self_attention(t + ".attn1", n1, nb, n, inner, bank=None if write is not None else self._banks.get(p),
-                                 frames=frames, cfg_row=cfg_row)
+                                 frames=frames, cfg_row=cfg_row, norm=t + ".norm1" if fuse else None)
         if ehs.shape[1] == 1:
             # one key: softmax == 1, attn2 output is the per-CFG-row constant to_out(to_v(e))
             cvec = self._clip_vector(t, ehs)
@@ -542,11 +559,15 @@ class UNet3DConditionModel:
         hid = self._lin(p + ".proj_in", xn.view(m, c))
         inner = hid.shape[1]
         hd = inner // self.heads
-        n1 = self._ln(t + ".norm1", hid)
-        o = self._self_attention(t + ".attn1", n1, nb, n, inner)
+        if (t + ".attn1.qkv_img") in self.w and n % 128 == 0:
+            o = self._self_attention(t + ".attn1", hid, nb, n, inner, norm=t + ".norm1")
+        else:
+            o = self._self_attention(t + ".attn1", self._ln(t + ".norm1", hid), nb, n, inner)
         hid = hip.gemm(o, self.w[t + ".attn1.o.w"], self.w[t + ".attn1.o.bias"], residual=hid)
-        n2 = self._ln(t + ".norm2", hid)
-        q3 = hip.gemm(n2, self.w[t + ".q3.w"])
+        if (t + ".q3_img") in self.w:
+            q3, _ = hip.rowgemm320(hid, self.w[t + ".q3_img"], 3 * inner, ln_gamma=self.w[t + ".norm2.g"], ln_beta=self.w[t + ".norm2.b"])
+        else:
+            q3 = hip.gemm(self._ln(t + ".norm2", hid), self.w[t + ".q3.w"])
         la = audio.shape[1]
         kv3 = hip.gemm(audio.view(nb * la, -1), self.w[t + ".kv3.w"])
         a3 = torch.empty_like(q3)
@@ -583,8 +604,12 @@ class UNet3DConditionModel:
         hid = self._lin(q + ".proj_in", xn.view(m, c))
         for i in range(2):
             a = f"{t}.attention_blocks.{i}"
-            nrm = hip.layernorm(hid, self.w[f"{t}.norms.{i}.g"], self.w[f"{t}.norms.{i}.bpe"], 1e-5, pe_div=n, pe_mod=frames)
-            qkv = hip.gemm(nrm, self.w[a + ".qkv.w"])
+            if (a + ".qkv_img") in self.w and n % 128 == 0:
+                qkv, _ = hip.rowgemm320(hid, self.w[a + ".qkv_img"], 3 * c, ln_gamma=self.w[f"{t}.norms.{i}.g"],
+                                        ln_beta=self.w[f"{t}.norms.{i}.bpe"], pe_div=n, pe_mod=frames)
+            else:
+                nrm = hip.layernorm(hid, self.w[f"{t}.norms.{i}.g"], self.w[f"{t}.norms.{i}.bpe"], 1e-5, pe_div=n, pe_mod=frames)
+                qkv = hip.gemm(nrm, self.w[a + ".qkv.w"])
             o = torch.empty((m, c), device=self._device, dtype=self._dtype)
             st = (frames * n * 3 * c, 3 * c, n * 3 * c)
             hip.attention(qkv, qkv[:, c:], qkv[:, 2 * c:], o, batch=b * n, heads=self.heads, hd=hd, nq=frames, nk=frames,
