@@ -151,6 +151,7 @@ int mmgt_ff_fused(const void* x, long ldx, const float* ln_gamma, const float* l
  * Replaces: norm1 / norm2 + to_q / to_k / to_v, and to_out[0] + residual, of src/models/attention.py:346-360,440-462,700-760
  * (diffusers Attention) and of src/models/motion_module.py:294-330 at the 64x64 level. */
 long mmgt_rowgemm320_image_bytes(int N);
+void mmgt_rowgemm_set_trace(void* stamps);   /* debug: u64 [workgroups][32] shader-clock stamps (mmgt_tune("rowgemm_dbg", 5)); NULL = off */
 int mmgt_rowgemm320(const void* x, long ldx, const float* ln_gamma, const float* ln_beta, int pe_div, int pe_mod, float eps,
                     const void* wimg, const float* bias, const float* bias2, int bias2_rows, const void* residual, long ldr,
                     void* out, long ldo, int n1, void* out_t, int n_tok, int npad, int M, int N, int dtype, void* stream);

@@ -42,6 +42,7 @@
 
 #include "common.h"
 #include "gemm_common.h"
+#include "ln_frag.h"
 #include "mmgt_hip.h"
 
 namespace {
@@ -153,36 +154,7 @@ void ff_fused_kernel(const bf16_t* __restrict__ x, long ldx, const float* __rest
       for (int ks = 0; ks < FF_KS; ++ks) xf[ks] = *reinterpret_cast<const s16x8*>(xr + 16 * ks);
     }
     __syncthreads();                     // (tables in LDS)
-    if (gamma) {   // LayerNorm (exact two-pass statistics in registers, as ln_kernel): y = (x - mean) * rstd * gamma + beta
-      const float* lgb = reinterpret_cast<const float*>(smem + FF_LG);
-      float sum = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < FF_KS; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sum += bf16_to_f32((bf16_t)xf[ks][j]);
-      sum += __shfl_xor(sum, 32);
-      const float mean = sum / (float)FFC;
-      float sq = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < FF_KS; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = bf16_to_f32((bf16_t)xf[ks][j]) - mean; sq += d * d; }
-      sq += __shfl_xor(sq, 32);
-      const float rstd = rsqrtf(sq / (float)FFC + eps);
-#pragma unroll
-      for (int ks = 0; ks < FF_KS; ++ks) {
-        const int c = 16 * ks + 8 * hh;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(lgb + c), g1 = *reinterpret_cast<const f32x4*>(lgb + c + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(lgb + FFC + c), b1 = *reinterpret_cast<const f32x4*>(lgb + FFC + c + 4);
-        float y[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          y[j] = (bf16_to_f32((bf16_t)xf[ks][j]) - mean) * rstd * g0[j] + b0[j];
-          y[4 + j] = (bf16_to_f32((bf16_t)xf[ks][4 + j]) - mean) * rstd * g1[j] + b1[j];
-        }
-        xf[ks] = pack8(y);
-      }
-    }
+    if (gamma) layernorm_fragments(xf, reinterpret_cast<const float*>(smem + FF_LG), hh, eps);
     stamp();
     s16x8 fr[PF + 1][2];
     // Iteration i of role A:  S(i) | GEGLU(i - 1) -> packed G tile -> LDS slot (i - 1) & 1, one VALU-only block | M(i) | ff1(i), one
@@ -473,35 +445,7 @@ void ff_fused1_kernel(const bf16_t* __restrict__ x, long ldx, const float* __res
     __syncthreads();
     for_range(FF_IC(0), FF_IC(FF_P1), [&](auto i) { issue1(0, i); });
     for_range(FF_IC(0), FF_IC(FF_P1), [&](auto i) { issue1(1, i); });
-    if (gamma) {   // LayerNorm (exact two-pass statistics in registers, as ln_kernel): y = (x - mean) * rstd * gamma + beta
-      float sum = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < FF_KS; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sum += bf16_to_f32((bf16_t)xf[ks][j]);
-      sum += __shfl_xor(sum, 32);
-      const float mean = sum / (float)FFC;
-      float sq = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < FF_KS; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = bf16_to_f32((bf16_t)xf[ks][j]) - mean; sq += d * d; }
-      sq += __shfl_xor(sq, 32);
-      const float rstd = rsqrtf(sq / (float)FFC + eps);
-#pragma unroll
-      for (int ks = 0; ks < FF_KS; ++ks) {
-        const int c = 16 * ks + 8 * hh;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(lgb + c), g1 = *reinterpret_cast<const f32x4*>(lgb + c + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(lgb + FFC + c), b1 = *reinterpret_cast<const f32x4*>(lgb + FFC + c + 4);
-        float y[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          y[j] = (bf16_to_f32((bf16_t)xf[ks][j]) - mean) * rstd * g0[j] + b0[j];
-          y[4 + j] = (bf16_to_f32((bf16_t)xf[ks][4 + j]) - mean) * rstd * g1[j] + b1[j];
-        }
-        xf[ks] = pack8(y);
-      }
-    }
+    if (gamma) layernorm_fragments(xf, reinterpret_cast<const float*>(smem + FF_LG), hh, eps);
   }
   f32x16 oacc[FF_NU];
 #pragma unroll

@@ -876,7 +876,7 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "splitk")) { g_splitk = value; return 0; }
   if (key && !strcmp(key, "attn64_pad")) { mmgt_attn64_set_pad(value); return 0; }
   if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 4) { mmgt_ffn_set_dbg(value); return 0; }
-  if (key && !strcmp(key, "rowgemm_dbg") && value >= 0 && value <= 4) { mmgt_rowgemm_set_dbg(value); return 0; }
+  if (key && !strcmp(key, "rowgemm_dbg") && value >= 0 && value <= 5) { mmgt_rowgemm_set_dbg(value); return 0; }
   if (key && !strcmp(key, "ffn_ver") && (value == 3 || value == 4)) { mmgt_ffn_set_ver(value); return 0; }
   mmgt_set_error("tune: unknown key");
   return 1;

@@ -20,6 +20,7 @@
 
 #include "common.h"
 #include "gemm_common.h"
+#include "ln_frag.h"
 #include "mmgt_hip.h"
 
 namespace {
@@ -38,6 +39,7 @@ struct RowGemmArgs {
   bf16_t* out; long ldo; int n1;                                           // normal tiles: columns [0, n1)
   bf16_t* out_t; int n_tok, npad;                                          // transposed tiles: columns [n1, N) -> out_t[row / n_tok][c - n1][row % n_tok]
   int M, N;
+  unsigned long long* trace;                                               // DBG 5: [workgroup][32] shader-clock stamps of wave 0
 };
 
 template <bool RES, int DBG>
@@ -50,6 +52,13 @@ void rowgemm320_kernel(const RowGemmArgs a) {
   const long row = row0 + wid * 32 + r;
   const long rowc = row < a.M ? row : a.M - 1;
   const int nt = a.N / 32, nt1 = a.n1 / 32;
+  int trace_n = 0;
+  auto stamp = [&]() {
+    if constexpr (DBG == 5) {
+      if (a.trace && wid == 0 && lane == 0 && trace_n < 32) a.trace[(long)blockIdx.x * 32 + trace_n++] = __builtin_amdgcn_s_memtime();
+    }
+  };
+  stamp();
   using std::integral_constant;
 #define R_IC(v) integral_constant<int, (v)>{}
   auto for_range = [](auto LOc, auto HIc, auto&& fn) {
@@ -91,42 +100,7 @@ void rowgemm320_kernel(const RowGemmArgs a) {
     dma_tile(0, 0);
     dma_tile(1, R_TILE);
     dma_tile(2, 2 * R_TILE);
-    if (a.gamma) {   // LayerNorm (exact two-pass statistics in registers, as ln_kernel): y = (x - mean) * rstd * gamma + beta
-      float sum = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < R_KS; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sum += bf16_to_f32((bf16_t)xf[ks][j]);
-      sum += __shfl_xor(sum, 32);
-      const float mean = sum / (float)RC;
-      // (opaque uses between the passes: left alone, LLVM keeps the 160 unpacked fp32 values of one pass alive for the next and spills)
-#pragma unroll
-      for (int ks = 0; ks < R_KS; ++ks) asm volatile("" : "+v"(xf[ks]));
-      float sq = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < R_KS; ++ks)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = bf16_to_f32((bf16_t)xf[ks][j]) - mean; sq += d * d; }
-      sq += __shfl_xor(sq, 32);
-      const float rstd = rsqrtf(sq / (float)RC + a.eps);
-#pragma unroll
-      for (int ks = 0; ks < R_KS; ++ks) asm volatile("" : "+v"(xf[ks]));
-#pragma unroll
-      for (int ks = 0; ks < R_KS; ++ks) {
-        const int c = 16 * ks + 8 * hh;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(lgb + c), g1 = *reinterpret_cast<const f32x4*>(lgb + c + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(lgb + RC + c), b1 = *reinterpret_cast<const f32x4*>(lgb + RC + c + 4);
-        float y[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          y[j] = (bf16_to_f32((bf16_t)xf[ks][j]) - mean) * rstd * g0[j] + b0[j];
-          y[4 + j] = (bf16_to_f32((bf16_t)xf[ks][4 + j]) - mean) * rstd * g1[j] + b1[j];
-        }
-        union { u32x4 u; s16x8 s; } cv;
-        cv.u = (u32x4){pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
-        xf[ks] = cv.s;
-      }
-    }
+    if (a.gamma) layernorm_fragments(xf, lgb, hh, a.eps);
   }
 
   // fragment ring: [group parity][k-step of the group]; 4 groups of 5 k-steps per tile (an EVEN number of groups: the first group of
@@ -162,8 +136,10 @@ void rowgemm320_kernel(const RowGemmArgs a) {
   const int tok0 = (int)(row0 - bt * a.n_tok) + wid * 32;
   bf16_t* ot = a.out_t ? a.out_t + (bt * (a.N - a.n1) + r) * (long)a.npad + tok0 + 8 * hh : nullptr;
 
+  stamp();
   wait_vmcnt<2 * R_PW>();                    // tile 0 has landed (tiles 1, 2 in flight)
   __builtin_amdgcn_s_barrier();
+  stamp();
   int so_cur = 0, so_nxt = R_TILE;           // ring stage (byte offset) of tile t / t + 1; tile t + 3 goes where tile t was
   read_group(smem + R_LW + lane * 16, R_IC(0));
   for (int t = 0; t < nt; ++t) {
@@ -239,15 +215,19 @@ void rowgemm320_kernel(const RowGemmArgs a) {
     if (t < nt1) tile(std::false_type{}); else tile(std::true_type{});
     so_cur = so_nxt;
     so_nxt = so_nxt == (R_NST - 1) * R_TILE ? 0 : so_nxt + R_TILE;
+    if (t & 1) stamp();
   }
 #undef R_IC
 }
 
 int g_rowgemm_dbg = 0;
+unsigned long long* g_rowgemm_trace = nullptr;
 
 }  // namespace
 
 void mmgt_rowgemm_set_dbg(int v) { g_rowgemm_dbg = v; }
+// Debug (tools/trace_rowgemm.py): device buffer of u64 [workgroups][32] for the stamps of the rowgemm_dbg = 5 build; NULL = off.
+extern "C" void mmgt_rowgemm_set_trace(void* p) { g_rowgemm_trace = reinterpret_cast<unsigned long long*>(p); }
 
 extern "C" long mmgt_rowgemm320_image_bytes(int N) {
   if (N <= 0 || N % 32 || N > R_MAXN) return -1;
@@ -281,11 +261,12 @@ extern "C" int mmgt_rowgemm320(const void* x, long ldx, const float* ln_gamma, c
   a.out = (bf16_t*)out; a.ldo = ldo; a.n1 = n1;
   a.out_t = (bf16_t*)out_t; a.n_tok = n_tok > 0 ? n_tok : 128; a.npad = npad;
   a.M = M; a.N = N;
+  a.trace = g_rowgemm_trace;
   const int d = g_rowgemm_dbg;
   auto kern = residual ? (d == 1 ? rowgemm320_kernel<true, 1> : d == 2 ? rowgemm320_kernel<true, 2> : rowgemm320_kernel<true, 0>)
                        : (d == 1 ? rowgemm320_kernel<false, 1> : d == 2 ? rowgemm320_kernel<false, 2> : d == 3 ? rowgemm320_kernel<false, 3>
-                          : d == 4 ? rowgemm320_kernel<false, 4> : rowgemm320_kernel<false, 0>);
-  static bool attr[2][5] = {};
+                          : d == 4 ? rowgemm320_kernel<false, 4> : d == 5 ? rowgemm320_kernel<false, 5> : rowgemm320_kernel<false, 0>);
+  static bool attr[2][6] = {};
   if (!attr[residual != nullptr][d]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS) != hipSuccess) {
       mmgt_set_error("rowgemm320: cannot reserve %d bytes of LDS", R_LDS);

@@ -48,6 +48,7 @@ _SIGS = {
     "mmgt_ff_fused": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long,
                               c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_rowgemm320_image_bytes": (c_long, [c_int]),
+    "mmgt_rowgemm_set_trace": (None, [c_void_p]),
     "mmgt_rowgemm320": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                 c_long, c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_channel_norm_gelu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),

@@ -132,3 +132,19 @@ def test_rowgemm_equals_the_launches_it_replaces_at_step_shape():
     frac = (d > 2.0 ** -8 * o_ref.float().abs() + 1e-3).float().mean().item()
     print(f"out-proj + residual: max|d| {d.max().item():.3e}, {100 * frac:.4f}% beyond one ulp")
     assert d.max() <= 4 * 2.0 ** -8 * o_ref.float().abs().max() and frac < 1e-3
+
+
+def test_rowgemm_layernorm_statistics_with_a_large_row_mean():
+    """The fused LayerNorm takes its variance from one pass (E[x^2] - mean^2 in fp32): rows with |mean| = 8 std against fp64."""
+    from mmgt_amd.synthetic import hash_uniform
+    M, N = 1024, 320
+    x = _bf(hash_uniform("rg.big.x", (M, C), 1.5) + 7.0)
+    g = 1 + 0.2 * hash_uniform("rg.g", (C,), 1.0)
+    b = 0.1 * hash_uniform("rg.b", (1, C), 1.0)
+    w = _bf(hash_uniform("rg.w320", (N, C), 1.0) * C ** -0.5)
+    ref = _ref(x, w, None, g, b)
+    out, _ = _run(x, w, None, ln_gamma=g, ln_beta=b)
+    d = (out.double() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 2e-3
+    print(f"|mean| = 8 std: max|d| {d.max().item():.3e}, worst d/tol {(d / tol).max().item():.2f}")
+    assert (d <= tol).all() and d.mean() <= 2.0 ** -9 * ref.abs().mean()
