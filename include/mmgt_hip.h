@@ -87,6 +87,10 @@ int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1, int NB, in
  * Replaces: InflatedGroupNorm / nn.GroupNorm (+F.silu) at resnet.py:220-221,231,237; transformer_3d.py:174;
  * motion_module.py:156; unet_3d.py:618-619. */
 int mmgt_groupnorm_chunks(int HW);
+/* GroupNorm statistics only, as per-(image, channel) tables scale = rstd * gamma, shift = beta - mean * scale ([NB][C] fp32 each;
+ * HW > 256): mmgt_rowgemm320(norm = 2) applies them while it loads x -- transformer_3d.py:174-188 (norm -> proj_in), motion_module.py:156-170. */
+int mmgt_groupnorm_affine(const void* x, int C, const float* gamma, const float* beta, float* workspace, float* scale, float* shift,
+                          int NB, int HW, int G, float eps, int dtype, void* stream);
 int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta, void* out,
                         float* workspace, int NB, int HW, int G, float eps, int silu, int dtype, void* stream);
 
@@ -140,8 +144,11 @@ int mmgt_ff_fused(const void* x, long ldx, const float* ln_gamma, const float* l
                   const float* bias2, const void* residual, long ldr, void* out, long ldo, int M, int C, int inner, int dtype,
                   void* stream);
 
-/* [LayerNorm ->] Linear(s) of the 320-channel level with the rows stationary in registers (csrc/rowgemm.hip), bf16:
- *   y[m, :] = [LN](x[m, :]) . W^T + bias [+ bias2[m / bias2_rows]] [+ residual[m, :]],   K = 320, N % 32 == 0, N <= 1920
+/* [LayerNorm | GroupNorm ->] Linear(s) of the 320-channel level with the rows stationary in registers (csrc/rowgemm.hip), bf16:
+ *   y[m, :] = [norm](x[m, :]) . W^T + bias [+ bias2[m / bias2_rows]] [+ residual[m, :]],   K = 320, N % 32 == 0, N <= 1920
+ * norm = 0: none; 1: LayerNorm over the row (gamma [320], beta [pe_mod][320]); 2: x * gamma[g] + beta[g] with both tables
+ * [pe_mod][320] and g = (m / pe_div) % pe_mod -- the second pass of a GroupNorm (tables from mmgt_groupnorm_affine, pe_div = HW,
+ * pe_mod = NB) applied while the rows are loaded: the normalised tensor is never written.
  * Columns [0, n1) are written row-major to out[m * ldo + c]; columns [n1, N) TRANSPOSED per batch of n_tok rows to
  * out_t[(m / n_tok) * (N - n1) * npad + (c - n1) * npad + m % n_tok] (the V^T operand of mmgt_attention with v_transposed = 1), so the
  * q | k GEMM and the W . X^T GEMM of a self-attention and the LayerNorm in front of both are one launch that reads x once.
@@ -152,7 +159,7 @@ int mmgt_ff_fused(const void* x, long ldx, const float* ln_gamma, const float* l
  * (diffusers Attention) and of src/models/motion_module.py:294-330 at the 64x64 level. */
 long mmgt_rowgemm320_image_bytes(int N);
 void mmgt_rowgemm_set_trace(void* stamps);   /* debug: u64 [workgroups][32] shader-clock stamps (mmgt_tune("rowgemm_dbg", 5)); NULL = off */
-int mmgt_rowgemm320(const void* x, long ldx, const float* ln_gamma, const float* ln_beta, int pe_div, int pe_mod, float eps,
+int mmgt_rowgemm320(const void* x, long ldx, int norm, const float* ln_gamma, const float* ln_beta, int pe_div, int pe_mod, float eps,
                     const void* wimg, const float* bias, const float* bias2, int bias2_rows, const void* residual, long ldr,
                     void* out, long ldo, int n1, void* out_t, int n_tok, int npad, int M, int N, int dtype, void* stream);
 

@@ -195,6 +195,38 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
   }
 }
 
+// ---- GroupNorm pass 2 as TABLES: scale[n][c] = rstd * gamma, shift[n][c] = beta - mean * scale (the head of gn_apply_kernel, the same
+// arithmetic), for a consumer that applies v = x * scale + shift itself while it loads x (csrc/rowgemm.hip, norm = 2).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_affine_kernel(const T* __restrict__ x0, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ partial, float* __restrict__ scale, float* __restrict__ shift,
+                                                        int C, int HW, int G, int chunks, float eps) {
+  __shared__ float smean[64], srstd[64];
+  const int n = blockIdx.x, cg = C / G;
+  if (threadIdx.x < G) {
+    float a = 0.f, b = 0.f;
+    for (int ch = 0; ch < chunks; ++ch) {
+      const float* src = partial + (((long)n * chunks + ch) * G + threadIdx.x) * 2;
+      a += src[0];
+      b += src[1];
+    }
+    const float cnt = (float)HW * (float)cg;
+    const float piv = Elem<T>::ld(x0 + (long)n * HW * C + threadIdx.x * cg);      // the pivot gn_stats_kernel shifted this group's values by
+    const float dm = a / cnt;
+    float var = b / cnt - dm * dm;
+    var = var < 0.f ? 0.f : var;
+    smean[threadIdx.x] = piv + dm;
+    srstd[threadIdx.x] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int g = c / cg;
+    const float sc = srstd[g] * gamma[c];
+    scale[(long)n * C + c] = sc;
+    shift[(long)n * C + c] = beta[c] - smean[g] * sc;
+  }
+}
+
 // ---- GroupNorm for small images (HW <= 256: the 16x16 and 8x8 levels), one launch: a workgroup owns one image and GPW = 4
 // groups (a slab of HW rows x 4 C/G channels, <= 164 KB, re-read from L2), and makes three passes over it -- sum, sum of squared
 // deviations from the exact mean, normalise -- with fixed-order reductions through LDS (bitwise reproducible, no pivot needed).
@@ -400,6 +432,30 @@ extern "C" int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C
                        workspace, HW, G, chunks, lpr);
     hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x0, C0, (const float*)x1, C1, gamma,
                        beta, workspace, (float*)out, HW, G, chunks, eps, silu, lpr);
+  }
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmgt_groupnorm_affine(const void* x, int C, const float* gamma, const float* beta, float* workspace, float* scale,
+                                     float* shift, int NB, int HW, int G, float eps, int dtype, void* stream) {
+  MMGT_CHECK(x && gamma && beta && workspace && scale && shift, "groupnorm_affine: null pointer");
+  MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "groupnorm_affine: bad dtype %d", dtype);
+  const int vec = dtype == MMGT_BF16 ? 8 : 4;
+  MMGT_CHECK(C <= GN_MAXC && C % G == 0 && G <= 64 && C % vec == 0, "groupnorm_affine: unsupported channels C=%d G=%d", C, G);
+  MMGT_CHECK(NB > 0 && HW > 0 && NB <= 65535, "groupnorm_affine: bad NB=%d HW=%d", NB, HW);
+  hipStream_t s = (hipStream_t)stream;
+  const int chunks = gn_chunks_used(HW, C);
+  dim3 grid(chunks, NB);
+  const int nvec = C / vec, maxs = GN_MAXC / (vec * 64);
+  int lpr = 8;
+  while (lpr < 64 && (lpr * maxs < nvec || nvec % lpr != 0)) lpr <<= 1;
+  if (dtype == MMGT_BF16) {
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, C, (const bf16_t*)nullptr, 0, workspace, HW, G, chunks, lpr);
+    hipLaunchKernelGGL(gn_affine_kernel<bf16_t>, dim3(NB), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, workspace, scale, shift, C, HW, G, chunks, eps);
+  } else {
+    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, C, (const float*)nullptr, 0, workspace, HW, G, chunks, lpr);
+    hipLaunchKernelGGL(gn_affine_kernel<float>, dim3(NB), dim3(256), 0, s, (const float*)x, gamma, beta, workspace, scale, shift, C, HW, G, chunks, eps);
   }
   MMGT_LAUNCH_CHECK();
   return 0;

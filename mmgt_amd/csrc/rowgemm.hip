@@ -1,4 +1,4 @@
-// Row-stationary GEMM for the 320-channel level (bf16, gfx950):   out = [LayerNorm](x) . W^T + bias [+ bias2[row group]] [+ residual]
+// Row-stationary GEMM for the 320-channel level (bf16, gfx950):   out = [LayerNorm | GroupNorm affine](x) . W^T + bias [+ bias2[row group]] [+ residual]
 //
 // The projections around the level-0 attentions (attention.py:346-360,440-462,700-760: to_q / to_k / to_v / to_out; motion_module.py:
 // 294-330) are M = 196 608 rows x K = 320: a 256 x 256 GEMM tile refills its pipeline every five K chunks and the LayerNorm in front
@@ -33,7 +33,7 @@ __device__ __forceinline__ f32x16 rmma(s16x8 a, s16x8 b, f32x16 c) { return __bu
 
 struct RowGemmArgs {
   const bf16_t* x; long ldx;
-  const float* gamma; const float* beta; int pe_div, pe_mod; float eps;   // LayerNorm (gamma == NULL: none); beta row (row / pe_div) % pe_mod
+  const float* gamma; const float* beta; int norm, pe_div, pe_mod; float eps;   // norm 1: LayerNorm, beta row (row / pe_div) % pe_mod; 2: x * gamma[g] + beta[g], both tables indexed so
   const char* wimg; const float* bias; const float* bias2; int bias2_rows;
   const bf16_t* res; long ldr;
   bf16_t* out; long ldo; int n1;                                           // normal tiles: columns [0, n1)
@@ -89,9 +89,11 @@ void rowgemm320_kernel(const RowGemmArgs a) {
     // tables -> LDS before the first LDS-DMA (with one in flight hipcc waits vmcnt(0) for every plain global load)
     float* lgb = reinterpret_cast<float*>(smem + R_LG);
     float* lb = reinterpret_cast<float*>(smem + R_LB);
-    if (a.gamma && tid < 2 * RC / 4) {
-      const float* beta = a.beta + (a.pe_mod > 1 ? (long)(((unsigned)row0 / (unsigned)a.pe_div) % (unsigned)a.pe_mod) * RC : 0);
-      const float* src = tid < RC / 4 ? a.gamma + 4 * tid : beta + 4 * (tid - RC / 4);
+    if (a.norm && tid < 2 * RC / 4) {
+      const long grp = a.pe_mod > 1 ? (long)(((unsigned)row0 / (unsigned)a.pe_div) % (unsigned)a.pe_mod) * RC : 0;
+      const float* beta = a.beta + grp;
+      const float* gamma = a.gamma + (a.norm == 2 ? grp : 0);
+      const float* src = tid < RC / 4 ? gamma + 4 * tid : beta + 4 * (tid - RC / 4);
       *reinterpret_cast<f32x4*>(lgb + 4 * tid) = *reinterpret_cast<const f32x4*>(src);
     }
     const float* b2 = a.bias2 ? a.bias2 + (long)((unsigned)row0 / (unsigned)a.bias2_rows) * a.N : nullptr;
@@ -100,7 +102,8 @@ void rowgemm320_kernel(const RowGemmArgs a) {
     dma_tile(0, 0);
     dma_tile(1, R_TILE);
     dma_tile(2, 2 * R_TILE);
-    if (a.gamma) layernorm_fragments(xf, lgb, hh, a.eps);
+    if (a.norm == 1) layernorm_fragments<R_KS, true>(xf, lgb, hh, a.eps);
+    else if (a.norm == 2) layernorm_fragments<R_KS, false>(xf, lgb, hh, a.eps);
   }
 
   // fragment ring: [group parity][k-step of the group]; 4 groups of 5 k-steps per tile (an EVEN number of groups: the first group of
@@ -234,7 +237,7 @@ extern "C" long mmgt_rowgemm320_image_bytes(int N) {
   return (long)N * RC * 2;
 }
 
-extern "C" int mmgt_rowgemm320(const void* x, long ldx, const float* ln_gamma, const float* ln_beta, int pe_div, int pe_mod, float eps,
+extern "C" int mmgt_rowgemm320(const void* x, long ldx, int norm, const float* ln_gamma, const float* ln_beta, int pe_div, int pe_mod, float eps,
                                const void* wimg, const float* bias, const float* bias2, int bias2_rows, const void* residual, long ldr,
                                void* out, long ldo, int n1, void* out_t, int n_tok, int npad, int M, int N, int dtype, void* stream) {
   MMGT_CHECK(x && wimg, "rowgemm320: null pointer");
@@ -242,8 +245,9 @@ extern "C" int mmgt_rowgemm320(const void* x, long ldx, const float* ln_gamma, c
   MMGT_CHECK(mmgt_rowgemm320_image_bytes(N) > 0, "rowgemm320: N = 32 .. %d in steps of 32 (got %d)", R_MAXN, N);
   MMGT_CHECK(n1 >= 0 && n1 <= N && n1 % 32 == 0, "rowgemm320: n1 = %d must be a multiple of 32 within N = %d", n1, N);
   MMGT_CHECK(M > 0 && ldx >= RC && ldx % 8 == 0, "rowgemm320: bad M = %d or ldx = %ld", M, ldx);
-  MMGT_CHECK((ln_gamma != nullptr) == (ln_beta != nullptr), "rowgemm320: gamma / beta must come together");
-  MMGT_CHECK(!ln_gamma || pe_mod <= 1 || (pe_div > 0 && pe_div % 128 == 0), "rowgemm320: pe_div = %d must be a multiple of 128", pe_div);
+  MMGT_CHECK(norm >= 0 && norm <= 2 && (norm != 0) == (ln_gamma != nullptr) && (norm != 0) == (ln_beta != nullptr),
+             "rowgemm320: norm = %d (0 none, 1 LayerNorm, 2 scale / shift tables) and gamma / beta must come together", norm);
+  MMGT_CHECK(!norm || pe_mod <= 1 || (pe_div > 0 && pe_div % 128 == 0), "rowgemm320: pe_div = %d must be a multiple of 128", pe_div);
   MMGT_CHECK(!bias2 || (bias2_rows > 0 && bias2_rows % 128 == 0), "rowgemm320: bias2_rows = %d must be a multiple of 128", bias2_rows);
   MMGT_CHECK(n1 == 0 || (out && ldo >= n1 && ldo % 8 == 0 && (long)M * ldo * 2 < (1l << 31)),
              "rowgemm320: normal output: null, bad ldo = %ld or beyond the 2 GiB range of a buffer resource (split the rows)", ldo);
@@ -255,7 +259,7 @@ extern "C" int mmgt_rowgemm320(const void* x, long ldx, const float* ln_gamma, c
              "rowgemm320: pointers must be 16-byte aligned");
   RowGemmArgs a;
   a.x = (const bf16_t*)x; a.ldx = ldx;
-  a.gamma = ln_gamma; a.beta = ln_beta; a.pe_div = pe_div > 0 ? pe_div : 1; a.pe_mod = pe_mod; a.eps = eps;
+  a.gamma = ln_gamma; a.beta = ln_beta; a.norm = norm; a.pe_div = pe_div > 0 ? pe_div : 1; a.pe_mod = pe_mod; a.eps = eps;
   a.wimg = (const char*)wimg; a.bias = bias; a.bias2 = bias2; a.bias2_rows = bias2_rows > 0 ? bias2_rows : 1;
   a.res = (const bf16_t*)residual; a.ldr = ldr;
   a.out = (bf16_t*)out; a.ldo = ldo; a.n1 = n1;

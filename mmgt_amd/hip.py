@@ -49,7 +49,9 @@ _SIGS = {
                               c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_rowgemm320_image_bytes": (c_long, [c_int]),
     "mmgt_rowgemm_set_trace": (None, [c_void_p]),
-    "mmgt_rowgemm320": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+    "mmgt_groupnorm_affine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int,
+                                      c_void_p]),
+    "mmgt_rowgemm320": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                 c_long, c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_channel_norm_gelu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
     "mmgt_lerp_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -271,6 +273,21 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x1=None, out=None):
     return out
 
 
+def groupnorm_affine(x, gamma, beta, groups, eps):
+    """x (NB, HW, C), HW > 256 -> (scale, shift), fp32 (NB, C) each: GroupNorm(x)[n, p, c] = x[n, p, c] * scale[n, c] + shift[n, c].
+    The statistics pass of `groupnorm` alone; `rowgemm320(pre_scale=, pre_shift=)` applies the tables while it loads x."""
+    _dev(x, gamma, beta)
+    assert x.dim() == 3 and x.is_contiguous() and x.shape[1] > 256
+    NB, HW, C = x.shape
+    chunks = lib().mmgt_groupnorm_chunks(HW)
+    ws = torch.empty((NB * chunks * groups * 2,), device=x.device, dtype=torch.float32)
+    scale = torch.empty((NB, C), device=x.device, dtype=torch.float32)
+    shift = torch.empty((NB, C), device=x.device, dtype=torch.float32)
+    _check(lib().mmgt_groupnorm_affine(_ptr(x), C, _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), _ptr(ws), _ptr(scale), _ptr(shift),
+                                       NB, HW, groups, eps, dtype_code(x.dtype), _stream()), "mmgt_groupnorm_affine")
+    return scale, shift
+
+
 def layernorm(x, gamma, beta, eps=1e-5, pe=None, pe_div=1, pe_mod=1, out=None):
     """x (rows, C) -> LayerNorm over C (+ pe[(row // pe_div) % pe_mod] added after the affine).  With pe=None and
     pe_mod > 1, `beta` is a (>= pe_mod, C) table of beta + pe rows indexed the same way."""
@@ -333,12 +350,18 @@ def rowgemm320_supported(dtype, K, N):
 
 
 def rowgemm320(x, wimg, N, bias=None, *, ln_gamma=None, ln_beta=None, pe_div=0, pe_mod=0, eps=1e-5, residual=None, bias2=None,
-               bias2_rows=0, n1=None, out=None, out_t=None, n_tok=0):
+               bias2_rows=0, n1=None, out=None, out_t=None, n_tok=0, pre_scale=None, pre_shift=None, pre_rows=0):
     """[LayerNorm ->] Linear of the 320-channel level in one launch that reads x once (csrc/rowgemm.hip).  x (M, 320) bf16, wimg =
     packing.pack_rowgemm(W (N, 320)).  Columns [0, n1) -> out (M, n1) row-major (+ residual, n1 == N only), columns [n1, N) ->
     out_t (M / n_tok, N - n1, npad) transposed per batch of n_tok rows (the V^T operand of `attention(v_transposed=True)`).
-    ln_beta (pe_mod, 320) fp32: row (m / pe_div) % pe_mod.  Returns (out, out_t)."""
-    _dev(x, wimg, bias, ln_gamma, ln_beta, residual, bias2, out, out_t)
+    ln_beta (pe_mod, 320) fp32: row (m / pe_div) % pe_mod.  pre_scale / pre_shift (M / pre_rows, 320) fp32 instead of a LayerNorm:
+    x * scale[m / pre_rows] + shift[m / pre_rows] (`groupnorm_affine`).  Returns (out, out_t)."""
+    _dev(x, wimg, bias, ln_gamma, ln_beta, residual, bias2, out, out_t, pre_scale, pre_shift)
+    norm = 1 if ln_gamma is not None else 0
+    if pre_scale is not None:
+        assert ln_gamma is None and pre_rows > 0 and x.shape[0] % pre_rows == 0
+        assert pre_scale.shape == pre_shift.shape == (x.shape[0] // pre_rows, 320) and pre_scale.is_contiguous() and pre_shift.is_contiguous()
+        norm, ln_gamma, ln_beta, pe_div, pe_mod = 2, pre_scale, pre_shift, pre_rows, x.shape[0] // pre_rows
     assert x.dim() == 2 and x.shape[1] == 320 and x.stride(1) == 1 and x.dtype == torch.bfloat16
     M = x.shape[0]
     n1 = N if n1 is None else n1
@@ -360,7 +383,7 @@ def rowgemm320(x, wimg, N, bias=None, *, ln_gamma=None, ln_beta=None, pe_div=0, 
         assert ln_beta.is_contiguous() and ln_beta.numel() >= 320 * max(pe_mod, 1)
     if bias2 is not None:
         assert bias2.dim() == 2 and bias2.shape[1] == N and bias2.is_contiguous() and (M + bias2_rows - 1) // bias2_rows <= bias2.shape[0]
-    _check(lib().mmgt_rowgemm320(_ptr(x), x.stride(0), _ptr(_f32(ln_gamma, "ln_gamma")), _ptr(_f32(ln_beta, "ln_beta")), pe_div, pe_mod,
+    _check(lib().mmgt_rowgemm320(_ptr(x), x.stride(0), norm, _ptr(_f32(ln_gamma, "ln_gamma")), _ptr(_f32(ln_beta, "ln_beta")), pe_div, pe_mod,
                                  eps, _ptr(wimg), _ptr(_f32(bias, "bias")), _ptr(_f32(bias2, "bias2")), bias2_rows, _ptr(residual),
                                  0 if residual is None else residual.stride(0), _ptr(out), 0 if out is None else out.stride(0), n1,
                                  _ptr(out_t), n_tok, npad, M, N, dtype_code(x.dtype), _stream()), "mmgt_rowgemm320")

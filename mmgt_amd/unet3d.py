@@ -254,6 +254,11 @@ class UNet3DConditionModel:
             if self._fuse_ln and hip.rowgemm320_supported(self._dtype, wcat.shape[1], wcat.shape[0]):
                 w[key] = pack_rowgemm(wcat.to(self._device))
 
+        def proj_in_img(p):      # GroupNorm -> proj_in of a transformer block as one launch (GroupNorm applied while the rows are loaded)
+            if has(p + ".proj_in.weight"):
+                wt = sd[p + ".proj_in.weight"]
+                rowimg(p + ".proj_in.img", [wt.reshape(wt.shape[0], -1)])
+
         def self_attn(p):
             if has(p + ".to_q.weight"):
                 w[p + ".qk.w"] = self._t(torch.cat([sd[p + ".to_q.weight"], sd[p + ".to_k.weight"]], 0))
@@ -307,6 +312,7 @@ class UNet3DConditionModel:
             t = p + ".transformer_blocks.0"
             norm(p + ".norm")
             lin(p + ".proj_in")
+            proj_in_img(p)
             lin(p + ".proj_out")
             for n in ("norm1", "norm2", "norm3"):
                 norm(f"{t}.{n}")
@@ -324,6 +330,7 @@ class UNet3DConditionModel:
             t = p + ".transformer_blocks.0"
             norm(p + ".norm")
             lin(p + ".proj_in")
+            proj_in_img(p)
             lin(p + ".proj_out")
             for n in ("norm1", "norm2", "norm3"):
                 norm(f"{t}.{n}")
@@ -354,6 +361,7 @@ class UNet3DConditionModel:
             t = q + ".transformer_blocks.0"
             norm(q + ".norm")
             lin(q + ".proj_in")
+            proj_in_img(q)
             lin(q + ".proj_out")
             for i in range(2):
                 a = f"{t}.attention_blocks.{i}"
@@ -429,6 +437,19 @@ class UNet3DConditionModel:
                                 self.w[p + ".ff2.w"].shape[1])
         return self._ff(p, self._ln(norm, hid), hid)
 
+    def _norm_proj_in(self, p, x):
+        """proj_in(GroupNorm(x)) of a transformer block (transformer_3d.py:174-188, motion_module.py:156-170) -> (nb*h*w, inner): at the
+        320-channel level the statistics pass alone, then one launch that normalises the rows while it loads them (csrc/rowgemm.hip)."""
+        nb, h, ww, c = x.shape
+        n = h * ww
+        img = self.w.get(p + ".proj_in.img")
+        if img is not None and n > 256 and n % 128 == 0:
+            sc, sh = hip.groupnorm_affine(x.view(nb, n, c), self.w[p + ".norm.g"], self.w[p + ".norm.b"], 32, 1e-6)
+            return hip.rowgemm320(x.view(nb * n, c), img, self.w[p + ".proj_in.w"].shape[0], self.w.get(p + ".proj_in.bias"),
+                                  pre_scale=sc, pre_shift=sh, pre_rows=n)[0]
+        xn = self._gn(p + ".norm", x, 1e-6)
+        return self._lin(p + ".proj_in", xn.view(nb * n, c))
+
     def _resnet(self, p, x, temb, skip=None):
         """ResnetBlock3D (resnet.py:217-247); `skip` = the UNet skip tensor that the reference concatenates first."""
         nb, h, ww, c0 = x.shape
@@ -495,8 +516,7 @@ class UNet3DConditionModel:
         n = h * ww
         m = nb * n
         t = p + ".transformer_blocks.0"
-        xn = self._gn(p + ".norm", x, 1e-6)
-        hid = self._lin(p + ".proj_in", xn.view(m, c))
+        hid = self._norm_proj_in(p, x)
         inner = hid.shape[1]
         fuse = write is None and (t + ".attn1.qkv_img") in self.w and n % 128 == 0
         n1 = hid if fuse else self._ln(t + ".norm1", hid)
@@ -555,8 +575,7 @@ class UNet3DConditionModel:
         n = h * ww
         m = nb * n
         t = p + ".transformer_blocks.0"
-        xn = self._gn(p + ".norm", x, 1e-6)
-        hid = self._lin(p + ".proj_in", xn.view(m, c))
+        hid = self._norm_proj_in(p, x)
         inner = hid.shape[1]
         hd = inner // self.heads
         if (t + ".attn1.qkv_img") in self.w and n % 128 == 0:
@@ -600,8 +619,7 @@ class UNet3DConditionModel:
             raise RuntimeError("temporal attention window is limited to 32 frames (positional encoding max_len)")
         q = p + ".temporal_transformer"
         t = q + ".transformer_blocks.0"
-        xn = self._gn(q + ".norm", x, 1e-6)
-        hid = self._lin(q + ".proj_in", xn.view(m, c))
+        hid = self._norm_proj_in(q, x)
         for i in range(2):
             a = f"{t}.attention_blocks.{i}"
             if (a + ".qkv_img") in self.w and n % 128 == 0:

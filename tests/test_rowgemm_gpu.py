@@ -148,3 +148,29 @@ def test_rowgemm_layernorm_statistics_with_a_large_row_mean():
     tol = 2.0 ** -8 * ref.abs() + 2e-3
     print(f"|mean| = 8 std: max|d| {d.max().item():.3e}, worst d/tol {(d / tol).max().item():.2f}")
     assert (d <= tol).all() and d.mean() <= 2.0 ** -9 * ref.abs().mean()
+
+
+def test_rowgemm_groupnorm_prologue_is_bitwise_the_two_launch_path():
+    """GroupNorm -> proj_in (transformer_3d.py:174-188): statistics as scale / shift tables + one launch that applies them while it
+    loads the rows, against groupnorm() followed by the same rowgemm without a prologue -- the same arithmetic, bit for bit --
+    and against gemm() within one ulp."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_rowgemm
+    from mmgt_amd.synthetic import hash_uniform
+    dev = "cuda:0"
+    nb, n = 6, 4096
+    x = _bf(hash_uniform("rg.gn.x", (nb, n, C), 1.5, dev) + 0.5 * hash_uniform("rg.gn.off", (nb, 1, C), 1.0, dev))
+    g, b = 1 + 0.2 * hash_uniform("rg.gn.g", (C,), 1.0, dev), 0.1 * hash_uniform("rg.gn.b", (C,), 1.0, dev)
+    w = _bf(hash_uniform("rg.gn.w", (C, C), 1.0, dev) * C ** -0.5)
+    bias = 0.1 * hash_uniform("rg.gn.bias", (C,), 1.0, dev)
+    img = pack_rowgemm(w)
+    xn = hip.groupnorm(x, g, b, 32, 1e-6)
+    two, _ = hip.rowgemm320(xn.view(nb * n, C), img, C, bias)
+    sc, sh = hip.groupnorm_affine(x, g, b, 32, 1e-6)
+    one, _ = hip.rowgemm320(x.view(nb * n, C), img, C, bias, pre_scale=sc, pre_shift=sh, pre_rows=n)
+    ref = hip.gemm(xn.view(nb * n, C), w, bias)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two), f"max|d| {(one.float() - two.float()).abs().max().item()}"
+    d = (one.float() - ref.float()).abs()
+    frac = (d > 2.0 ** -8 * ref.float().abs() + 1e-3).float().mean().item()
+    assert d.max() <= 4 * 2.0 ** -8 * ref.float().abs().max() and frac < 1e-3
