@@ -50,6 +50,15 @@ def key_of(name, args, kw):
     if name == "layernorm":
         x = args[0]
         return f"layernorm rows={x.shape[0]} c={x.shape[1]} pe={int(kw.get('pe') is not None)}", 0
+    if name == "rowgemm320":
+        x, N = args[0], args[2]
+        n1 = kw.get("n1")
+        pro = "LN" if kw.get("ln_gamma") is not None else "GN" if kw.get("pre_scale") is not None else "-"
+        return (f"rowgemm320 M={x.shape[0]} N={N} ({pro} prologue{', V^T' if n1 not in (None, N) else ''}{', +res' if kw.get('residual') is not None else ''})",
+                2 * x.shape[0] * N * 320)
+    if name == "groupnorm_affine":
+        x = args[0]
+        return f"groupnorm_affine nb={x.shape[0]} hw={x.shape[1]} c={x.shape[2]} (statistics only)", 0
     if name == "ff_fused":
         x = args[0]
         inner = args[6] if len(args) > 6 else kw["inner"]
@@ -76,7 +85,7 @@ def main():
     if len(sys.argv) > 2:                                       # window length (the reference ships context_frames = 12)
         bench.FRAMES = int(sys.argv[2])
         bench.build_inputs.__defaults__ = (bench.FRAMES,) + bench.build_inputs.__defaults__[1:]
-    for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "ff_fused", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
+    for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "ff_fused", "rowgemm320", "groupnorm_affine", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
               "ncfhw_to_nhwc", "nhwc_to_ncfhw", "timestep_features", "silu", "cfg_ddim_step", "accumulate_window"]:
         wrap(n)
     sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
