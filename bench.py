@@ -172,6 +172,24 @@ def kernel_rooflines(unet, dev):
     fl = 2.0 * M * 2560 * 320
     out.append({"kernel": "gemm GEGLU ff1 M=196608 N=2560 K=320", "bound": "mfma", "ms": ms, "achieved": fl / ms / 1e9,
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS})
+    # the whole FeedForward of a level-0 block as the step runs it: LayerNorm -> ff1 -> GEGLU -> ff2 -> + residual, one launch (csrc/ffn.hip)
+    if (t + ".ff.ffimg") in unet.w:
+        img, b2 = unet.w[t + ".ff.ffimg"], unet.w[t + ".ff.ff2.bias"]
+        g3, b3 = unet.w[t + ".norm3.g"], unet.w[t + ".norm3.b"]
+        ms = _time_ms(lambda: hip.ff_fused(x, g3, b3, img, b2, x, 1280))
+        fl = 2.0 * M * 3 * 1280 * 320
+        out.append({"kernel": "ff_fused M=196608 C=320 inner=1280 (LayerNorm + ff1 + GEGLU + ff2 + residual)", "bound": "mfma", "ms": ms,
+                    "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS})
+    # LayerNorm -> q | k (row-major) + V^T of a level-0 self-attention, one launch (csrc/rowgemm.hip): x once in, 3 x 126 MB out
+    if (t + ".attn1.qkv_img") in unet.w:
+        img, g1, b1n = unet.w[t + ".attn1.qkv_img"], unet.w[t + ".norm1.g"], unet.w[t + ".norm1.b"]
+        vt_o = torch.empty((48, C, 4096), device=dev, dtype=dt)
+        qk_o = torch.empty((M, 2 * C), device=dev, dtype=dt)
+        ms = _time_ms(lambda: hip.rowgemm320(x, img, 3 * C, ln_gamma=g1, ln_beta=b1n, n1=2 * C, n_tok=4096, out=qk_o, out_t=vt_o))
+        by = 4.0 * M * C * 2
+        out.append({"kernel": "rowgemm320 M=196608 N=960 (LayerNorm + q|k + V^T)", "bound": "hbm", "ms": ms, "achieved": by / ms / 1e6,
+                    "peak": 8000.0, "unit": "GB/s", "frac": by / ms / 1e6 / 8000.0})
+        del vt_o, qk_o
     # spatial attention with bank (uncond half: 4096 keys, cond half: 8192 keys), hd 40
     n, heads, hd = 4096, 8, 40
     qk = hash_uniform("k.qk", (48 * n, 2 * C), 1.0, dev).to(dt)

@@ -89,6 +89,19 @@ def smooth_seams(tps_origin):
     return out
 
 
+def read_wav_16k(path):
+    """Mono float waveform of a 16-kHz PCM .wav (stdlib `wave`; the reference resamples with librosa, which this build does not
+    include: other rates are refused)."""
+    import wave
+    with wave.open(path, "rb") as w:
+        if w.getframerate() != 16000:
+            raise SystemExit(f"audio2vid: {path} is sampled at {w.getframerate()} Hz; resample to 16 kHz first (librosa is not part of this build)")
+        if w.getsampwidth() != 2:
+            raise SystemExit(f"audio2vid: {path} must be 16-bit PCM")
+        pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").reshape(-1, w.getnchannels())
+    return torch.from_numpy(pcm.astype(np.float32).mean(1) / 32768.0)
+
+
 def main():
     a = parse_args()
     if not a.synthetic:
@@ -155,7 +168,10 @@ def main():
     from mmgt_amd.wav2vec import Wav2VecModel, wav2vec_spec
     w2v = Wav2VecModel(device=dev, dtype=dtype)
     w2v.load_state_dict(synth_state_dict(wav2vec_spec(), prefix="w2v.", device=dev))
-    wave = hash_uniform("a2v.wave", (1, a.L * 16000 // (a.fps or 25)), 1.0)
+    if a.audio_path:      # a 16-kHz PCM .wav drives the Stage-2 audio conditioning (audio_processor.py:103-110 loads with librosa at 16 kHz)
+        wave = read_wav_16k(a.audio_path)[None, :a.L * 16000 // (a.fps or 25)]
+    else:
+        wave = hash_uniform("a2v.wave", (1, a.L * 16000 // (a.fps or 25)), 1.0)
     wave = ((wave - wave.mean()) / (wave.var(unbiased=False) + 1e-7).sqrt()).to(dev)                        # Wav2Vec2FeatureExtractor's normalisation
     feats = w2v.audio_emb(wave, a.L)                                                                        # (frames, 12 layers, 768)
     audio_tensor = audioproj(C.process_audio_emb_device(feats)[None])                                       # (1, L, 32, 768)
@@ -165,7 +181,10 @@ def main():
 
     # ---- 5. Stage 2 (:484-498) + output path
     from PIL import Image
-    ref_img = Image.fromarray(((hash_uniform("a2v.ref", (a.H, a.W, 3), 0.5) + 0.5) * 255).clamp(0, 255).to(torch.uint8).numpy())
+    if a.image_path:
+        ref_img = Image.open(a.image_path).convert("RGB")
+    else:
+        ref_img = Image.fromarray(((hash_uniform("a2v.ref", (a.H, a.W, 3), 0.5) + 0.5) * 255).clamp(0, 255).to(torch.uint8).numpy())
     t0 = time.time()
     out = pipe(ref_img, pose, audio_tensor.float(), full, face, lips, a.W, a.H, a.L, a.steps, a.cfg,
                generator=torch.manual_seed(a.seed), motion_scale=[1.0, 1.0, 2.0], context_frames=a.num_c, output_type="uint8")

@@ -4,11 +4,16 @@
     python scripts/pose2vid.py --synthetic -W 512 -H 512 -L 24 --steps 25         # BASELINE config 2 geometry
     python scripts/pose2vid.py --synthetic -W 64 -H 64 -L 8 --steps 4             # config 1 geometry
 
+    python scripts/pose2vid.py --image_path ref.png --pose_path pose_frames/ --face_mask_path face.npy --lips_mask_path lips.npy \
+        [--hands_mask_path hands/] -c configs/prompts/animation.yaml          # the reference's single-sample mode (:196-300)
+
 --synthetic: random-init weights of the reference architecture (no checkpoints ship with the reference) and synthetic
 pose / mask / audio inputs, everything a pure function of names (mmgt_amd/synthetic.py); prints the timing breakdown.
-Without --synthetic the reference's inputs are needed (config yaml paths, checkpoints, pose / mask videos); image and
-video decoding (cv2 / PyAV in the reference) is out of scope of this build, so that mode only covers the
-checkpoint-loading half and stops with a clear message at the first missing dependency.
+Without --synthetic the inputs are FILES, as in the reference (scripts/pose2vid.py:196-271): the reference image through PIL, the
+pose / mask clips as directories of images, .npy stacks or animated images (mmgt_amd/inputs.py: video containers need PyAV / cv2,
+which this build does not include, and say so), the masks blurred / resampled on the device (mmgt_amd/conditioning.py).  Weights
+come from the checkpoints the config yaml names (:137-190) -- or, with --random-weights, from the hash-seeded initialisation (no
+checkpoint exists in this image).  The clip is written as .gif / .npy (mp4 muxing is out of scope: mmgt_amd/video_out.py).
 """
 import argparse
 import json
@@ -41,6 +46,9 @@ def parse_args():
     p.add_argument("--steps", type=int, default=30)          # animation.yaml:28
     p.add_argument("--cfg", type=float, default=3.5)         # animation.yaml:29
     p.add_argument("--synthetic", action="store_true")
+    p.add_argument("--random-weights", action="store_true",
+                   help="file inputs with the hash-seeded random initialisation instead of the checkpoints of --config")
+    p.add_argument("--format", default="gif", choices=["gif", "npy"], help="output container of the file-input mode")
     p.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     p.add_argument("--no-decode", action="store_true")
     p.add_argument("--clip-parallel", action="store_true",
@@ -91,6 +99,78 @@ def build_synthetic_broadcast(dev, dtype, rank):
                               pose_guider=mods["pose"], scheduler=DDIMScheduler())
 
 
+def build_from_checkpoints(cfg_path, num_c, dev, dtype):
+    """scripts/pose2vid.py:137-197 of the reference: the modules from the checkpoints named by the config yaml."""
+    import yaml
+    from mmgt_amd.clip_vision import CLIPVisionModelWithProjection
+    from mmgt_amd.inputs import load_checkpoint, split_net_checkpoint
+    from mmgt_amd.pipeline import Pose2VideoPipeline
+    from mmgt_amd.reference_unet import UNet2DConditionModel
+    from mmgt_amd.scheduler import DDIMScheduler
+    from mmgt_amd.side_models import PoseGuider
+    from mmgt_amd.unet3d import UNet3DConditionModel
+    from mmgt_amd.vae import AutoencoderKL
+    if not os.path.isfile(cfg_path):
+        raise SystemExit(f"pose2vid: config {cfg_path} not found (it names the checkpoints: pretrained_vae_path, pretrained_base_model_path, "
+                         "image_encoder_path, audio_ckpt_dir, inference_config); pass --random-weights to run without checkpoints")
+    cfg = yaml.safe_load(open(cfg_path))
+    infer = yaml.safe_load(open(cfg["inference_config"]))
+    vae = AutoencoderKL(device=dev, dtype=dtype)
+    vae.load_state_dict(load_checkpoint(cfg["pretrained_vae_path"]))
+    refnet = UNet2DConditionModel(device=dev, dtype=dtype)
+    unet = UNet3DConditionModel.from_pretrained_2d(cfg["pretrained_base_model_path"], os.path.join(cfg["audio_ckpt_dir"], f"net-{num_c}.pth"),
+                                                   subfolder="unet", unet_additional_kwargs=infer["unet_additional_kwargs"], device=dev, dtype=dtype)
+    pg = PoseGuider(320, block_out_channels=(16, 32, 96, 256), device=dev, dtype=dtype)
+    clip = CLIPVisionModelWithProjection(device=dev, dtype=dtype)
+    clip.load_state_dict(load_checkpoint(cfg["image_encoder_path"]))
+    net = split_net_checkpoint(load_checkpoint(os.path.join(cfg["audio_ckpt_dir"], "modules", f"net-{num_c}.pth")))   # (:186-190)
+    refnet.load_state_dict(net["reference_unet"])
+    unet.load_state_dict(net["denoising_unet"], strict=False)
+    pg.load_state_dict(net["pose_guider"])
+    unet.enable_gradient_checkpointing()
+    return Pose2VideoPipeline(vae=vae, image_encoder=clip, reference_unet=refnet, denoising_unet=unet, pose_guider=pg,
+                              scheduler=DDIMScheduler(**infer.get("noise_scheduler_kwargs", {})))
+
+
+def run_files(a, dev, dtype):
+    """The reference's single-sample mode on files (:196-300)."""
+    from PIL import Image
+    from mmgt_amd import inputs
+    from mmgt_amd.video_out import save_videos_grid
+    for name in ("image_path", "pose_path", "face_mask_path", "lips_mask_path"):
+        if not getattr(a, name):
+            raise SystemExit(f"pose2vid: --{name} is required without --synthetic")
+    t0 = time.time()
+    pipe = build_synthetic(dev, dtype) if a.random_weights else build_from_checkpoints(a.config, a.num_c, dev, dtype)
+    t_build = time.time() - t0
+    ref_img = Image.open(a.image_path).convert("RGB")
+    pose_frames = inputs.read_frames(a.pose_path, a.L)
+    face_frames = inputs.read_frames(a.face_mask_path, a.L)
+    lips_frames = inputs.read_frames(a.lips_mask_path, a.L)
+    hands_frames = inputs.read_frames(a.hands_mask_path, a.L) if a.hands_mask_path and os.path.exists(a.hands_mask_path) else None
+    L = min(len(pose_frames), len(face_frames), len(lips_frames), len(hands_frames) if hands_frames else 10 ** 9, a.L)
+    if L < 1:
+        raise SystemExit("pose2vid: no usable frames (check the pose / mask inputs)")
+    if L < a.L:
+        print(f"note: {L} usable frames < L = {a.L}: sampling {L} frames")
+    pose = inputs.pose_tensor(pose_frames[:L], a.W, a.H)
+    full, face, lips = inputs.motion_masks(face_frames, lips_frames, hands_frames, L, dev, a.H)
+    audio = torch.zeros(1, L, 32, 768)                        # pose2vid runs with null audio (:279)
+    gen = torch.manual_seed(a.seed)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    out = pipe(ref_img, pose, audio, full, face, lips, a.W, a.H, L, a.steps, a.cfg, generator=gen, motion_scale=[1.0, 1.0, 2.0],
+               context_frames=a.num_c, output_type="uint8")
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    save_dir = os.path.join(a.out_dir, f"multi_person_{a.num_c}")
+    path = os.path.join(save_dir, f"{os.path.splitext(os.path.basename(a.image_path))[0]}.{a.format}")
+    save_videos_grid(out.videos, path, n_rows=1, fps=a.fps)
+    v = torch.as_tensor(out.videos)
+    print(json.dumps({"video": list(v.shape), "saved": path, "frames": L, "build_s": round(t_build, 2), "sample_s": round(dt, 3),
+                      "steps": a.steps, "weights": "random" if a.random_weights else a.config, "dtype": a.dtype}))
+
+
 def main():
     a = parse_args()
     if not torch.cuda.is_available():
@@ -105,8 +185,9 @@ def main():
         rank = dist.get_rank()
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     if not a.synthetic:
-        raise SystemExit("non-synthetic runs need the reference's checkpoints and PyAV/cv2 video decoding, which this "
-                         "build does not include; see INTEGRATION.md for wiring mmgt_amd into the reference's own script")
+        if a.clip_parallel or a.window_parallel:
+            raise SystemExit("pose2vid: --clip-parallel / --window-parallel run with --synthetic inputs")
+        return run_files(a, dev, dtype)
     from mmgt_amd.synthetic import hash_uniform, synth_masks
     t0 = time.time()
     # window-parallel: the same hash-seeded weights are built on every rank; clip-parallel: rank 0 broadcasts them

@@ -394,3 +394,49 @@ def test_full_mask_with_hands():
     face, lips, hands = [torch.rand(3, 16)], [torch.rand(3, 16)], [torch.rand(3, 16)]
     full = full_mask_with_hands(face, lips, hands)[0]
     assert torch.equal(full, (1 - face[0] + lips[0] + hands[0]).clamp(0, 1)) and full.min() >= 0 and full.max() <= 1
+
+
+def test_inputs_read_frames_and_checkpoints(tmp_path):
+    """mmgt_amd/inputs.py: clips from a directory of images / a .npy stack / an animated GIF, the video-container refusal, the pose tensor
+    (torchvision Resize + ToTensor semantics through PIL), checkpoint files and the reference's `Net` checkpoint split."""
+    import numpy as np
+    import pytest
+    from PIL import Image
+    from safetensors.torch import save_file
+    from mmgt_amd import inputs
+    rng = np.random.default_rng(1)
+    frames = rng.integers(0, 255, (5, 20, 24, 3), dtype=np.uint8)
+    os.makedirs(tmp_path / "d")
+    for i, f in enumerate(frames):
+        Image.fromarray(f).save(tmp_path / "d" / f"{i:03d}.png")
+    (tmp_path / "d" / "notes.txt").write_text("ignored")
+    got = inputs.read_frames(tmp_path / "d")
+    assert len(got) == 5 and all(np.array_equal(np.asarray(g), f) for g, f in zip(got, frames))
+    assert len(inputs.read_frames(tmp_path / "d", 3)) == 3
+    np.save(tmp_path / "s.npy", frames[..., 0])
+    got = inputs.read_frames(tmp_path / "s.npy")
+    assert len(got) == 5 and np.array_equal(np.asarray(got[2]), frames[2, ..., 0])
+    pil = [Image.fromarray(f[..., 0]) for f in frames]
+    pil[0].save(tmp_path / "a.gif", save_all=True, append_images=pil[1:])
+    assert len(inputs.read_frames(tmp_path / "a.gif")) == 5
+    (tmp_path / "v.mp4").write_bytes(b"x")
+    with pytest.raises(RuntimeError, match="needs a video decoder"):
+        inputs.read_frames(tmp_path / "v.mp4")
+    with pytest.raises(FileNotFoundError):
+        inputs.read_frames(tmp_path / "missing")
+    x = inputs.pose_tensor(got[:0] or [Image.fromarray(f) for f in frames], 24, 20)
+    assert x.shape == (1, 3, 5, 20, 24) and torch.equal(x[0, :, 1], torch.from_numpy(frames[1]).permute(2, 0, 1).float() / 255)
+    y = inputs.pose_tensor([Image.fromarray(frames[0])], 12, 10)
+    ref = torch.from_numpy(np.array(Image.fromarray(frames[0]).resize((12, 10), Image.BILINEAR))).permute(2, 0, 1).float() / 255
+    assert y.shape == (1, 3, 1, 10, 12) and torch.equal(y[0, :, 0], ref)
+    sd = {"pose_guider.conv_in.weight": torch.ones(2, 3), "denoising_unet.conv_in.bias": torch.zeros(4), "audioproj.norm.weight": torch.ones(3)}
+    save_file(sd, str(tmp_path / "net.safetensors"))
+    torch.save(sd, tmp_path / "net.pth")
+    for name in ("net.safetensors", "net.pth"):
+        parts = inputs.split_net_checkpoint(inputs.load_checkpoint(tmp_path / name))
+        assert set(parts["pose_guider"]) == {"conv_in.weight"} and set(parts["denoising_unet"]) == {"conv_in.bias"} and not parts["reference_unet"]
+    os.makedirs(tmp_path / "unet")
+    save_file({"w": torch.ones(1)}, str(tmp_path / "unet" / "diffusion_pytorch_model.safetensors"))
+    assert set(inputs.load_checkpoint(tmp_path / "unet")) == {"w"}
+    with pytest.raises(RuntimeError, match="unexpected key"):
+        inputs.split_net_checkpoint({"vae.x": torch.ones(1)})
