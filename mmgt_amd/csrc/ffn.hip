@@ -427,24 +427,34 @@ void ff_fused1_kernel(const bf16_t* __restrict__ x, long ldx, const float* __res
   };
 #define FF_IC(v) integral_constant<int, (v)>{}
 
-  // ---- the wave's 32 rows as ff1 B fragments: lane (r, hh) holds channels 16 ks + 8 hh .. + 7 of row r
+  // ---- prologue: everything the workgroup needs from memory is requested up front, in ONE latency -- the first two ff1 weight
+  // blocks (LDS-DMA), the wave's 32 rows, gamma | beta | bias2 and the ff1 biases of all sub-blocks (into registers) -- and only then
+  // used (hipcc waits vmcnt(0) at the first use of a plain load while an LDS-DMA is in flight: exactly what is wanted here; rows ->
+  // tables (a load-store loop) -> barrier -> DMA paid the memory latency several times in a row).
+  for_range(FF_IC(0), FF_IC(FF_P1), [&](auto i) { issue1(0, i); });
+  for_range(FF_IC(0), FF_IC(FF_P1), [&](auto i) { issue1(1, i); });
+  // the wave's 32 rows as ff1 B fragments: lane (r, hh) holds channels 16 ks + 8 hh .. + 7 of row r
   s16x8 xf[FF_KS];
   {
     const bf16_t* xr = x + rowc * ldx + 8 * hh;
 #pragma unroll
     for (int ks = 0; ks < FF_KS; ++ks) xf[ks] = *reinterpret_cast<const s16x8*>(xr + 16 * ks);
-    // gamma | beta | bias2 and the ff1 biases go through LDS: with an LDS-DMA in flight hipcc waits vmcnt(0) for every plain global
-    // load, so the weight DMA starts only behind these loads
     float* lgb = reinterpret_cast<float*>(smem + FF_LG);
-    if (tid < 3 * FFC / 4 && (gamma || tid >= 2 * FFC / 4)) {   // 3 x 80 vectors
-      const float* src = tid < FFC / 4 ? gamma + 4 * tid : tid < 2 * FFC / 4 ? beta + 4 * (tid - FFC / 4) : bias2 + 4 * (tid - 2 * FFC / 4);
-      *reinterpret_cast<f32x4*>(lgb + 4 * tid) = *reinterpret_cast<const f32x4*>(src);
+    const bool has_tab = tid < 3 * FFC / 4 && (gamma || tid >= 2 * FFC / 4);     // 3 x 80 vectors
+    f32x4 tv = (f32x4)(0.f), bv[FF_MAXSB * 16 / 256];
+    if (has_tab) tv = *reinterpret_cast<const f32x4*>(tid < FFC / 4 ? gamma + 4 * tid : tid < 2 * FFC / 4 ? beta + 4 * (tid - FFC / 4) : bias2 + 4 * (tid - 2 * FFC / 4));
+#pragma unroll
+    for (int i = 0; i < FF_MAXSB * 16 / 256; ++i) {              // 16 vectors of 4 ff1 biases per sub-block, from the image
+      const int v = tid + 256 * i;
+      if (v < nsb * 16) bv[i] = *reinterpret_cast<const f32x4*>(wimg + (long)(v >> 4) * FF_IMG + FF_B1 + (v & 15) * 16);
     }
-    for (int v = tid; v < nsb * 16; v += 256)                    // 16 vectors of 4 biases per sub-block, from the image
-      *reinterpret_cast<f32x4*>(smem + FF_LB + v * 16) = *reinterpret_cast<const f32x4*>(wimg + (long)(v >> 4) * FF_IMG + FF_B1 + (v & 15) * 16);
+    if (has_tab) *reinterpret_cast<f32x4*>(lgb + 4 * tid) = tv;
+#pragma unroll
+    for (int i = 0; i < FF_MAXSB * 16 / 256; ++i) {
+      const int v = tid + 256 * i;
+      if (v < nsb * 16) *reinterpret_cast<f32x4*>(smem + FF_LB + v * 16) = bv[i];
+    }
     __syncthreads();
-    for_range(FF_IC(0), FF_IC(FF_P1), [&](auto i) { issue1(0, i); });
-    for_range(FF_IC(0), FF_IC(FF_P1), [&](auto i) { issue1(1, i); });
     if (gamma) layernorm_fragments(xf, reinterpret_cast<const float*>(smem + FF_LG), hh, eps);
   }
   f32x16 oacc[FF_NU];

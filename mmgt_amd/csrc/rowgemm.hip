@@ -80,28 +80,48 @@ void rowgemm320_kernel(const RowGemmArgs a) {
     });
   };
 
-  // ---- the wave's 32 rows as MFMA fragments: lane (r, hh) holds channels 16 ks + 8 hh .. + 7 of row r
+  // ---- prologue.  Everything the workgroup needs from memory is requested up front, in ONE latency: the first three weight tiles
+  // (LDS-DMA), the wave's 32 rows, the norm tables and the bias vectors (into registers), and only then is anything used.  (hipcc
+  // waits vmcnt(0) at the first use of a plain load while an LDS-DMA is in flight, which is exactly what is wanted here; the order
+  // rows -> tables (a load-use-store loop) -> barrier -> DMA paid the HBM latency three to five times in a row: stamps, 31 000 cycles
+  // in front of the first MFMA.)
+  dma_tile(0, 0);
+  dma_tile(1, R_TILE);
+  dma_tile(2, 2 * R_TILE);
+  // the wave's 32 rows as MFMA fragments: lane (r, hh) holds channels 16 ks + 8 hh .. + 7 of row r
   s16x8 xf[R_KS];
   {
     const bf16_t* xr = a.x + rowc * a.ldx + 8 * hh;
 #pragma unroll
     for (int ks = 0; ks < R_KS; ++ks) xf[ks] = *reinterpret_cast<const s16x8*>(xr + 16 * ks);
-    // tables -> LDS before the first LDS-DMA (with one in flight hipcc waits vmcnt(0) for every plain global load)
     float* lgb = reinterpret_cast<float*>(smem + R_LG);
     float* lb = reinterpret_cast<float*>(smem + R_LB);
-    if (a.norm && tid < 2 * RC / 4) {
+    f32x4 tn = (f32x4)(0.f), tb[2] = {(f32x4)(0.f), (f32x4)(0.f)}, tb2[2] = {(f32x4)(0.f), (f32x4)(0.f)};
+    const bool has_norm = a.norm && tid < 2 * RC / 4;
+    if (has_norm) {
       const long grp = a.pe_mod > 1 ? (long)(((unsigned)row0 / (unsigned)a.pe_div) % (unsigned)a.pe_mod) * RC : 0;
       const float* beta = a.beta + grp;
       const float* gamma = a.gamma + (a.norm == 2 ? grp : 0);
-      const float* src = tid < RC / 4 ? gamma + 4 * tid : beta + 4 * (tid - RC / 4);
-      *reinterpret_cast<f32x4*>(lgb + 4 * tid) = *reinterpret_cast<const f32x4*>(src);
+      tn = *reinterpret_cast<const f32x4*>(tid < RC / 4 ? gamma + 4 * tid : beta + 4 * (tid - RC / 4));
     }
     const float* b2 = a.bias2 ? a.bias2 + (long)((unsigned)row0 / (unsigned)a.bias2_rows) * a.N : nullptr;
-    for (int c = tid; c < a.N; c += 256) lb[c] = (a.bias ? a.bias[c] : 0.f) + (b2 ? b2[c] : 0.f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {            // N <= 1920: at most two vectors of four columns per thread
+      const int c = 4 * (tid + 256 * i);
+      if (c < a.N) {
+        if (a.bias) tb[i] = *reinterpret_cast<const f32x4*>(a.bias + c);
+        if (b2) tb2[i] = *reinterpret_cast<const f32x4*>(b2 + c);
+      }
+    }
+    if (DBG == 5) { stamp(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(); }
+    if (has_norm) *reinterpret_cast<f32x4*>(lgb + 4 * tid) = tn;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = 4 * (tid + 256 * i);
+      if (c < a.N) *reinterpret_cast<f32x4*>(lb + c) = tb[i] + tb2[i];
+    }
     __syncthreads();
-    dma_tile(0, 0);
-    dma_tile(1, R_TILE);
-    dma_tile(2, 2 * R_TILE);
+    if (DBG == 5) stamp();
     if (a.norm == 1) layernorm_fragments<R_KS, true>(xf, lgb, hh, a.eps);
     else if (a.norm == 2) layernorm_fragments<R_KS, false>(xf, lgb, hh, a.eps);
   }
@@ -254,7 +274,7 @@ extern "C" int mmgt_rowgemm320(const void* x, long ldx, int norm, const float* l
   MMGT_CHECK(n1 == N || (out_t && n_tok > 0 && n_tok % 128 == 0 && M % n_tok == 0 && npad >= n_tok && npad % 8 == 0),
              "rowgemm320: transposed output needs n_tok %% 128 == 0, M %% n_tok == 0, npad >= n_tok, npad %% 8 == 0 (n_tok %d, npad %d)", n_tok, npad);
   MMGT_CHECK(!residual || (n1 == N && ldr >= N && ldr % 8 == 0), "rowgemm320: a residual needs normal tiles only and ldr >= N, ldr %% 8 == 0");
-  MMGT_CHECK((((uintptr_t)x | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)out_t | (uintptr_t)wimg) & 15) == 0 &&
+  MMGT_CHECK((((uintptr_t)x | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)out_t | (uintptr_t)wimg | (uintptr_t)bias | (uintptr_t)bias2) & 15) == 0 &&
                  (!ln_gamma || (((uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) == 0),
              "rowgemm320: pointers must be 16-byte aligned");
   RowGemmArgs a;

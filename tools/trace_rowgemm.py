@@ -37,7 +37,7 @@ def main():
     d = (t[:, 1:n] - t[:, :n - 1]).float()
     tot = (t[:, n - 1] - t[:, 0]).float()
     print(f"N={N} ln={ln}: {n} stamps; whole wave: median {tot.median().item():.0f} ticks (min {tot.min().item():.0f}, max {tot.max().item():.0f})")
-    names = ["rows loaded, tables, LayerNorm", "tile 0 landed + barrier"] + [f"tiles {2 * i}, {2 * i + 1}" for i in range(n)]
+    names = ["start -> all requests issued", "requests landed (vmcnt 0)", "tables to LDS + barrier", "LayerNorm", "tile 0 wait + barrier"] + [f"tiles {2 * i}, {2 * i + 1}" for i in range(n)]
     for i in range(n - 1):
         col = d[:, i]
         print(f"  {names[i]:34s} median {col.median().item():8.0f}  p10 {col.quantile(0.1).item():8.0f}  p90 {col.quantile(0.9).item():8.0f}")
