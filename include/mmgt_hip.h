@@ -143,6 +143,14 @@ int mmgt_ff_fused_image_bytes(int C, int inner);
 int mmgt_ff_fused(const void* x, long ldx, const float* ln_gamma, const float* ln_beta, float eps, const void* wimg,
                   const float* bias2, const void* residual, long ldr, void* out, long ldo, int M, int C, int inner, int dtype,
                   void* stream);
+/* ... and the block's proj_out on the end of the same launch:
+ *   hidden = bf16(residual + bias2 + FeedForward(LN(x)))  (never stored),   out[m] = residual2[m] + bias_po + Wpo . hidden[m]
+ * wpo: mmgt_amd/packing.py: pack_ff_proj_out(proj_out.weight (320, 320)), 204 800 bytes.
+ * Replaces additionally: `hidden_states = self.proj_out(hidden_states)` + `output = hidden_states + residual` of
+ * src/models/transformer_3d.py:262-268 and src/models/motion_module.py:178-182. */
+int mmgt_ff_fused_po(const void* x, long ldx, const float* ln_gamma, const float* ln_beta, float eps, const void* wimg,
+                     const float* bias2, const void* residual, long ldr, const void* wpo, const float* bias_po, const void* residual2,
+                     long ldr2, void* out, long ldo, int M, int C, int inner, int dtype, void* stream);
 
 /* [LayerNorm | GroupNorm ->] Linear(s) of the 320-channel level with the rows stationary in registers (csrc/rowgemm.hip), bf16:
  *   y[m, :] = [norm](x[m, :]) . W^T + bias [+ bias2[m / bias2_rows]] [+ residual[m, :]],   K = 320, N % 32 == 0, N <= 1920

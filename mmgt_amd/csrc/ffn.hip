@@ -385,11 +385,16 @@ constexpr int ff_ms_first(int slot) {     // first micro-step of MFMA slot `slot
 }
 static_assert(ff_ms_first(0) == 0 && ff_ms_first(FF_SLOTS) == 8 * FF_MS, "micro-step schedule");
 
-template <int DBG, bool TRACE>
+// PO: the transformer block's proj_out rides on the end -- out = res2 + bias_po + Wpo . bf16(hidden), hidden = res + b2 + FeedForward(...)
+// as before but never stored: packed to bf16 it IS the B operand of the proj_out MFMAs (the accumulator registers' k order, matched by
+// the weight image of packing.pack_ff_proj_out), whose 10 x 20 KiB weight tiles stream through the ff1 ring, two tiles (two
+// independent accumulation chains) at a time; the 160 output registers are reused for the second GEMM.
+template <int DBG, bool TRACE, bool PO>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void ff_fused1_kernel(const bf16_t* __restrict__ x, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
                       float eps, const char* __restrict__ wimg, int nsb, const float* __restrict__ bias2,
-                      const bf16_t* __restrict__ res, long ldr, bf16_t* __restrict__ out, long ldo, int M, unsigned long long* trace) {
+                      const bf16_t* __restrict__ res, long ldr, bf16_t* __restrict__ out, long ldo, int M, unsigned long long* trace,
+                      const char* __restrict__ wpo, const float* __restrict__ bias_po, const bf16_t* __restrict__ res2, long ldr2) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
@@ -407,16 +412,16 @@ void ff_fused1_kernel(const bf16_t* __restrict__ x, long ldx, const float* __res
   // This wave's share of W1(sb) is the 10 contiguous 1-KiB pieces 10 wid .. 10 wid + 9 of the ff1 part, of W2(sb) the 5 pieces 5 wid ..
   // 5 wid + 4 of the ff2 part.  Sub-blocks beyond the image are "loaded" too, with the poison offset (the range check returns zeros,
   // nothing is fetched): every iteration issues the same number of pieces and the counted waits are compile-time constants.
-  auto piece = [&](auto Ic, unsigned voff, int src, char* dst) {     // piece i of a run: group i / 4 (one M0 / soffset), instruction offset 1024 (i % 4)
+  auto piece = [&](auto Ic, unsigned voff, int src, char* dst, const __amdgpu_buffer_rsrc_t rs) {     // piece i of a run: group i / 4 (one M0 / soffset), instruction offset 1024 (i % 4)
     constexpr int i = decltype(Ic)::value;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + (i / 4) * 4096), 16, (int)voff,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + (i / 4) * 4096), 16, (int)voff,
                                              src + (i / 4) * 4096, (i % 4) * 1024, 0);
   };
   auto issue1 = [&](int sb, auto Ic) {
-    piece(Ic, (DBG != 1 && sb < nsb) ? lane16 : DMA_POISON, sb * FF_IMG + wid * (FF_P1 * 1024), smem + FF_L1 + (sb & 1) * FF_W1 + wid * (FF_P1 * 1024));
+    piece(Ic, (DBG != 1 && sb < nsb) ? lane16 : DMA_POISON, sb * FF_IMG + wid * (FF_P1 * 1024), smem + FF_L1 + (sb & 1) * FF_W1 + wid * (FF_P1 * 1024), rw);
   };
   auto issue2 = [&](int sb, auto Ic) {
-    piece(Ic, (DBG != 1 && sb < nsb) ? lane16 : DMA_POISON, sb * FF_IMG + FF_W1 + wid * (FF_P2 * 1024), smem + FF_L2 + (sb & 1) * FF_W2 + wid * (FF_P2 * 1024));
+    piece(Ic, (DBG != 1 && sb < nsb) ? lane16 : DMA_POISON, sb * FF_IMG + FF_W1 + wid * (FF_P2 * 1024), smem + FF_L2 + (sb & 1) * FF_W2 + wid * (FF_P2 * 1024), rw);
   };
   using std::integral_constant;
   constexpr integral_constant<bool, true> T{};
@@ -448,7 +453,10 @@ void ff_fused1_kernel(const bf16_t* __restrict__ x, long ldx, const float* __res
       const int v = tid + 256 * i;
       if (v < nsb * 16) bv[i] = *reinterpret_cast<const f32x4*>(wimg + (long)(v >> 4) * FF_IMG + FF_B1 + (v & 15) * 16);
     }
+    f32x4 pv = (f32x4)(0.f);
+    if (PO && tid < FFC / 4) pv = *reinterpret_cast<const f32x4*>(bias_po + 4 * tid);
     if (has_tab) *reinterpret_cast<f32x4*>(lgb + 4 * tid) = tv;
+    if (PO && tid < FFC / 4) *reinterpret_cast<f32x4*>(smem + FF_LGT + 16 * tid) = pv;      // (the G slots of the two-role kernel: unused here)
 #pragma unroll
     for (int i = 0; i < FF_MAXSB * 16 / 256; ++i) {
       const int v = tid + 256 * i;
@@ -613,8 +621,17 @@ void ff_fused1_kernel(const bf16_t* __restrict__ x, long ldx, const float* __res
     if (j < 6) stamp();
     phaseB(j, T, T, T, T, gbp, hn, gn, gbn);
   };
+  // proj_out weights: tile pair p (tiles 2 p, 2 p + 1, 40 KiB) -> half p & 1 of the ff1 ring; this wave's 10 contiguous pieces
+  const __amdgpu_buffer_rsrc_t rpo = dma_rsrc(PO ? wpo : wimg);
+  auto issue_po = [&](int pr, auto Ic) {
+    piece(Ic, (DBG != 1 && pr < FF_NU / 2) ? lane16 : DMA_POISON, pr * FF_W1 + wid * (FF_P1 * 1024), smem + FF_L1 + (pr & 1) * FF_W1 + wid * (FF_P1 * 1024), rpo);
+  };
   auto last_iteration = [&](int j, f32x16& hp, f32x16& gp, u32x4 (&gbp)[2]) {
     hand_over(FF_IC(0));
+    if constexpr (PO) {     // the ff1 ring is idle from here on (every wave is through ff1 of the last sub-block): proj_out tile pairs 0 and 1
+      for_range(FF_IC(0), FF_IC(FF_P1), [&](auto i) { issue_po(0, i); });
+      for_range(FF_IC(0), FF_IC(FF_P1), [&](auto i) { issue_po(1, i); });
+    }
     read_b(j, FF_IC(0));
     phaseA(j + 1, F, T, F, F, hp, gp, hp, gp, gbp);
     phaseB(j, T, F, F, F, gbp, hp, gp, gbp);
@@ -631,15 +648,90 @@ void ff_fused1_kernel(const bf16_t* __restrict__ x, long ldx, const float* __res
     last_iteration(j, hA, gA, gbA);
   }
   stamp();
+  if constexpr (PO) {
+    // ---- hidden = FeedForward + b2 + residual in the ACCUMULATOR layout, packed to bf16: the B fragments of proj_out.  A residual
+    // vector holds channels c .. c + 7 (lane hh = 0) / c + 8 .. c + 15 (hh = 1) of c = 32 u + 16 (k / 2); the registers 4 k .. 4 k + 3 and
+    // 4 k + 4 .. 4 k + 7 of the tile want c + 4 hh + (0..3) and c + 8 + 4 hh + (0..3): v_permlane32_swap of the vector's first half
+    // with its second half (two packed dwords each) is exactly that exchange (the inverse of the store epilogue's).
+    s16x8 hf[2 * FF_NU];
+    {
+      const bf16_t* rr = res + rowc * ldr + 8 * hh;
+      u32x4 rv[2 * FF_NU];
+#pragma unroll
+      for (int i = 0; i < 2 * FF_NU; ++i) rv[i] = *reinterpret_cast<const u32x4*>(rr + 16 * i);
+      const float* lb2a = reinterpret_cast<const float*>(smem + FF_LG) + 2 * FFC + 4 * hh;
+#pragma unroll
+      for (int u = 0; u < FF_NU; ++u) {
+        float hv[16];
+#pragma unroll
+        for (int k = 0; k < 4; k += 2) {
+          const u32x4 r4 = rv[2 * u + k / 2];
+          const auto s0 = __builtin_amdgcn_permlane32_swap(r4[0], r4[2], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(r4[1], r4[3], false, false);
+          const unsigned lo[2] = {s0[0], s1[0]}, hi[2] = {s0[1], s1[1]};      // packed residual of registers 4 k .. 4 k + 3 / 4 k + 4 .. 4 k + 7
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(lb2a + 32 * u + 8 * k), b1 = *reinterpret_cast<const f32x4*>(lb2a + 32 * u + 8 * k + 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned wl = lo[e >> 1], wh = hi[e >> 1];
+            const float rl = __uint_as_float((e & 1) ? (wl & 0xffff0000u) : (wl << 16)), rh = __uint_as_float((e & 1) ? (wh & 0xffff0000u) : (wh << 16));
+            hv[4 * k + e] = oacc[u][4 * k + e] + b0[e] + rl;
+            hv[4 * k + 4 + e] = oacc[u][4 * k + 4 + e] + b1[e] + rh;
+          }
+        }
+#pragma unroll
+        for (int sx = 0; sx < 2; ++sx) {
+          float v8[8];
+#pragma unroll
+          for (int jx = 0; jx < 8; ++jx) v8[jx] = hv[8 * sx + jx];
+          hf[2 * u + sx] = pack8(v8);
+        }
+      }
+    }
+    // ---- proj_out: tile pair p = output channels 64 p .. 64 p + 63, 2 x 20 MFMAs into oacc[2 p], oacc[2 p + 1]
+    s16x8 fp[2][4];                          // fragment ring: [group parity][tile of the pair x k-step of the group]
+    for_range(FF_IC(0), FF_IC(FF_NU / 2), [&](auto pc) {
+      constexpr int pr = decltype(pc)::value;
+      const char* sp = smem + FF_L1 + (pr & 1) * FF_W1 + lane * 16;
+      if constexpr (pr + 1 < FF_NU / 2) wait_vmcnt<FF_P1>(); else wait_vmcnt<0>();     // pair pr has landed (pair pr + 1 may be in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      auto read_p = [&](auto Gc) {           // group g: k-steps 2 g, 2 g + 1 of both tiles
+        constexpr int g = decltype(Gc)::value;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fp[g & 1][q] = *reinterpret_cast<const s16x8*>(sp + (q >> 1) * (FF_KS * 1024) + (2 * g + (q & 1)) * 1024);
+      };
+      read_p(FF_IC(0));
+      for_range(FF_IC(0), FF_IC(FF_KS / 2), [&](auto gcx) {
+        constexpr int g = decltype(gcx)::value;
+        if constexpr (g + 1 < FF_KS / 2) { read_p(FF_IC(g + 1)); __builtin_amdgcn_s_waitcnt(0xC07F | (4 << 8)); }
+        else __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        if (DBG != 2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {      // order (tile 0, k0) (tile 1, k0) (tile 0, k1) (tile 1, k1)
+            const int t = q & 1, kk = q >> 1;
+            const f32x16 cin = (g == 0 && kk == 0) ? (f32x16)(0.f) : oacc[2 * pr + t];
+            oacc[2 * pr + t] = mma32b(fp[g & 1][2 * t + kk], hf[2 * g + kk], cin);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if constexpr (pr + 2 < FF_NU / 2) {    // every wave is through pair pr: its half of the ring takes pair pr + 2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for_range(FF_IC(0), FF_IC(FF_P1), [&](auto i) { issue_po(pr + 2, i); });
+      }
+    });
+  }
   // ---- epilogue (as the two-role kernel's): + b2 + residual, bf16, 16-byte stores through a buffer resource sized to the M valid rows
   {
-    const bf16_t* rr = res + rowc * ldr + 8 * hh;
+    const bf16_t* rr = PO ? res2 + rowc * ldr2 + 8 * hh : res + rowc * ldr + 8 * hh;
     u32x4 rv[2 * FF_NU];
 #pragma unroll
     for (int i = 0; i < 2 * FF_NU; ++i) rv[i] = *reinterpret_cast<const u32x4*>(rr + 16 * i);   // channels 16 i + 8 hh .. + 7
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((long)M * ldo * 2), 0x00020000);
     const unsigned obase = (unsigned)(row * ldo + 8 * hh) * 2u;          // (rows >= M: beyond num_records -> dropped)
-    const float* lb2 = reinterpret_cast<const float*>(smem + FF_LG) + 2 * FFC + 8 * hh;
+    const float* lb2 = (PO ? reinterpret_cast<const float*>(smem + FF_LGT) : reinterpret_cast<const float*>(smem + FF_LG) + 2 * FFC) + 8 * hh;
 #pragma unroll
     for (int u = 0; u < FF_NU; ++u)
 #pragma unroll
@@ -678,9 +770,11 @@ extern "C" int mmgt_ff_fused_image_bytes(int C, int inner) {
   return (inner / 32) * FF_IMG;
 }
 
-extern "C" int mmgt_ff_fused(const void* x, long ldx, const float* ln_gamma, const float* ln_beta, float eps, const void* wimg,
-                             const float* bias2, const void* residual, long ldr, void* out, long ldo, int M, int C, int inner,
-                             int dtype, void* stream) {
+namespace {
+// shared launcher: wpo == NULL: the FeedForward alone; else + proj_out (single-role kernel only)
+int ff_fused_launch(const void* x, long ldx, const float* ln_gamma, const float* ln_beta, float eps, const void* wimg, const float* bias2,
+                    const void* residual, long ldr, void* out, long ldo, int M, int C, int inner, int dtype, void* stream,
+                    const void* wpo, const float* bias_po, const void* res2, long ldr2) {
   MMGT_CHECK(x && wimg && bias2 && residual && out, "ff_fused: null pointer");
   MMGT_CHECK(dtype == MMGT_BF16, "ff_fused: bf16 only (the fp32-I/O mode runs LayerNorm / GEMM / GEMM)");
   MMGT_CHECK(mmgt_ff_fused_image_bytes(C, inner) > 0, "ff_fused: built for %d channels (got %d) and inner = 64 .. %d in steps of 32 (got %d)",
@@ -691,24 +785,53 @@ extern "C" int mmgt_ff_fused(const void* x, long ldx, const float* ln_gamma, con
   MMGT_CHECK((((uintptr_t)x | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)wimg | (uintptr_t)bias2) & 15) == 0 &&
                  (!ln_gamma || (((uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) == 0),
              "ff_fused: pointers must be 16-byte aligned");
+  MMGT_CHECK(!wpo || (bias_po && res2 && ldr2 >= C && ldr2 % 8 == 0 && (((uintptr_t)wpo | (uintptr_t)bias_po | (uintptr_t)res2) & 15) == 0),
+             "ff_fused_po: proj_out needs its bias, its residual (row stride >= %d, %% 8 == 0) and 16-byte aligned pointers", C);
   const size_t lds = FF_LB + (size_t)(inner / 32) * 256;
-  const bool one = g_ffn_ver == 4;
-  auto kern = one ? (g_ffn_dbg == 1 ? ff_fused1_kernel<1, false> : g_ffn_dbg == 2 ? ff_fused1_kernel<2, false>
-                     : g_ffn_trace ? ff_fused1_kernel<0, true> : ff_fused1_kernel<0, false>)
-                  : (g_ffn_dbg == 1 ? ff_fused_kernel<1> : g_ffn_dbg == 2 ? ff_fused_kernel<2> : g_ffn_dbg == 3 ? ff_fused_kernel<3>
-                     : g_ffn_dbg == 4 ? ff_fused_kernel<4> : ff_fused_kernel<0>);
-  static bool attr[2][6] = {};
-  const int ai = one && g_ffn_trace ? 5 : g_ffn_dbg;
-  if (!attr[one][ai]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, FF_LB + FF_MAXSB * 256) != hipSuccess) {
-      mmgt_set_error("ff_fused: cannot reserve %d bytes of LDS", FF_LB + FF_MAXSB * 256);
-      return 2;
-    }
-    attr[one][ai] = true;
-  }
   const unsigned grid = (unsigned)((M + 127) / 128);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(one ? 256 : 512), lds, (hipStream_t)stream, (const bf16_t*)x, ldx, ln_gamma, ln_beta, eps,
-                     (const char*)wimg, inner / 32, bias2, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, M, g_ffn_trace);
+  auto reserve = [](const void* k, bool& done) {
+    if (done) return true;
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, FF_LB + FF_MAXSB * 256) != hipSuccess) {
+      mmgt_set_error("ff_fused: cannot reserve %d bytes of LDS", FF_LB + FF_MAXSB * 256);
+      return false;
+    }
+    return done = true;
+  };
+  if (g_ffn_ver == 4 || wpo) {
+    auto kern = wpo ? (g_ffn_dbg == 1 ? ff_fused1_kernel<1, false, true> : g_ffn_dbg == 2 ? ff_fused1_kernel<2, false, true>
+                       : g_ffn_trace ? ff_fused1_kernel<0, true, true> : ff_fused1_kernel<0, false, true>)
+                    : (g_ffn_dbg == 1 ? ff_fused1_kernel<1, false, false> : g_ffn_dbg == 2 ? ff_fused1_kernel<2, false, false>
+                       : g_ffn_trace ? ff_fused1_kernel<0, true, false> : ff_fused1_kernel<0, false, false>);
+    static bool attr[2][4] = {};
+    const int ai = g_ffn_dbg == 1 ? 1 : g_ffn_dbg == 2 ? 2 : g_ffn_trace ? 3 : 0;
+    if (!reserve(reinterpret_cast<const void*>(kern), attr[wpo != nullptr][ai])) return 2;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x, ldx, ln_gamma, ln_beta, eps,
+                       (const char*)wimg, inner / 32, bias2, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, M, g_ffn_trace,
+                       (const char*)wpo, bias_po, (const bf16_t*)res2, ldr2);
+  } else {
+    auto kern = g_ffn_dbg == 1 ? ff_fused_kernel<1> : g_ffn_dbg == 2 ? ff_fused_kernel<2> : g_ffn_dbg == 3 ? ff_fused_kernel<3>
+                : g_ffn_dbg == 4 ? ff_fused_kernel<4> : ff_fused_kernel<0>;
+    static bool attr[5] = {};
+    if (!reserve(reinterpret_cast<const void*>(kern), attr[g_ffn_dbg])) return 2;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)x, ldx, ln_gamma, ln_beta, eps,
+                       (const char*)wimg, inner / 32, bias2, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, M, g_ffn_trace);
+  }
   MMGT_LAUNCH_CHECK();
   return 0;
+}
+}  // namespace
+
+extern "C" int mmgt_ff_fused(const void* x, long ldx, const float* ln_gamma, const float* ln_beta, float eps, const void* wimg,
+                             const float* bias2, const void* residual, long ldr, void* out, long ldo, int M, int C, int inner,
+                             int dtype, void* stream) {
+  return ff_fused_launch(x, ldx, ln_gamma, ln_beta, eps, wimg, bias2, residual, ldr, out, ldo, M, C, inner, dtype, stream, nullptr, nullptr,
+                         nullptr, 0);
+}
+
+extern "C" int mmgt_ff_fused_po(const void* x, long ldx, const float* ln_gamma, const float* ln_beta, float eps, const void* wimg,
+                                const float* bias2, const void* residual, long ldr, const void* wpo, const float* bias_po,
+                                const void* residual2, long ldr2, void* out, long ldo, int M, int C, int inner, int dtype, void* stream) {
+  MMGT_CHECK(wpo, "ff_fused_po: null proj_out image");
+  return ff_fused_launch(x, ldx, ln_gamma, ln_beta, eps, wimg, bias2, residual, ldr, out, ldo, M, C, inner, dtype, stream, wpo, bias_po,
+                         residual2, ldr2);
 }

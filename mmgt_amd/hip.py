@@ -49,6 +49,8 @@ _SIGS = {
                               c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_rowgemm320_image_bytes": (c_long, [c_int]),
     "mmgt_rowgemm_set_trace": (None, [c_void_p]),
+    "mmgt_ff_fused_po": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p,
+                                 c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_groupnorm_affine": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int,
                                       c_void_p]),
     "mmgt_rowgemm320": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
@@ -342,6 +344,25 @@ def ff_fused(x, ln_gamma, ln_beta, wimg, bias2, residual, inner, eps=1e-5, out=N
     _check(lib().mmgt_ff_fused(_ptr(x), x.stride(0), _ptr(_f32(ln_gamma, "ln_gamma")), _ptr(_f32(ln_beta, "ln_beta")), eps, _ptr(wimg),
                                _ptr(_f32(bias2, "bias2")), _ptr(residual), residual.stride(0), _ptr(out), out.stride(0), M, C, inner,
                                dtype_code(x.dtype), _stream()), "mmgt_ff_fused")
+    return out
+
+
+def ff_fused_po(x, ln_gamma, ln_beta, wimg, bias2, residual, inner, wpo, bias_po, residual2, eps=1e-5, out=None):
+    """`ff_fused` with the transformer block's proj_out on the end of the same launch: out = residual2 + bias_po + Wpo . hidden,
+    hidden = bf16(residual + bias2 + FeedForward(LN(x))) never stored (wpo = packing.pack_ff_proj_out(proj_out.weight))."""
+    _dev(x, ln_gamma, ln_beta, wimg, bias2, residual, wpo, bias_po, residual2)
+    assert x.dim() == 2 and x.stride(1) == 1 and residual.shape == x.shape and residual.stride(1) == 1 and residual.dtype == x.dtype
+    assert residual2.shape == x.shape and residual2.stride(1) == 1 and residual2.dtype == x.dtype
+    M, C = x.shape
+    assert wimg.dtype == torch.uint8 and wimg.is_contiguous() and wimg.numel() == lib().mmgt_ff_fused_image_bytes(C, inner)
+    assert wpo.dtype == torch.uint8 and wpo.is_contiguous() and wpo.numel() == C * C * 2
+    if out is None:
+        out = torch.empty((M, C), device=x.device, dtype=x.dtype)
+    assert out.shape == (M, C) and out.stride(1) == 1 and out.dtype == x.dtype
+    _check(lib().mmgt_ff_fused_po(_ptr(x), x.stride(0), _ptr(_f32(ln_gamma, "ln_gamma")), _ptr(_f32(ln_beta, "ln_beta")), eps, _ptr(wimg),
+                                  _ptr(_f32(bias2, "bias2")), _ptr(residual), residual.stride(0), _ptr(wpo), _ptr(_f32(bias_po, "bias_po")),
+                                  _ptr(residual2), residual2.stride(0), _ptr(out), out.stride(0), M, C, inner, dtype_code(x.dtype), _stream()),
+           "mmgt_ff_fused_po")
     return out
 
 

@@ -93,3 +93,21 @@ def pack_rowgemm(w):
     assert K == 320 and N % 32 == 0
     img = w.to(torch.bfloat16).reshape(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()   # (nt, ks, hh, c, 8)
     return img.view(torch.uint8).reshape(-1)
+
+
+def pack_ff_proj_out(w):
+    """proj_out weight (320, 320) -> the image of the proj_out tail of csrc/ffn.hip (mmgt_ff_fused_po): [output tile v = 0 .. 9][k-step f =
+    0 .. 19] 1-KiB fragments, lane l = (n = l & 31, hh = l >> 5) owns 8 bf16 w[32 v + n][32 (f >> 1) + 16 (f & 1) + 8 (j >> 2) + 4 hh + (j & 3)]
+    -- k in the order of the FeedForward's output accumulator registers, which, packed to bf16, are the B operand."""
+    N, K = w.shape
+    assert N == 320 and K == 320
+    dev = w.device
+    w = w.to(torch.bfloat16)
+    lane = torch.arange(64, device=dev)
+    n, hh = lane & 31, lane >> 5
+    j = torch.arange(8, device=dev)
+    kperm = 8 * (j >> 2)[None, :] + 4 * hh[:, None] + (j & 3)[None, :]                                    # (64, 8)
+    rows = 32 * torch.arange(N // 32, device=dev)[:, None] + n[None, :]                                   # (10, 64)
+    cols = 16 * torch.arange(K // 16, device=dev)[:, None, None] + kperm[None]                            # (20, 64, 8)
+    img = w[rows[:, None, :, None], cols[None, :, :, :]]                                                  # (10, 20, 64, 8)
+    return img.contiguous().view(torch.uint8).reshape(-1)

@@ -20,7 +20,7 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from . import hip
-from .packing import pack_conv3x3, pack_ff_fused, pack_geglu, pack_rowgemm, pad_cols, pad_rows, round_up
+from .packing import pack_conv3x3, pack_ff_fused, pack_ff_proj_out, pack_geglu, pack_rowgemm, pad_cols, pad_rows, round_up
 from .unet3d_spec import unet3d_spec
 
 SD15_CONFIG = dict(  # SD-1.5 unet/config.json + unet_3d.py:649-662 + config/prompts/animation.yaml:47-75
@@ -258,6 +258,11 @@ class UNet3DConditionModel:
             if has(p + ".proj_in.weight"):
                 wt = sd[p + ".proj_in.weight"]
                 rowimg(p + ".proj_in.img", [wt.reshape(wt.shape[0], -1)])
+            if has(p + ".proj_out.weight"):     # ... and proj_out + residual on the end of the fused FeedForward launch (csrc/ffn.hip)
+                wt = sd[p + ".proj_out.weight"]
+                wt = wt.reshape(wt.shape[0], -1)
+                if self._fuse_ff and tuple(wt.shape) == (320, 320) and hip.ff_fused_supported(320, 1280, self._dtype):
+                    w[p + ".proj_out.img"] = pack_ff_proj_out(wt.to(self._device))
 
         def self_attn(p):
             if has(p + ".to_q.weight"):
@@ -450,6 +455,16 @@ class UNet3DConditionModel:
         xn = self._gn(p + ".norm", x, 1e-6)
         return self._lin(p + ".proj_in", xn.view(nb * n, c))
 
+    def _norm_ff_proj_out(self, p, norm, hid, q, x_res):
+        """proj_out(hid + FeedForward(LayerNorm(hid))) + x_res, the tail of a transformer block (transformer_3d.py:262-268,
+        motion_module.py:178-182): one launch where both weight images exist (bf16, 320 channels), else FeedForward then GEMM."""
+        img, po = self.w.get(p + ".ffimg"), self.w.get(q + ".proj_out.img")
+        if img is not None and po is not None and (q + ".proj_out.bias") in self.w:
+            return hip.ff_fused_po(hid, self.w[norm + ".g"], self.w[norm + ".b"], img, self.w[p + ".ff2.bias"], hid,
+                                   self.w[p + ".ff2.w"].shape[1], po, self.w[q + ".proj_out.bias"], x_res)
+        hid = self._norm_ff(p, norm, hid)
+        return hip.gemm(hid, self.w[q + ".proj_out.w"], self.w.get(q + ".proj_out.bias"), residual=x_res)
+
     def _resnet(self, p, x, temb, skip=None):
         """ResnetBlock3D (resnet.py:217-247); `skip` = the UNet skip tensor that the reference concatenates first."""
         nb, h, ww, c0 = x.shape
@@ -535,8 +550,7 @@ class UNet3DConditionModel:
         else:
             hid = hip.gemm(o, self.w[t + ".attn1.o.w"], self.w[t + ".attn1.o.bias"], residual=hid)
             hid = self._cross_attention(t, hid, ehs if cfg_row is None else ehs[cfg_row:cfg_row + 1], nb, n, inner)
-        hid = self._norm_ff(t + ".ff", t + ".norm3", hid)
-        out = hip.gemm(hid, self.w[p + ".proj_out.w"], self.w[p + ".proj_out.bias"], residual=x.view(m, c))
+        out = self._norm_ff_proj_out(t + ".ff", t + ".norm3", hid, p, x.view(m, c))
         return out.view(nb, h, ww, c)
 
     def _clip_vector(self, t, ehs):
@@ -603,8 +617,7 @@ class UNet3DConditionModel:
                 self._zbias[key] = (self.w[f"{t}.z{i}.bias"] * s).contiguous()
             hid = hip.gemm_post(a3[:, i * inner:(i + 1) * inner], self.w[f"{t}.oz{i}.w"], self.w[f"{t}.oz{i}.bias"], mask, s,
                                 self._zbias[key], hid)
-        hid = self._norm_ff(t + ".ff", t + ".norm3", hid)
-        out = hip.gemm(hid, self.w[p + ".proj_out.w"], self.w[p + ".proj_out.bias"], residual=x.view(m, c))
+        out = self._norm_ff_proj_out(t + ".ff", t + ".norm3", hid, p, x.view(m, c))
         return out.view(nb, h, ww, c)
 
     def _motion_module(self, p, x, frames):
@@ -633,8 +646,7 @@ class UNet3DConditionModel:
             hip.attention(qkv, qkv[:, c:], qkv[:, 2 * c:], o, batch=b * n, heads=self.heads, hd=hd, nq=frames, nk=frames,
                           scale=hd ** -0.5, q_str=st, k_str=st, v_str=st, o_str=(frames * n * c, c, n * c), bdiv=n)
             hid = hip.gemm(o, self.w[a + ".o.w"], self.w[a + ".o.bias"], residual=hid)
-        hid = self._norm_ff(t + ".ff", t + ".ff_norm", hid)
-        out = hip.gemm(hid, self.w[q + ".proj_out.w"], self.w[q + ".proj_out.bias"], residual=x.view(m, c))
+        out = self._norm_ff_proj_out(t + ".ff", t + ".ff_norm", hid, q, x.view(m, c))
         return out.view(nb, h, ww, c)
 
     # ------------------------------------------------------------------------------------------ forward

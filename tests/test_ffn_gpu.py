@@ -109,3 +109,73 @@ def test_ff_fused_equals_three_launch_path_at_step_shape():
     assert torch.isfinite(fused).all() and d.max() <= 4 * 2.0 ** -8 * three.float().abs().max() and frac < 1e-3
     again = hip.ff_fused(x, g, b, pack_ff_fused(w1, b1, w2), b2, x, INNER)
     assert torch.equal(fused, again), "not bitwise reproducible"
+
+
+# ---- proj_out on the end of the same launch (mmgt_ff_fused_po)
+
+def _run_po(x, g, b, w1, b1, w2, b2, res, wpo, bpo, res2):
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_ff_fused, pack_ff_proj_out
+    dev = "cuda:0"
+    img = pack_ff_fused(w1.to(dev), b1.to(dev).float(), w2.to(dev))
+    mv = lambda t: None if t is None else t.to(dev).contiguous()
+    out = hip.ff_fused_po(mv(x), mv(g), mv(b), img, mv(b2.float()), mv(res), INNER, pack_ff_proj_out(wpo.to(dev)), mv(bpo.float()), mv(res2))
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+@pytest.mark.parametrize("M", [128, 3000])
+def test_ff_fused_proj_out_exact_integers(M):
+    """FeedForward on exact integers (gate = 8: gelu(8) == 8 in fp32) -> hidden (integers <= 128: exact in bf16) -> proj_out with sparse
+    +-1 rows: bit for bit."""
+    gen = torch.Generator().manual_seed(7 * M)
+    ri = lambda shape, lo, hi: torch.randint(lo, hi + 1, shape, generator=gen).float()
+    x = _bf(ri((M, C), -1, 1))
+    w1 = torch.zeros(2 * INNER, C)
+    cols = torch.stack([torch.randperm(C, generator=gen)[:4] for _ in range(INNER)])
+    w1[:INNER].scatter_(1, cols, ri((INNER, 4), -1, 1))
+    b1 = torch.cat([ri((INNER,), -3, 3), torch.full((INNER,), 8.0)])
+    w2 = torch.zeros(C, INNER)
+    cols2 = torch.stack([torch.randperm(INNER, generator=gen)[:2] for _ in range(C)])
+    w2.scatter_(1, cols2, ri((C, 2), -1, 1))
+    b2 = ri((C,), -4, 4)
+    res = _bf(ri((M, C), -8, 8))
+    hidden = _ref(x, None, None, _bf(w1), b1, _bf(w2), b2, res)
+    assert hidden.abs().max() <= 128 and torch.equal(hidden, hidden.round())          # exact in bf16
+    wpo = torch.zeros(C, C)
+    cols3 = torch.stack([torch.randperm(C, generator=gen)[:6] for _ in range(C)])
+    wpo.scatter_(1, cols3, ri((C, 6), -1, 1))
+    bpo = ri((C,), -4, 4)
+    res2 = _bf(ri((M, C), -8, 8))
+    ref = hidden @ wpo.double().t() + bpo.double() + res2.double()
+    assert ref.abs().max() < 2 ** 15 and torch.equal(ref, ref.round())
+    out = _run_po(x, None, None, _bf(w1), b1, _bf(w2), b2, res, _bf(wpo), bpo, res2)
+    assert torch.equal(out, _bf(ref.float())), f"max|d| {(out.double() - ref).abs().max().item()}"
+
+
+def test_ff_fused_proj_out_random_against_fp64_and_the_two_launches():
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_ff_fused
+    from mmgt_amd.synthetic import hash_uniform
+    M = 4096
+    x = _bf(hash_uniform("ffn.x4096", (M, C), 1.5) + 0.3)
+    g, b = 1 + 0.2 * hash_uniform("ffn.g", (C,), 1.0), 0.1 * hash_uniform("ffn.b", (C,), 1.0)
+    w1 = _bf(hash_uniform("ffn.w1", (2 * INNER, C), 1.0) * C ** -0.5)
+    b1 = 0.1 * hash_uniform("ffn.b1", (2 * INNER,), 1.0)
+    w2 = _bf(hash_uniform("ffn.w2", (C, INNER), 1.0) * INNER ** -0.5)
+    b2 = 0.1 * hash_uniform("ffn.b2", (C,), 1.0)
+    wpo = _bf(hash_uniform("ffn.wpo", (C, C), 1.0) * C ** -0.5)
+    bpo = 0.1 * hash_uniform("ffn.bpo", (C,), 1.0)
+    res2 = _bf(hash_uniform("ffn.res2", (M, C), 1.0))
+    dev = "cuda:0"
+    # the hidden tensor exactly as the kernel rounds it: the stand-alone launch's output
+    hidden = hip.ff_fused(x.to(dev), g.to(dev), b.to(dev), pack_ff_fused(w1.to(dev), b1.to(dev), w2.to(dev)), b2.to(dev), x.to(dev), INNER)
+    two = hip.gemm(hidden, wpo.to(dev), bpo.to(dev), residual=res2.to(dev)).cpu()
+    ref = hidden.cpu().double() @ wpo.double().t() + bpo.double() + res2.double()
+    out = _run_po(x, g, b, w1, b1, w2, b2, x, wpo, bpo, res2)
+    d = (out.double() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 2e-3
+    print(f"ff_fused_po: max|d| {d.max().item():.3e}, worst d/tol {(d / tol).max().item():.2f}; vs ff_fused + gemm: {(out.float() - two.float()).abs().max().item():.3e}")
+    assert (d <= tol).all() and d.mean() <= 2.0 ** -9 * ref.abs().mean()
+    frac = ((out.float() - two.float()).abs() > 2.0 ** -8 * two.float().abs() + 1e-3).float().mean().item()
+    assert frac < 1e-3

@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmgt_amd import hip  # noqa: E402
-from mmgt_amd.packing import pack_ff_fused, pack_geglu  # noqa: E402
+from mmgt_amd.packing import pack_ff_fused, pack_ff_proj_out, pack_geglu  # noqa: E402
 from mmgt_amd.synthetic import hash_uniform  # noqa: E402
 
 
@@ -42,6 +42,17 @@ def main():
     fused = lambda: hip.ff_fused(x, g, b, img, b2, x, INNER, out=out)
     three = lambda: hip.gemm(hip.gemm(hip.layernorm(x, g, b, 1e-5), wp, bp, act=hip.ACT_GEGLU), w2, b2, residual=x)
     fl = 2.0 * M * (2 * INNER * C + C * INNER)
+    wpo = bf(hash_uniform("ffn.wpo", (C, C), 1.0, dev) * C ** -0.5)
+    bpo = 0.1 * hash_uniform("ffn.bpo", (C,), 1.0, dev)
+    res2 = bf(hash_uniform("ffn.res2", (M, C), 1.0, dev))
+    imgpo = pack_ff_proj_out(wpo)
+    out2 = torch.empty_like(x)
+    two = lambda: hip.gemm(hip.ff_fused(x, g, b, img, b2, x, INNER, out=out), wpo, bpo, residual=res2, out=out2)
+    po = lambda: hip.ff_fused_po(x, g, b, img, b2, x, INNER, imgpo, bpo, res2, out=out2)
+    hip.lib().mmgt_tune(b"ffn_ver", 4)
+    for rnd in range(3):
+        t2, tp = t_ms(two), t_ms(po)
+        print(f"round {rnd}: ff_fused + proj_out GEMM (+res) {t2 * 1e3:7.1f} us | ff_fused_po {tp * 1e3:7.1f} us", flush=True)
     def ver(v):
         hip.lib().mmgt_tune(b"ffn_ver", v)
         return t_ms(fused)

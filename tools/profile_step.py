@@ -59,6 +59,11 @@ def key_of(name, args, kw):
     if name == "groupnorm_affine":
         x = args[0]
         return f"groupnorm_affine nb={x.shape[0]} hw={x.shape[1]} c={x.shape[2]} (statistics only)", 0
+    if name == "ff_fused_po":
+        x = args[0]
+        inner = args[6]
+        return (f"ff_fused_po M={x.shape[0]} C={x.shape[1]} inner={inner} (LN + ff1 + GEGLU + ff2 + res + proj_out + res)",
+                2 * x.shape[0] * (3 * inner + x.shape[1]) * x.shape[1])
     if name == "ff_fused":
         x = args[0]
         inner = args[6] if len(args) > 6 else kw["inner"]
@@ -85,7 +90,7 @@ def main():
     if len(sys.argv) > 2:                                       # window length (the reference ships context_frames = 12)
         bench.FRAMES = int(sys.argv[2])
         bench.build_inputs.__defaults__ = (bench.FRAMES,) + bench.build_inputs.__defaults__[1:]
-    for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "ff_fused", "rowgemm320", "groupnorm_affine", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
+    for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "ff_fused", "ff_fused_po", "rowgemm320", "groupnorm_affine", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
               "ncfhw_to_nhwc", "nhwc_to_ncfhw", "timestep_features", "silu", "cfg_ddim_step", "accumulate_window"]:
         wrap(n)
     sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
