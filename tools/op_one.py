@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One in-step operator shape launched a few times (the target of the rocprofv3 PMC passes of tools/pmc_ops.sh).
-    python3 tools/op_one.py gemm M N K [res]      | geglu M N K | conv NB H CIN COUT | ffn | attn"""
+    python3 tools/op_one.py gemm M N K [res]      | geglu M N K | conv NB H CIN COUT | ffn | ffn_po | rowgemm N [vt] | attn"""
 import math
 import os
 import sys
@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmgt_amd import hip  # noqa: E402
-from mmgt_amd.packing import pack_conv3x3, pack_ff_fused, pack_geglu  # noqa: E402
+from mmgt_amd.packing import pack_conv3x3, pack_ff_fused, pack_ff_proj_out, pack_geglu, pack_rowgemm  # noqa: E402
 
 dev = torch.device("cuda:0")
 rnd = lambda *s: (torch.rand(s, device=dev) * 2 - 1)
@@ -42,6 +42,26 @@ elif kind == "ffn":
     b2 = 0.1 * rnd(C)
     out = torch.empty_like(x)
     fn = lambda: hip.ff_fused(x, g, b, img, b2, x, INNER, out=out)
+elif kind == "ffn_po":
+    M, C, INNER = 48 * 4096, 320, 1280
+    x = rnd(M, C).bfloat16()
+    g, b = 1 + 0.2 * rnd(C), 0.1 * rnd(C)
+    img = pack_ff_fused((rnd(2 * INNER, C) * C ** -0.5).bfloat16(), 0.1 * rnd(2 * INNER), (rnd(C, INNER) * INNER ** -0.5).bfloat16())
+    b2, bpo = 0.1 * rnd(C), 0.1 * rnd(C)
+    po = pack_ff_proj_out((rnd(C, C) * C ** -0.5).bfloat16())
+    res2 = rnd(M, C).bfloat16()
+    out = torch.empty_like(x)
+    fn = lambda: hip.ff_fused_po(x, g, b, img, b2, x, INNER, po, bpo, res2, out=out)
+elif kind == "rowgemm":
+    M, C, N = 48 * 4096, 320, int(sys.argv[2])
+    vt = len(sys.argv) > 3 and sys.argv[3] == "vt"
+    x = rnd(M, C).bfloat16()
+    g, b = 1 + 0.2 * rnd(C), 0.1 * rnd(C)
+    img = pack_rowgemm((rnd(N, C) * C ** -0.5).bfloat16())
+    n1 = N - C if vt else N
+    out = torch.empty((M, n1), device=dev, dtype=torch.bfloat16)
+    out_t = torch.empty((48, C, 4096), device=dev, dtype=torch.bfloat16) if vt else None
+    fn = lambda: hip.rowgemm320(x, img, N, ln_gamma=g, ln_beta=b, n1=n1, n_tok=4096 if vt else 0, out=out, out_t=out_t)
 elif kind == "attn":
     hd, n, nb, f = 40, 4096, 48, 24
     inner = 8 * hd

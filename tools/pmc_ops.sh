@@ -23,7 +23,11 @@ conv 48 64 320 320
 conv 48 32 640 640
 conv 48 8 1280 1280
 ffn
+ffn_po
+rowgemm 960
+rowgemm 960 vt
+rowgemm 320
 attn
 LIST
-python3 $R/tools/pmc_table.py $R/gpurun_out/pmcops > $R/gpurun_out/pmc_ops_r3.md
+python3 $R/tools/pmc_table.py $R/gpurun_out/pmcops > $R/gpurun_out/pmc_ops_r3d.md
 find $R/gpurun_out/pmcops -name "*.db" -delete; find $R/gpurun_out/pmcops -name "*.csv" -size +2M -delete
