@@ -44,6 +44,8 @@ const char* mmgt_last_error(void);
  *   "gn_rows"  = 0 (default: measured choice) or the GroupNorm rows per workgroup;
  *   "splitk"   = 1 (default) / 0: split-K of long reductions on grids of at most half a tile per CU (the 8x8-level convs);
  *   "ffn_dbg"  = 0 (default) .. 4: ablation builds of mmgt_ff_fused (timing only, results are garbage for v > 0).
+ *   "tailsplit" = 1 (default) / 0: convs whose tile count leaves the last round of the persistent grid half empty run that round's rows
+ *               as a second launch with the reduction split in two (A/B switch).
  *   "ffn_ver"  = 4 (default): single-role kernel of mmgt_ff_fused, 3: the producer / consumer kernel (A/B measurements). */
 int mmgt_tune(const char* key, int value);
 /* Debug only (tools/trace_gemm16.py): p = device buffer of u64 [grid][32 tiles][2 wave groups][4] that gemm16's workgroups fill

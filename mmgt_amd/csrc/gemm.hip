@@ -737,13 +737,14 @@ int launch_cfg(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, i
 }
 
 int g_splitk = 1;     // mmgt_tune("splitk", 0 / 1): A/B switch of the split-K path
+int g_tailsplit = 1;  // mmgt_tune("tailsplit", 0 / 1): A/B switch of the tail split (below)
 int g_gemm_cfg = 0;   // 0 = heuristic; 1, 3, 6, 9, 12, 16 force a tile configuration (mmgt_tune("gemm_cfg", v), benchmarking only)
 
 }  // namespace
 // gemm16.hip: the bf16 256x256 8-phase core on 16x16x32 MFMAs (cfg 16)
 int mmgt_gemm16_launch(int mode, int bn, const void* ad, const void* W, long bsw, const void* ep, int M, int N, int K,
                        int batch, void* stream);
-int mmgt_gemm16_splitk(int mode, int bn, const void* ad, const void* W, const void* ep, int M, int N, int K, int S, void* stream);
+int mmgt_gemm16_splitk(int mode, int bn, const void* ad, const void* W, const void* ep, int M, int N, int K, int S, void* stream, int m0);
 namespace {
 
 template <typename T, int MODE>
@@ -763,7 +764,7 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     // 59 -> 47 us at 12 frames --; between 65 and 128 tiles only long slices do: the 16x16 convs of a 12-frame window -5 %, their ff2 +10 %)
     for (int c = 8; c >= 2; --c)
       if (tiles * c <= 256 && nch % c == 0 && nch / c >= (tiles <= 64 ? 16 : 64)) { S = c; break; }
-    if (S >= 2 && tiles <= 128) return mmgt_gemm16_splitk(MODE, bn, &ad, W, &ep, M, N, K, S, s);
+    if (S >= 2 && tiles <= 128) return mmgt_gemm16_splitk(MODE, bn, &ad, W, &ep, M, N, K, S, s, 0);
   }
   if (cfg == 18) cfg = 0;
   if (cfg == 0) {
@@ -809,8 +810,39 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
   if (cfg == 16 || cfg == 17) {   // gemm16.hip, 256 / 320 columns: bf16, plain vectorised epilogue only (GEGLU: 256); else fall back
     const bool post = ep.row_scale || ep.alpha != 1.f || ep.bias_post;   // row scale / alpha / post-scale bias: without GEGLU only
     if (std::is_same<T, bf16_t>::value && ep.fast && ep.act <= (cfg == 16 && !post ? 1 : 0) &&
-        (((uintptr_t)ep.bias | (uintptr_t)ep.bias2 | (uintptr_t)ep.bias_post) & 15) == 0 && N % 4 == 0)   // (bias vectors travel by 16-byte DMA)
-      return mmgt_gemm16_launch(MODE, cfg == 16 ? 256 : 320, &ad, W, bsw, &ep, M, N, K, batch, s);
+        (((uintptr_t)ep.bias | (uintptr_t)ep.bias2 | (uintptr_t)ep.bias_post) & 15) == 0 && N % 4 == 0) {   // (bias vectors travel by 16-byte DMA)
+      const int bn = cfg == 16 ? 256 : 320;
+      // Tail split.  A persistent grid of T tiles runs ceil(T / 256) rounds of one tile per CU; with a long reduction and T = 256 q + r,
+      // r <= 128 (the 32x32 level: 49 152 rows x 640 columns = 384 tiles), the last round keeps half the chip idle for a whole tile.  The
+      // rows of the r tail tiles run as a second launch with the reduction split in two (2 r <= 256 half-tiles: one round of half the
+      // length) + the fixed-order reduce.  Convs only (reductions of 2880 .. 17 280: 32x32 convs 640 -> 640 338 -> 310 us, 1280 -> 640
+      // 631 -> 556, 1920 -> 640 923 -> 791): the fp32 partial slabs and the reduce cost ~25 us, which a dense K = 2560 tile does not repay.
+      const long tiles_n = (N + bn - 1) / bn, tiles_m = (M + 255) / 256, ntile = tiles_m * tiles_n;
+      const int nch = K / 64;
+      if (g_tailsplit && MODE == 1 && batch == 1 && !ad.ksplit && ep.act == 0 && !post && N % bn == 0 && N % 8 == 0 && K >= 2560 && nch % 2 == 0 && ntile > 256) {
+        const long rows_a = (256 * (ntile / 256) / tiles_n) * 256;                  // whole row tiles that fill ntile / 256 full rounds
+        const long tail = (tiles_m - rows_a / 256) * tiles_n;
+        const long img = MODE == 1 ? (long)ad.OH * ad.OW : 1;
+        if (rows_a > 0 && rows_a < M && tail > 0 && 2 * tail <= 256 && 4 * tail >= 256 && rows_a % img == 0) {
+          int rc = mmgt_gemm16_launch(MODE, bn, &ad, W, bsw, &ep, (int)rows_a, N, K, 1, s);
+          if (rc) return rc;
+          ADesc adb = ad;
+          Epi epb = ep;
+          const long esz = sizeof(T);
+          if (MODE == 1) {
+            const long n0 = rows_a / img;
+            adb.src0 = ad.src0 + n0 * ad.IH * ad.IW * ad.C0 * esz;
+            if (ad.src1) adb.src1 = ad.src1 + n0 * ad.IH * ad.IW * ad.C1 * esz;
+          } else {
+            adb.src0 = ad.src0 + rows_a * ad.ld0 * esz;
+          }
+          if (ep.residual) epb.residual = ep.residual + rows_a * ep.ldr * esz;
+          epb.out = ep.out + rows_a * ep.ldo * esz;
+          return mmgt_gemm16_splitk(MODE, bn, &adb, W, &epb, (int)(M - rows_a), N, K, 2, s, (int)rows_a);
+        }
+      }
+      return mmgt_gemm16_launch(MODE, bn, &ad, W, bsw, &ep, M, N, K, batch, s);
+    }
     cfg = cfg == 16 ? 9 : geglu ? 1 : 12;   // (GEGLU pairs need 64-column wave tiles: not the 320-column tile)
   }
   // anything beyond bias / per-batch bias / GEGLU / residual on the vectorised path runs the FULL instantiation (128x128 tile)
@@ -874,6 +906,7 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "attn64")) { mmgt_attn_set64(value); return 0; }
   if (key && !strcmp(key, "gn_rows")) { mmgt_gn_set_rows(value); return 0; }
   if (key && !strcmp(key, "splitk")) { g_splitk = value; return 0; }
+  if (key && !strcmp(key, "tailsplit")) { g_tailsplit = value; return 0; }
   if (key && !strcmp(key, "attn64_pad")) { mmgt_attn64_set_pad(value); return 0; }
   if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 4) { mmgt_ffn_set_dbg(value); return 0; }
   if (key && !strcmp(key, "rowgemm_dbg") && value >= 0 && value <= 5) { mmgt_rowgemm_set_dbg(value); return 0; }

@@ -555,7 +555,7 @@ namespace {
 // kernel sums the slabs in slice order (bitwise reproducible) and applies bias / per-batch bias / residual.  8 columns per thread.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, long slab, const float* __restrict__ bias,
                                                             const float* __restrict__ bias2, int b2rows, const bf16_t* __restrict__ res,
-                                                            long ldr, bf16_t* __restrict__ out, long ldo, int M, int N) {
+                                                            long ldr, bf16_t* __restrict__ out, long ldo, int M, int N, int m0) {
   const int nv = N / 8;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)M * nv) return;
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
   if (bias) { a0 += *reinterpret_cast<const f32x4*>(bias + c); a1 += *reinterpret_cast<const f32x4*>(bias + c + 4); }
   if (bias2) {
-    const float* b2 = bias2 + (long)(m / b2rows) * N + c;
+    const float* b2 = bias2 + (long)((m + m0) / b2rows) * N + c;      // (m0: the launch covers rows m0 .. of a larger problem)
     a0 += *reinterpret_cast<const f32x4*>(b2);
     a1 += *reinterpret_cast<const f32x4*>(b2 + 4);
   }
@@ -590,7 +590,7 @@ size_t g_splitk_bytes = 0;
 // Split-K entry for gemm.hip's dispatcher: bf16, one problem (batch 1), no activation / row scale / post-scale bias, N % 8 == 0,
 // (K / 64) % S == 0.  Returns 0 on success; the partial slabs live in a library-owned device buffer that grows on demand (work on
 // one stream at a time: the buffer is reused by the next call).
-int mmgt_gemm16_splitk(int mode, int bn, const void* adp, const void* W, const void* epp, int M, int N, int K, int S, void* stream) {
+int mmgt_gemm16_splitk(int mode, int bn, const void* adp, const void* W, const void* epp, int M, int N, int K, int S, void* stream, int m0) {
   ADesc ad = *reinterpret_cast<const ADesc*>(adp);
   const Epi& ep = *reinterpret_cast<const Epi*>(epp);
   hipStream_t s = (hipStream_t)stream;
@@ -620,7 +620,7 @@ int mmgt_gemm16_splitk(int mode, int bn, const void* adp, const void* W, const v
   if (rc) return rc;
   const long nthr = (long)M * (N / 8);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, g_splitk_ws, S, (long)M * N, ep.bias, ep.bias2,
-                     ep.bias2 ? ep.bias2_rows : 1, reinterpret_cast<const bf16_t*>(ep.residual), ep.ldr, reinterpret_cast<bf16_t*>(ep.out), ep.ldo, M, N);
+                     ep.bias2 ? ep.bias2_rows : 1, reinterpret_cast<const bf16_t*>(ep.residual), ep.ldr, reinterpret_cast<bf16_t*>(ep.out), ep.ldo, M, N, m0);
   MMGT_LAUNCH_CHECK();
   return 0;
 }

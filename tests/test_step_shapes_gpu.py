@@ -143,3 +143,56 @@ def test_gemm16_splitk_equals_unsplit_and_fp64(kind, shape):
     check(plain, ref, 4e-5, f"unsplit {kind} {shape}")
     again, _, _ = run(exact=False)
     assert torch.equal(split, again), "split-K is not bitwise reproducible"
+
+
+@pytest.mark.parametrize("kind,shape", [("conv", (48, 32, 640, 0, 640)), ("conv", (48, 32, 1280, 640, 640))])
+def test_gemm16_tail_split_equals_one_launch_and_fp64(kind, shape):
+    """Tail split (the 32x32 level: 384 tiles for 256 CUs): the rows of the last, half-empty round run as a second launch with the
+    reduction split in two.  Small-integer operands: every partial sum is exact, so both schedules must equal the int64 reference BIT
+    FOR BIT -- across the row split (image 32 of 48), with a per-image-group bias2 (the time embedding: its row group changes INSIDE
+    the tail), a concatenated second source and a residual; random operands: one output ulp against fp64; bitwise reproducible."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_conv3x3
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    ri = lambda shape, lo, hi: torch.randint(lo, hi + 1, shape, generator=gen, device=DEV).float()
+
+    def run(exact):
+        if kind == "conv":
+            nb, h, c0, c1, cout = shape
+            mk = (lambda s, sc: ri(s, -2, 2).bfloat16()) if exact else (lambda s, sc: rnd(f"ts.{s}", s, sc))
+            x0 = mk((nb, h, h, c0), 1.0)
+            x1 = mk((nb, h, h, c1), 1.0) if c1 else None
+            w = (ri((cout, c0 + c1, 3, 3), -1, 1) * (torch.rand((cout, c0 + c1, 3, 3), generator=gen, device=DEV) < 0.02)).bfloat16() if exact \
+                else rnd("ts.w", (cout, c0 + c1, 3, 3), (9 * (c0 + c1)) ** -0.5)
+            b = ri((cout,), -3, 3) if exact else hash_uniform("ts.b", (cout,), 0.2, DEV)
+            b2 = ri((2, cout), -3, 3) if exact else hash_uniform("ts.b2", (2, cout), 0.2, DEV)      # one row per CFG batch entry: 24 images each
+            res = mk((nb, h, h, cout), 1.0)
+            wp = pack_conv3x3(w)
+            f = lambda: hip.conv3x3(x0, wp, b, residual=res, x1=x1, bias2=b2, bias2_rows=(nb // 2) * h * h)
+            xin = x0 if x1 is None else torch.cat([x0, x1], 3)
+            ref = F.conv2d(xin.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) + res.double() + \
+                b2.double().repeat_interleave(nb // 2, 0)[:, None, None, :]
+        else:
+            M, N, K = shape
+            a = ri((M, K), -2, 2).bfloat16() if exact else rnd("ts.a", (M, K))
+            w = (ri((N, K), -1, 1) * (torch.rand((N, K), generator=gen, device=DEV) < 0.02)).bfloat16() if exact else rnd("ts.wd", (N, K), K ** -0.5)
+            b = ri((N,), -3, 3) if exact else hash_uniform("ts.bd", (N,), 0.2, DEV)
+            res = ri((M, N), -4, 4).bfloat16() if exact else rnd("ts.rd", (M, N))
+            f = lambda: hip.gemm(a, w, b, residual=res)
+            ref = a.double() @ w.double().t() + b.double() + res.double()
+        hip.tune("tailsplit", 1)
+        split = f()
+        hip.tune("tailsplit", 0)
+        plain = f()
+        hip.tune("tailsplit", 1)
+        return split, plain, ref
+
+    split, plain, ref = run(exact=True)
+    assert ref.abs().max() < 256 and torch.equal(ref, ref.round())
+    assert torch.equal(plain.double(), ref), "one launch, exact-integer case"
+    assert torch.equal(split.double(), ref), "tail split, exact-integer case"
+    split, plain, ref = run(exact=False)
+    check(split, ref, 4e-5, f"tail split {kind} {shape}")
+    check(plain, ref, 4e-5, f"one launch {kind} {shape}")
+    again, _, _ = run(exact=False)
+    assert torch.equal(split, again), "the tail split is not bitwise reproducible"
