@@ -356,37 +356,84 @@ class GestureDiffusion:
         times = list(reversed(times.int().tolist()))
         return list(zip(times[:-1], times[1:]))
 
+    def _step_coeffs(self, time, time_next):
+        ac = self.alphas_cumprod
+        a = float(ac[time])
+        if time_next < 0:
+            return math.sqrt(1.0 / a), math.sqrt(1.0 / a - 1), 0.0, 0.0, 0.0, True
+        an = float(ac[time_next])
+        sigma = self.eta * math.sqrt((1 - a / an) * (1 - an) / (1 - a))
+        return math.sqrt(1.0 / a), math.sqrt(1.0 / a - 1), math.sqrt(an), math.sqrt(1 - an - sigma ** 2), sigma, False
+
+    def _loop(self, x, prep, times_dev, noise_of):
+        """The 50 DDIM steps (diffusion.py:252-274): decoder (both guidance passes batched) + guided x0-prediction update."""
+        m = self.model
+        n = x.shape[0] * x.shape[1]
+        k = 0
+        for i, (time, time_next) in enumerate(self.time_pairs()):
+            pred = m._forward2(x, times_dev[i], prep)
+            c0, c1, a_next_sqrt, c, sigma, last = self._step_coeffs(time, time_next)
+            noise = None
+            if not last:
+                noise = noise_of(k)
+                k += 1
+            x = hip.smga_ddim_step(pred[:n], pred[n:], x, noise, self.guidance_weight, c0, c1, a_next_sqrt, c, sigma, last)
+        return x
+
     @torch.no_grad()
     def ddim_sample(self, shape, cond_frame, cond, last_half=None, noises: Optional[List[torch.Tensor]] = None, generator=None,
                     **kwargs):
         """diffusion.py:241-274.  `noises` (parity tests): the normal draws in the reference's order -- the initial x, then one per
-        DDIM step that draws; otherwise they come from torch.randn on the device (`generator` optional)."""
+        DDIM step that draws; otherwise they come from torch.randn on the device (`generator` optional).
+
+        The loop is ~5000 small launches (50 steps x ~100 kernels over 80 x 512 activations): launch-bound.  Without injected noises it
+        is captured ONCE per shape into a HIP graph -- condition preparation, 50 decoder passes and updates -- over static input / noise
+        buffers and replayed (same kernels, same draw order: bitwise the eager result; MMGT_NO_SMGA_GRAPH=1 keeps the eager loop)."""
+        import os
         m = self.model
         dev = m.device
         b = shape[0]
-        prep = m.prepare(cond_frame, cond)
-        draw = (lambda: next(it).to(dev).float().contiguous()) if noises is not None else \
-            (lambda: torch.randn(shape, device=dev, generator=generator))
-        it = iter(noises) if noises is not None else None
-        x = draw()
-        ac = self.alphas_cumprod
-        n = b * shape[1]
-        for time, time_next in self.time_pairs():
-            pred = m._forward2(x, torch.full((b,), time), prep)
-            last = time_next < 0
-            a = float(ac[time])
-            if last:
-                a_next_sqrt = c = sigma = 0.0
-                noise = None
-            else:
-                an = float(ac[time_next])
-                sigma = self.eta * math.sqrt((1 - a / an) * (1 - an) / (1 - a))
-                c = math.sqrt(1 - an - sigma ** 2)
-                a_next_sqrt = math.sqrt(an)
-                noise = draw()
-            x = hip.smga_ddim_step(pred[:n], pred[n:], x, noise, self.guidance_weight, math.sqrt(1.0 / a), math.sqrt(1.0 / a - 1),
-                                   a_next_sqrt, c, sigma, last)
-        return x
+        pairs = self.time_pairs()
+        ndraw = sum(1 for _, tn in pairs if tn >= 0)
+        if noises is not None or os.environ.get("MMGT_NO_SMGA_GRAPH") == "1" or torch.device(dev).type != "cuda":
+            prep = m.prepare(cond_frame, cond)
+            it = iter(noises) if noises is not None else None
+            draw = (lambda: next(it).to(dev).float().contiguous()) if noises is not None else \
+                (lambda: torch.randn(shape, device=dev, generator=generator))
+            x = draw()
+            times_dev = [torch.full((b,), t, device=dev, dtype=torch.long) for t, _ in pairs]
+            return self._loop(x, prep, times_dev, lambda k: draw())
+        key = (tuple(shape), tuple(cond_frame.shape), tuple(cond.shape))
+        g = self._graphs.get(key) if hasattr(self, "_graphs") else None
+        if g is None:
+            if not hasattr(self, "_graphs"):
+                self._graphs = {}
+            st = dict(cf=torch.zeros(tuple(cond_frame.shape), device=dev, dtype=torch.float32),
+                      cond=torch.zeros(tuple(cond.shape), device=dev, dtype=torch.float32),
+                      x0=torch.zeros(shape, device=dev, dtype=torch.float32),
+                      noise=torch.zeros((max(ndraw, 1),) + tuple(shape), device=dev, dtype=torch.float32),
+                      times=[torch.full((b,), t, device=dev, dtype=torch.long) for t, _ in pairs])
+
+            def body():
+                prep = m.prepare(st["cf"], st["cond"])
+                return self._loop(st["x0"], prep, st["times"], lambda k: st["noise"][k])
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):            # warm-up outside the capture: library attributes, allocator pools
+                body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                st["out"] = body()
+            g = self._graphs[key] = (graph, st)
+        graph, st = g
+        st["cf"].copy_(cond_frame.to(dev).float())
+        st["cond"].copy_(cond.to(dev).float())
+        st["x0"].copy_(torch.randn(shape, device=dev, generator=generator))          # the reference's draw order: x first, then one per step
+        for k in range(ndraw):
+            st["noise"][k].copy_(torch.randn(shape, device=dev, generator=generator))
+        graph.replay()
+        return st["out"].clone()
 
     def render_sample(self, shape, cond_frame, cond, epoch=None, render_out=None, last_half=None, mode="normal", **kwargs):
         if mode != "normal":
