@@ -897,6 +897,9 @@ int check_common(int dtype, int M, int N, int K, int act) {
 
 void mmgt_attn_set64(int v);
 void mmgt_gn_set_rows(int v);
+void mmgt_gn_set_interleave(int v);
+void mmgt_gn_set_lpr0(int v);
+void mmgt_gn_set_narrow(int v);
 void mmgt_ffn_set_dbg(int v);
 void mmgt_ffn_set_ver(int v);
 void mmgt_rowgemm_set_dbg(int v);
@@ -905,6 +908,9 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return 0; }
   if (key && !strcmp(key, "attn64")) { mmgt_attn_set64(value); return 0; }
   if (key && !strcmp(key, "gn_rows")) { mmgt_gn_set_rows(value); return 0; }
+  if (key && !strcmp(key, "gn_interleave")) { mmgt_gn_set_interleave(value); return 0; }
+  if (key && !strcmp(key, "gn_narrow")) { mmgt_gn_set_narrow(value); return 0; }
+  if (key && !strcmp(key, "gn_lpr0")) { if (value != 4 && value != 8 && value != 16) return -1; mmgt_gn_set_lpr0(value); return 0; }
   if (key && !strcmp(key, "splitk")) { g_splitk = value; return 0; }
   if (key && !strcmp(key, "tailsplit")) { g_tailsplit = value; return 0; }
   if (key && !strcmp(key, "attn64_pad")) { mmgt_attn64_set_pad(value); return 0; }

@@ -8,6 +8,9 @@ namespace {
 
 constexpr int GN_MAXC = 2560;
 
+int g_gn_interleave = -1;   // mmgt_tune("gn_interleave", v): -1 = the default (interleaved), 0 / 1 = force the row mapping (GnRows below)
+int g_gn_lpr0 = 8;          // mmgt_tune("gn_lpr0", v): smallest lanes-per-row tried (benchmarking only)
+int g_gn_narrow = 1;        // mmgt_tune("gn_narrow", 0): the general two-pass kernels for every shape (A/B)
 int g_gn_rows = 0;   // mmgt_tune("gn_rows", v): force the rows per workgroup (0 = the measured choice below; benchmarking only)
 // Upper bound of the chunk count for an image of HW pixels: what callers size the workspace with (mmgt_groupnorm_chunks).
 inline int gn_chunks(int HW) {
@@ -18,8 +21,11 @@ inline int gn_chunks(int HW) {
 // barriers) is as long as ~8 row steps of its loop, so more rows per workgroup amortise it until the grid no longer covers
 // the chip -- measured (48 images, tools/bench_norm.py): 4096 x 320: 256 rows 84 us / 128 rows 92 / 64 rows 131 / 512 rows 119;
 // 4096 x 640 and x 960: 128 rows best; 1024 x 640: 64 rows 51 us against 60 at 32.
-inline int gn_chunks_used(int HW, int C) {
-  const int rows = g_gn_rows > 0 ? g_gn_rows : HW >= 2048 ? (C <= 320 ? 256 : 128) : 64;
+inline int gn_chunks_used(int HW, int C, int NB) {
+  int rows = g_gn_rows > 0 ? g_gn_rows : HW >= 2048 ? (C <= 320 ? 256 : 128) : 64;
+  // Large images in small batches (the VAE decoder's 256 x 256 and 512 x 512 levels, 4-8 frames): ~1024 workgroups in all measured
+  // best -- 8 x 262144 x 128: 2048 rows 395 us against 411 at 1024; 8 x 65536 x 256: 512 rows 210 us / 256 rows 230 / 1024 rows 262.
+  if (g_gn_rows <= 0 && HW >= 65536) rows = max(rows, (int)(((long)HW * NB + 1023) / 1024));
   int c = (HW + rows - 1) / rows;
   const int cap = gn_chunks(HW);
   return c < 1 ? 1 : (c > cap ? cap : c);
@@ -42,6 +48,28 @@ struct VecIO {
   }
 };
 
+// Which rows (pixels) of its image a workgroup of the two chunked passes walks: `wg_rows` rows per step of its four waves.
+//   contiguous   rows [chunk * rows_per, (chunk + 1) * rows_per);
+//   interleaved  steps chunk, chunk + chunks, chunk + 2 chunks, ... of `wg_rows` rows each: the image's workgroups together stream one
+//                contiguous window forward instead of `chunks` streams a fixed distance apart.  Measured (tools/bench_norm.py, GN_IL=0,1):
+//                -2..-5 % on every chunked shape (48 x 4096 x 320: 84 -> 81 us, x 960: 303 -> 294; 8 x 262144 x 256: 803 -> 779).
+// `partial` holds one entry per (image, chunk) either way; both passes of a launch use the same mapping.
+struct GnRows {
+  int r0, r1, step;
+  __device__ GnRows(int HW, int chunks, int chunk, int wg_rows, int interleave) {
+    if (interleave) {
+      r0 = chunk * wg_rows;
+      r1 = HW;
+      step = chunks * wg_rows;
+    } else {
+      const int rows_per = (HW + chunks - 1) / chunks;
+      r0 = chunk * rows_per;
+      r1 = min(HW, r0 + rows_per);
+      step = wg_rows;
+    }
+  }
+};
+
 // ---- GroupNorm pass 1: per (image, row chunk) partial sum / sum of squares per group, of the values SHIFTED by a per-group
 // pivot p_g = x[image][pixel 0][first channel of the group]: var = E[(x - p)^2] - (E[x - p])^2 cancels against (mean - p)^2,
 // which is of the order of the variance itself for a pivot drawn from the data, instead of against mean^2 (real SD-1.5
@@ -51,7 +79,7 @@ struct VecIO {
 // streams 64 / LPR rows at once with every lane busy); a lane always owns the same channels.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1,
-                                                       float* __restrict__ partial, int HW, int G, int chunks, int lpr) {
+                                                       float* __restrict__ partial, int HW, int G, int chunks, int lpr, int interleave) {
   constexpr int VEC = VecIO<T>::VEC;
   constexpr int MAXS = GN_MAXC / (VEC * 64);
   __shared__ float ssum[GN_MAXC], ssq[GN_MAXC];
@@ -65,10 +93,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x0,
     }
     __syncthreads();
   }
-  const int rows_per = (HW + chunks - 1) / chunks;
-  const int r0 = chunk * rows_per, r1 = min(HW, r0 + rows_per);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int rpw = 64 / lpr, sub = lane / lpr, li = lane - sub * lpr;
+  const GnRows rows(HW, chunks, chunk, 4 * rpw, interleave);
+  const int r1 = rows.r1;
 
   float s[MAXS][VEC], q[MAXS][VEC];
 #pragma unroll
@@ -80,7 +108,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x0,
   // registers next to the 2 x MAXS x VEC accumulators cost the kernel half its occupancy (174 VGPRs, 2 waves per SIMD)
   for (int c = threadIdx.x; c < C; c += 256) ssq[c] = ssum[c];
   __syncthreads();
-  for (int r = r0 + wid * rpw + sub; r < r1; r += 4 * rpw) {
+  for (int r = rows.r0 + wid * rpw + sub; r < r1; r += rows.step) {
     const long pix = (long)n * HW + r;
     int keep = 0;
     asm volatile("" : "+v"(keep));                    // opaque zero: keeps the pivot reads inside the row loop
@@ -133,38 +161,54 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x0,
   }
 }
 
+// Mean / rstd of every group of image n from the per-chunk partial sums: four adjacent lanes per group sum every fourth chunk each
+// (independent loads, eight in flight) and are folded by a fixed xor tree -- the one-thread-per-group loop this replaces walked up to
+// 256 dependent L2 round trips at the head of EVERY workgroup of the apply pass (~90 us of a 130 us workgroup on the VAE decoder's
+// 512 x 512 levels).  Same order in every workgroup and every run: bitwise reproducible.  Needs G <= 64 and blockDim = 256.
+__device__ __forceinline__ void gn_group_stats(const float* __restrict__ partial, int n, int chunks, int G, float cnt, float eps,
+                                               float piv, float* smean, float* srstd) {
+  const int g = threadIdx.x >> 2, j = threadIdx.x & 3;
+  float a = 0.f, b = 0.f;
+  if (g < G) {
+    const float* src = partial + ((long)n * chunks * G + g) * 2;
+#pragma unroll 8
+    for (int ch = j; ch < chunks; ch += 4) {
+      const f32x2 v = *reinterpret_cast<const f32x2*>(src + (long)ch * G * 2);
+      a += v[0];
+      b += v[1];
+    }
+  }
+  a += __shfl_xor(a, 1); b += __shfl_xor(b, 1);
+  a += __shfl_xor(a, 2); b += __shfl_xor(b, 2);
+  if (g < G && j == 0) {
+    const float dm = a / cnt;
+    float var = b / cnt - dm * dm;
+    var = var < 0.f ? 0.f : var;
+    smean[g] = piv + dm;
+    srstd[g] = rsqrtf(var + eps);
+  }
+}
+
 // ---- GroupNorm pass 2: normalise (+ SiLU) ----
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ partial, T* __restrict__ out, int HW,
-                                                       int G, int chunks, float eps, int silu, int lpr) {
+                                                       int G, int chunks, float eps, int silu, int lpr, int interleave) {
   constexpr int VEC = VecIO<T>::VEC;
   constexpr int MAXS = GN_MAXC / (VEC * 64);
   __shared__ float sscale[GN_MAXC], sshift[GN_MAXC];
   __shared__ float smean[64], srstd[64];
   const int C = C0 + C1, nvec = C / VEC, cg = C / G;
   const int n = blockIdx.y, chunk = blockIdx.x;
-  const int rows_per = (HW + chunks - 1) / chunks;
-  const int r0 = chunk * rows_per, r1 = min(HW, r0 + rows_per);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int rpw = 64 / lpr, sub = lane / lpr, li = lane - sub * lpr;
-  if (threadIdx.x < G) {
-    float a = 0.f, b = 0.f;
-    for (int ch = 0; ch < chunks; ++ch) {
-      const float* src = partial + (((long)n * chunks + ch) * G + threadIdx.x) * 2;
-      a += src[0];
-      b += src[1];
-    }
-    const float cnt = (float)HW * (float)cg;
-    const int c0 = threadIdx.x * cg;                   // the pivot gn_stats_kernel shifted this group's values by
+  const GnRows rows(HW, chunks, chunk, 4 * rpw, interleave);
+  const int r1 = rows.r1;
+  {
+    const int g = threadIdx.x >> 2, c0 = (g < G ? g : 0) * cg;     // the pivot gn_stats_kernel shifted this group's values by
     const float piv = c0 < C0 ? Elem<T>::ld(x0 + (long)n * HW * C0 + c0) : Elem<T>::ld(x1 + (long)n * HW * C1 + (c0 - C0));
-    const float dm = a / cnt;
-    float var = b / cnt - dm * dm;
-    var = var < 0.f ? 0.f : var;
-    const float mean = piv + dm;
-    smean[threadIdx.x] = mean;
-    srstd[threadIdx.x] = rsqrtf(var + eps);
+    gn_group_stats(partial, n, chunks, G, (float)HW * (float)cg, eps, piv, smean, srstd);
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -174,7 +218,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
     sshift[c] = beta[c] - smean[g] * sc;
   }
   __syncthreads();
-  for (int r = r0 + wid * rpw + sub; r < r1; r += 4 * rpw) {
+  for (int r = rows.r0 + wid * rpw + sub; r < r1; r += rows.step) {
     const long pix = (long)n * HW + r;
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
@@ -195,6 +239,103 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x0,
   }
 }
 
+// ---- GroupNorm for NARROW rows: C / VEC in {8, 16, 32, 64} vectors per pixel (the VAE's 128 / 256 / 512-channel tensors, up to
+// 1.1 GB each: nothing is served from the Infinity Cache, the passes run at what HBM streams).  A lane owns ONE 16-byte channel vector for
+// the whole kernel -- its pivots (pass 1) or scale / shift pairs (pass 2) live in registers, 2 x VEC accumulators in all -- and keeps U
+// row steps in flight: every load instruction of a wave covers 64 / nvec whole rows (1 KB contiguous), a workgroup step U x 4 of them.
+// 40-50 VGPRs against the general kernels' 142 / 51 with their LDS table reads per element: 8 waves per SIMD, ~128 KB in flight per CU.
+// Rows are interleaved over the image's workgroups as in GnRows.  Host side: HW % (4 * (64 / nvec) * U) == 0.
+template <typename T, int U>
+__global__ __launch_bounds__(256) void gn_stats_narrow_kernel(const T* __restrict__ x, float* __restrict__ partial, int C, int HW, int G,
+                                                              int chunks) {
+  constexpr int VEC = VecIO<T>::VEC;
+  __shared__ float ssum[4][64 * VEC], ssq[4][64 * VEC];
+  const int nvec = C / VEC, cg = C / G;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int rpw = 64 / nvec, sub = lane / nvec, li = lane - sub * nvec, c = li * VEC;
+  const T* img = x + (long)n * HW * C;
+  float pv[VEC], s[VEC], q[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    pv[e] = Elem<T>::ld(img + ((c + e) / cg) * cg);     // the group's pivot (see gn_stats_kernel)
+    s[e] = q[e] = 0.f;
+  }
+  const int RS = 4 * rpw;
+  for (int r = chunk * RS * U + wid * rpw + sub; r < HW; r += chunks * RS * U) {
+    float f[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) VecIO<T>::load(img + (long)(r + u * RS) * C + c, f[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { const float d = f[u][e] - pv[e]; s[e] += d; q[e] += d * d; }
+  }
+  for (int o = nvec; o < 64; o <<= 1) {                 // the wave's row slots (fixed xor tree)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { s[e] += __shfl_xor(s[e], o); q[e] += __shfl_xor(q[e], o); }
+  }
+  if (sub == 0) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { ssum[wid][c + e] = s[e]; ssq[wid][c + e] = q[e]; }
+  }
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < C; ch += 256) {       // the four waves in a fixed order
+    ssum[0][ch] = (ssum[0][ch] + ssum[1][ch]) + (ssum[2][ch] + ssum[3][ch]);
+    ssq[0][ch] = (ssq[0][ch] + ssq[1][ch]) + (ssq[2][ch] + ssq[3][ch]);
+  }
+  __syncthreads();
+  if (threadIdx.x < G) {
+    float a = 0.f, b = 0.f;
+    for (int ch = threadIdx.x * cg; ch < (threadIdx.x + 1) * cg; ++ch) { a += ssum[0][ch]; b += ssq[0][ch]; }
+    float* dst = partial + (((long)n * chunks + chunk) * G + threadIdx.x) * 2;
+    dst[0] = a;
+    dst[1] = b;
+  }
+}
+
+template <typename T, int U>
+__global__ __launch_bounds__(256) void gn_apply_narrow_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ partial,
+                                                              T* __restrict__ out, int C, int HW, int G, int chunks, float eps, int silu) {
+  constexpr int VEC = VecIO<T>::VEC;
+  __shared__ float smean[64], srstd[64];
+  const int nvec = C / VEC, cg = C / G;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int rpw = 64 / nvec, sub = lane / nvec, li = lane - sub * nvec, c = li * VEC;
+  const T* img = x + (long)n * HW * C;
+  T* dst = out + (long)n * HW * C;
+  {
+    const int g = threadIdx.x >> 2;
+    const float piv = Elem<T>::ld(img + (g < G ? g : 0) * cg);
+    gn_group_stats(partial, n, chunks, G, (float)HW * (float)cg, eps, piv, smean, srstd);
+  }
+  __syncthreads();
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const int g = (c + e) / cg;
+    sc[e] = srstd[g] * gamma[c + e];
+    sh[e] = beta[c + e] - smean[g] * sc[e];
+  }
+  const int RS = 4 * rpw;
+  for (int r = chunk * RS * U + wid * rpw + sub; r < HW; r += chunks * RS * U) {
+    float f[U][VEC];
+#pragma unroll
+    for (int u = 0; u < U; ++u) VecIO<T>::load(img + (long)(r + u * RS) * C + c, f[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float v = f[u][e] * sc[e] + sh[e];
+        f[u][e] = silu ? silu_f(v) : v;
+      }
+      VecIO<T>::store(dst + (long)(r + u * RS) * C + c, f[u]);
+    }
+  }
+}
+
 // ---- GroupNorm pass 2 as TABLES: scale[n][c] = rstd * gamma, shift[n][c] = beta - mean * scale (the head of gn_apply_kernel, the same
 // arithmetic), for a consumer that applies v = x * scale + shift itself while it loads x (csrc/rowgemm.hip, norm = 2).
 template <typename T>
@@ -203,20 +344,10 @@ __global__ __launch_bounds__(256) void gn_affine_kernel(const T* __restrict__ x0
                                                         int C, int HW, int G, int chunks, float eps) {
   __shared__ float smean[64], srstd[64];
   const int n = blockIdx.x, cg = C / G;
-  if (threadIdx.x < G) {
-    float a = 0.f, b = 0.f;
-    for (int ch = 0; ch < chunks; ++ch) {
-      const float* src = partial + (((long)n * chunks + ch) * G + threadIdx.x) * 2;
-      a += src[0];
-      b += src[1];
-    }
-    const float cnt = (float)HW * (float)cg;
-    const float piv = Elem<T>::ld(x0 + (long)n * HW * C + threadIdx.x * cg);      // the pivot gn_stats_kernel shifted this group's values by
-    const float dm = a / cnt;
-    float var = b / cnt - dm * dm;
-    var = var < 0.f ? 0.f : var;
-    smean[threadIdx.x] = piv + dm;
-    srstd[threadIdx.x] = rsqrtf(var + eps);
+  {
+    const int g = threadIdx.x >> 2;
+    const float piv = Elem<T>::ld(x0 + (long)n * HW * C + (g < G ? g : 0) * cg);   // the pivot gn_stats_kernel shifted this group's values by
+    gn_group_stats(partial, n, chunks, G, (float)HW * (float)cg, eps, piv, smean, srstd);
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -384,6 +515,9 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ x, long l
 }  // namespace
 
 void mmgt_gn_set_rows(int v) { g_gn_rows = v; }
+void mmgt_gn_set_interleave(int v) { g_gn_interleave = v; }
+void mmgt_gn_set_lpr0(int v) { g_gn_lpr0 = v; }
+void mmgt_gn_set_narrow(int v) { g_gn_narrow = v; }
 extern "C" int mmgt_groupnorm_chunks(int HW) { return gn_chunks(HW); }
 
 extern "C" int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta,
@@ -413,25 +547,51 @@ extern "C" int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C
       return 0;
     }
   }
-  const int chunks = gn_chunks_used(HW, C);
-  dim3 grid(chunks, NB);
   const int nvec = C / vec;
+  {
+    // narrow rows (the VAE): a lane per channel vector, see gn_stats_narrow_kernel
+    constexpr int U = 4;
+    const bool fits = C1 == 0 && nvec >= 8 && nvec <= 64 && 64 % nvec == 0 && HW % (4 * (64 / (nvec > 0 ? nvec : 1)) * U) == 0;
+    if (fits && g_gn_narrow) {
+      int rows = g_gn_rows > 0 ? g_gn_rows : 64;     // 8 x 4096 x 512: 64-128 rows 29 us, 256 rows 46 us; larger images: ~2048 workgroups in all
+      if (g_gn_rows <= 0) rows = max(rows, (int)(((long)HW * NB + 2047) / 2048));
+      rows = (rows + 4 * (64 / nvec) * U - 1) / (4 * (64 / nvec) * U) * (4 * (64 / nvec) * U);
+      int chunks = (HW + rows - 1) / rows;
+      const int cap = gn_chunks(HW);
+      chunks = chunks < 1 ? 1 : (chunks > cap ? cap : chunks);
+      dim3 grid(chunks, NB);
+      if (dtype == MMGT_BF16) {
+        hipLaunchKernelGGL((gn_stats_narrow_kernel<bf16_t, U>), grid, dim3(256), 0, s, (const bf16_t*)x0, workspace, C, HW, G, chunks);
+        hipLaunchKernelGGL((gn_apply_narrow_kernel<bf16_t, U>), grid, dim3(256), 0, s, (const bf16_t*)x0, gamma, beta, workspace,
+                           (bf16_t*)out, C, HW, G, chunks, eps, silu);
+      } else {
+        hipLaunchKernelGGL((gn_stats_narrow_kernel<float, U>), grid, dim3(256), 0, s, (const float*)x0, workspace, C, HW, G, chunks);
+        hipLaunchKernelGGL((gn_apply_narrow_kernel<float, U>), grid, dim3(256), 0, s, (const float*)x0, gamma, beta, workspace,
+                           (float*)out, C, HW, G, chunks, eps, silu);
+      }
+      MMGT_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  const int chunks = gn_chunks_used(HW, C, NB);
+  dim3 grid(chunks, NB);
   // lanes per pixel row: the fewest of 8 / 16 / 32 / 64 whose lanes x MAXS vectors tile the row exactly, so that every lane
   // streams a vector in every load instruction: C = 320 -> 8 lanes x 5 vectors (8 rows per wave instruction), 640 -> 16,
   // 1280 -> 32, 2560 -> 64 (with 64 lanes per row the 40 vectors of a 320-channel row left 24 lanes idle).
   const int maxs = GN_MAXC / (vec * 64);
-  int lpr = 8;
+  int lpr = g_gn_lpr0;
   while (lpr < 64 && (lpr * maxs < nvec || nvec % lpr != 0)) lpr <<= 1;   // ragged rows (C = 960, 1920) measured faster at 64
+  const int il = g_gn_interleave >= 0 ? g_gn_interleave : 1;
   if (dtype == MMGT_BF16) {
     hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x0, C0, (const bf16_t*)x1, C1,
-                       workspace, HW, G, chunks, lpr);
+                       workspace, HW, G, chunks, lpr, il);
     hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x0, C0, (const bf16_t*)x1, C1, gamma,
-                       beta, workspace, (bf16_t*)out, HW, G, chunks, eps, silu, lpr);
+                       beta, workspace, (bf16_t*)out, HW, G, chunks, eps, silu, lpr, il);
   } else {
     hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x0, C0, (const float*)x1, C1,
-                       workspace, HW, G, chunks, lpr);
+                       workspace, HW, G, chunks, lpr, il);
     hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x0, C0, (const float*)x1, C1, gamma,
-                       beta, workspace, (float*)out, HW, G, chunks, eps, silu, lpr);
+                       beta, workspace, (float*)out, HW, G, chunks, eps, silu, lpr, il);
   }
   MMGT_LAUNCH_CHECK();
   return 0;
@@ -445,16 +605,17 @@ extern "C" int mmgt_groupnorm_affine(const void* x, int C, const float* gamma, c
   MMGT_CHECK(C <= GN_MAXC && C % G == 0 && G <= 64 && C % vec == 0, "groupnorm_affine: unsupported channels C=%d G=%d", C, G);
   MMGT_CHECK(NB > 0 && HW > 0 && NB <= 65535, "groupnorm_affine: bad NB=%d HW=%d", NB, HW);
   hipStream_t s = (hipStream_t)stream;
-  const int chunks = gn_chunks_used(HW, C);
+  const int chunks = gn_chunks_used(HW, C, NB);
   dim3 grid(chunks, NB);
   const int nvec = C / vec, maxs = GN_MAXC / (vec * 64);
-  int lpr = 8;
+  int lpr = g_gn_lpr0;
   while (lpr < 64 && (lpr * maxs < nvec || nvec % lpr != 0)) lpr <<= 1;
+  const int il = g_gn_interleave >= 0 ? g_gn_interleave : 1;
   if (dtype == MMGT_BF16) {
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, C, (const bf16_t*)nullptr, 0, workspace, HW, G, chunks, lpr);
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, C, (const bf16_t*)nullptr, 0, workspace, HW, G, chunks, lpr, il);
     hipLaunchKernelGGL(gn_affine_kernel<bf16_t>, dim3(NB), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, workspace, scale, shift, C, HW, G, chunks, eps);
   } else {
-    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, C, (const float*)nullptr, 0, workspace, HW, G, chunks, lpr);
+    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, C, (const float*)nullptr, 0, workspace, HW, G, chunks, lpr, il);
     hipLaunchKernelGGL(gn_affine_kernel<float>, dim3(NB), dim3(256), 0, s, (const float*)x, gamma, beta, workspace, scale, shift, C, HW, G, chunks, eps);
   }
   MMGT_LAUNCH_CHECK();
@@ -472,7 +633,7 @@ extern "C" int mmgt_layernorm(const void* x, long ldx, const float* gamma, const
   MMGT_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)gamma % 16) == 0 &&
                  ((uintptr_t)beta % 16) == 0, "layernorm: pointers must be 16-byte aligned");
   const int nvec = C / vec;
-  int lpr = 8;
+  int lpr = g_gn_lpr0;
   while (lpr < 64 && (nvec % lpr != 0 || nvec / lpr > 5)) lpr <<= 1;
   MMGT_CHECK(nvec % lpr == 0 && nvec / lpr <= 5, "layernorm: C=%d does not map onto 8..64 lanes x <=5 vectors", C);
   const int vpl = nvec / lpr, rows_per_block = 4 * (64 / lpr);

@@ -305,7 +305,32 @@ def test_groupnorm(dt, c0, c1, hw, silu):
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
 
-@pytest.mark.parametrize("c0,c1,hw,eps", [(320, 0, 4096, 1e-5), (640, 320, 1024, 1e-5), (512, 0, 4096, 1e-6), (1280, 0, 64, 1e-6)])
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("c,hw,silu", [(128, 16384, True), (256, 4096, True), (512, 4096, False), (256, 1024, True), (128, 4100, True)])
+def test_groupnorm_narrow_rows(dt, c, hw, silu):
+    """The VAE decoder's shapes (C / VEC in {16, 32, 64}: csrc/norm.hip gn_*_narrow_kernel; hw = 4100 and the fp32 C = 512 case fall back
+    to the general kernels) against torch in fp64, and against the general two-pass kernels on the same input."""
+    from mmgt_amd import hip
+    nb = 2
+    x = rnd("nx", (nb, hw, c), 1.5, dt) + rnd("nx.mean", (c,), 2.0).to(dt)
+    g = rnd("g", (c,), 0.2) + 1.0
+    b = rnd("b", (c,), 0.2)
+    ref = F.group_norm(x.double().permute(0, 2, 1), 32, g.double(), b.double(), 1e-6).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    out = hip.groupnorm(x, g, b, 32, 1e-6, silu=silu)
+    torch.testing.assert_close(out.double(), ref, **tol(dt))
+    assert torch.equal(out, hip.groupnorm(x, g, b, 32, 1e-6, silu=silu))          # fixed-order reductions: bitwise reproducible
+    hip.tune("gn_narrow", 0)
+    try:
+        general = hip.groupnorm(x, g, b, 32, 1e-6, silu=silu)
+    finally:
+        hip.tune("gn_narrow", 1)
+    torch.testing.assert_close(out.double(), general.double(), **tol(dt))
+
+
+@pytest.mark.parametrize("c0,c1,hw,eps", [(320, 0, 4096, 1e-5), (640, 320, 1024, 1e-5), (512, 0, 4096, 1e-6), (1280, 0, 64, 1e-6),
+                                          (128, 0, 8192, 1e-6), (256, 0, 4096, 1e-6)])
 def test_groupnorm_mean_much_larger_than_std_fp32(c0, c1, hw, eps):
     """Real SD-1.5 / VAE activations have channels whose |mean| is 30-100x their std: the statistics
     must not lose the variance to cancellation.  Per-channel means up to +-100 with unit-scale noise, a few whole groups
