@@ -123,6 +123,18 @@ int mmgt_attention(const void* q, long q_bs0, long q_bs1, long q_ts, const void*
 int mmgt_softmax_rows(const void* x, long ldx, void* out, long ldo, int rows, int cols, float scale, int dtype,
                       void* stream);
 
+/* The bf16 path of the VAE mid-block attention (one 512-wide head over 4096 tokens per frame; replaces diffusers 0.24.0
+ * `Attention` as called by `AutoencoderKL.decode` at pipeline_pose2vid_long.py:112-125).  Its logits reach hundreds with
+ * sd-vae-ft-mse weights, so q . k keeps ~17 bits through hi / lo bf16 operand pieces on the bf16 MFMA path instead of an fp32 GEMM:
+ *   mmgt_gemm_bf16_f32          out fp32 [M][ldo] = A bf16 [M][lda] . W bf16 [N][ldw]^T, raw accumulators, no epilogue
+ *                               (K % 64 == 0, N % 8 == 0);
+ *   mmgt_qk_split3              qk fp32 [rows][4C] = [t Wq_hi^T | t Wq_lo^T | t Wk_hi^T | t Wk_lo^T]  ->  q = qk0 + qk1 + bias_q,
+ *                               k = qk2 + qk3 + bias_k,  Qp bf16 [rows][3C] = [q_hi | q_hi | q_lo],  Kp = [k_hi | k_lo | k_hi];
+ *   mmgt_softmax_rows_f32_bf16  fp32 logits -> bf16 probabilities in one pass (cols a multiple of 256, at most 8192). */
+int mmgt_gemm_bf16_f32(const void* A, long lda, const void* W, long ldw, float* out, long ldo, int M, int N, int K, void* stream);
+int mmgt_qk_split3(const float* qk, const float* bias_q, const float* bias_k, void* Qp, void* Kp, long rows, int C, void* stream);
+int mmgt_softmax_rows_f32_bf16(const float* x, long ldx, void* out, long ldo, int rows, int cols, float scale, void* stream);
+
 /* Layout / dtype plumbing between the reference's (b, c, f, h, w) fp32 tensors and channels-last T:
  * out[(b*F + f), y, x, c] (c padded with zeros up to Cpad) <- in[b, c, f, y, x]; and the inverse (first C channels).
  * Replaces: the einops rearranges at resnet.py:13-15; transformer_3d.py:158,178-180,248-252,264. */

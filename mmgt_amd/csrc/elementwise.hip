@@ -140,8 +140,76 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__
   for (int c = lane; c < cols; c += 64) Elem<T>::st(out + row * ldo + c, __expf(Elem<T>::ld(xr + c) * scale - m) * inv);
 }
 
-}  // namespace
+// fp32 logits -> bf16 probabilities, one wave per row held in registers (cols = 256 * NV): one read, one write (the generic kernel above
+// makes three scalar passes over a row).  The VAE mid-block attention: 32768 rows x 4096.
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_f32_bf16_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ out, long ldo,
+                                                                    int rows, float scale) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long row = (long)blockIdx.x * 4 + wid;
+  if (row >= rows) return;
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * ldx);
+  f32x4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = xr[i * 64 + lane];
+  float m = -1e30f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] *= scale;
+    m = fmaxf(m, fmaxf(fmaxf(v[i][0], v[i][1]), fmaxf(v[i][2], v[i][3])));
+  }
+  m = wave_max(m);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[i][e] = __expf(v[i][e] - m); s += v[i][e]; }
+  }
+  s = wave_sum(s);
+  const float inv = 1.f / s;
+  u32x2* orow = reinterpret_cast<u32x2*>(out + row * ldo);
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    orow[i * 64 + lane] = (u32x2){pack_bf16x2(v[i][0] * inv, v[i][1] * inv), pack_bf16x2(v[i][2] * inv, v[i][3] * inv)};
+}
 
+// q / k of the VAE attention as hi / lo bf16 pieces for a three-term product on the bf16 MFMA path:
+//   qk [rows][4 C] fp32 = [t Wq_hi^T | t Wq_lo^T | t Wk_hi^T | t Wk_lo^T]  (mmgt_gemm_bf16_f32 against the stacked weight pieces)
+//   q = qk[0] + qk[1] + bias_q, k = qk[2] + qk[3] + bias_k, x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
+//   Qp [rows][3 C] = [q_hi | q_hi | q_lo],  Kp [rows][3 C] = [k_hi | k_lo | k_hi]   ->   Qp . Kp = q_hi k_hi + q_hi k_lo + q_lo k_hi,
+// i.e. q . k without the lo x lo term: relative error ~2^-17 per product against 2^-9 for plain bf16 operands.
+__global__ __launch_bounds__(256) void qk_split3_kernel(const float* __restrict__ qk, const float* __restrict__ bias_q,
+                                                        const float* __restrict__ bias_k, bf16_t* __restrict__ Qp, bf16_t* __restrict__ Kp,
+                                                        long rows, int C) {
+  const int nv = C / 4;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * nv) return;
+  const long r = idx / nv;
+  const int c = (int)(idx - r * nv) * 4;
+  const float* src = qk + r * 4 * C + c;
+  const f32x4 q = *reinterpret_cast<const f32x4*>(src) + *reinterpret_cast<const f32x4*>(src + C) + *reinterpret_cast<const f32x4*>(bias_q + c);
+  const f32x4 k = *reinterpret_cast<const f32x4*>(src + 2 * C) + *reinterpret_cast<const f32x4*>(src + 3 * C) +
+                  *reinterpret_cast<const f32x4*>(bias_k + c);
+  auto split = [](const f32x4& x, u32x2& hi, u32x2& lo) {
+    hi = (u32x2){pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3])};
+    const float h0 = __uint_as_float(hi[0] << 16), h1 = __uint_as_float(hi[0] & 0xffff0000u);
+    const float h2 = __uint_as_float(hi[1] << 16), h3 = __uint_as_float(hi[1] & 0xffff0000u);
+    lo = (u32x2){pack_bf16x2(x[0] - h0, x[1] - h1), pack_bf16x2(x[2] - h2, x[3] - h3)};
+  };
+  u32x2 qh, ql, kh, kl;
+  split(q, qh, ql);
+  split(k, kh, kl);
+  bf16_t* qd = Qp + r * 3 * C + c;
+  bf16_t* kd = Kp + r * 3 * C + c;
+  *reinterpret_cast<u32x2*>(qd) = qh;
+  *reinterpret_cast<u32x2*>(qd + C) = qh;
+  *reinterpret_cast<u32x2*>(qd + 2 * C) = ql;
+  *reinterpret_cast<u32x2*>(kd) = kh;
+  *reinterpret_cast<u32x2*>(kd + C) = kl;
+  *reinterpret_cast<u32x2*>(kd + 2 * C) = kh;
+}
+
+}  // namespace
 
 extern "C" int mmgt_ncfhw_to_nhwc(const float* in, void* out, int B, int C, int F, int H, int W, int Cpad, float scale,
                                   int dtype, void* stream) {
@@ -245,6 +313,36 @@ extern "C" int mmgt_softmax_rows(const void* x, long ldx, void* out, long ldo, i
   else
     hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx,
                        (float*)out, ldo, rows, cols, scale);
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmgt_softmax_rows_f32_bf16(const float* x, long ldx, void* out, long ldo, int rows, int cols, float scale, void* stream) {
+  MMGT_CHECK(x && out && rows > 0, "softmax_rows_f32_bf16: bad arguments");
+  MMGT_CHECK(cols % 256 == 0 && cols >= 256 && cols <= 8192 && ldx % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)x % 16) == 0 &&
+                 ((uintptr_t)out % 8) == 0,
+             "softmax_rows_f32_bf16: cols must be a multiple of 256 up to 8192 with aligned rows (cols=%d)", cols);
+  dim3 grid((rows + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  bf16_t* o = reinterpret_cast<bf16_t*>(out);
+  switch (cols / 256) {
+#define SM_CASE(NV_) case NV_: hipLaunchKernelGGL(softmax_rows_f32_bf16_kernel<NV_>, grid, dim3(256), 0, s, x, ldx, o, ldo, rows, scale); break
+    SM_CASE(1); SM_CASE(2); SM_CASE(3); SM_CASE(4); SM_CASE(6); SM_CASE(8); SM_CASE(12); SM_CASE(16); SM_CASE(24); SM_CASE(32);
+#undef SM_CASE
+    default: MMGT_CHECK(false, "softmax_rows_f32_bf16: cols / 256 = %d has no instantiation", cols / 256);
+  }
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmgt_qk_split3(const float* qk, const float* bias_q, const float* bias_k, void* Qp, void* Kp, long rows, int C, void* stream) {
+  MMGT_CHECK(qk && bias_q && bias_k && Qp && Kp && rows > 0 && C > 0 && C % 4 == 0, "qk_split3: bad arguments");
+  MMGT_CHECK(((uintptr_t)qk % 16) == 0 && ((uintptr_t)bias_q % 16) == 0 && ((uintptr_t)bias_k % 16) == 0 && ((uintptr_t)Qp % 8) == 0 &&
+                 ((uintptr_t)Kp % 8) == 0, "qk_split3: misaligned pointer");
+  const long total = rows * (C / 4);
+  MMGT_CHECK(total < (1l << 31) * 256, "qk_split3: too large");
+  hipLaunchKernelGGL(qk_split3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, qk, bias_q, bias_k,
+                     reinterpret_cast<bf16_t*>(Qp), reinterpret_cast<bf16_t*>(Kp), rows, C);
   MMGT_LAUNCH_CHECK();
   return 0;
 }

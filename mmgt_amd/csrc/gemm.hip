@@ -798,7 +798,8 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     if (MODE == 1) {
       if (b16 && N % 320 == 0 && (M >= 49152 || (M >= 24576 && N >= 640))) cfg = 17;   // (12-frame windows: the 32x32-level convs, -7..-9 % against 128x128)
       else if (b16 && N % 256 == 0 && tiles256sq >= 192) cfg = 16;
-      else cfg = (N % 320 == 0 && M >= 49152) ? 12 : big_ok ? 9 : tiles128 < 512 ? 3 : 1;
+      else cfg = (N % 320 == 0 && M >= 49152) ? 12 : big_ok ? 9 : (tiles128 < 512 || N <= 64) ? 3 : 1;   // (N <= 64: conv_out's 3 / 4 channels padded
+                                                                                                         //  to 64 -- VAE 8 x 512^2 x 128 -> 64: 651 -> 503 us on the 128x64 tile)
     } else if (b16 && !geglu && N % 320 == 0 && N <= 960 && M >= 131072) cfg = 17;
     else if (b16 && !geglu && N % 320 == 0 && N <= 1280 && M >= 49152 && (K >= 1280 || ep.residual || N == 1280)) cfg = 17;   // 32x32 level
     else if (sq_ok) cfg = b16 ? 16 : 9;

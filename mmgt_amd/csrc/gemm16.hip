@@ -625,6 +625,29 @@ int mmgt_gemm16_splitk(int mode, int bn, const void* adp, const void* W, const v
   return 0;
 }
 
+// bf16 operands, RAW fp32 accumulators out: out[m][n] = sum_k A[m][k] * W[n][k], no epilogue -- the split-K slab writer with one slice that
+// covers the whole reduction.  For products whose result must keep more than a bf16 mantissa (the VAE's 512-wide attention logits, fed
+// with hi / lo split operands: mmgt_amd/vae.py).  K % 64 == 0, N % 8 == 0, 16-byte aligned rows.
+extern "C" int mmgt_gemm_bf16_f32(const void* A, long lda, const void* W, long ldw, float* out, long ldo, int M, int N, int K, void* stream) {
+  MMGT_CHECK(A && W && out && M > 0 && N > 0 && K > 0, "gemm_bf16_f32: bad arguments");
+  MMGT_CHECK(K % 64 == 0 && N % 8 == 0 && lda >= K && ldw >= K && ldo >= N && lda % 8 == 0 && ldw % 8 == 0 && ldo % 4 == 0,
+             "gemm_bf16_f32: unsupported shape M=%d N=%d K=%d lda=%ld ldw=%ld ldo=%ld", M, N, K, lda, ldw, ldo);
+  MMGT_CHECK(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0, "gemm_bf16_f32: pointers must be 16-byte aligned");
+  MMGT_CHECK(((long)(M - 1) * lda + K) * 2 < (1l << 31) && ((long)(N - 1) * ldw + K) * 2 < (1l << 31),
+             "gemm_bf16_f32: an operand exceeds the 2 GiB range of the 32-bit LDS-DMA offsets");
+  ADesc ad{};
+  ad.src0 = reinterpret_cast<const char*>(A);
+  ad.ld0 = lda;
+  ad.ksplit = 1;
+  ad.ldw = (int)ldw;
+  Epi pe{};
+  pe.out = reinterpret_cast<char*>(out);
+  pe.ldo = ldo;
+  pe.alpha = 1.f;
+  pe.fast = 1;
+  return launch16<0, 256>(ad, W, 0, pe, M, N, K, 1, (hipStream_t)stream);
+}
+
 // Entry for gemm.hip's dispatcher.  Preconditions (checked there): bf16, vectorised epilogue (ep.fast), act in {none, GEGLU}
 // (GEGLU with bn = 256 only and without row scale / alpha / post-scale bias), 16-byte aligned bias vectors, K % 64 == 0.
 int mmgt_gemm16_launch(int mode, int bn, const void* adp, const void* W, long bsw, const void* epp, int M, int N, int K,

@@ -40,6 +40,9 @@ _SIGS = {
                                c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                c_int, c_int, c_void_p]),
     "mmgt_softmax_rows": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_float, c_int, c_void_p]),
+    "mmgt_gemm_bf16_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p]),
+    "mmgt_qk_split3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
+    "mmgt_softmax_rows_f32_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_float, c_void_p]),
     "mmgt_ncfhw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "mmgt_nhwc_to_ncfhw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                    c_int, c_void_p]),
@@ -433,6 +436,44 @@ def softmax_rows(x, scale=1.0, out=None):
     _check(lib().mmgt_softmax_rows(_ptr(x), x.stride(0), _ptr(out), out.stride(0), x.shape[0], x.shape[1], scale,
                                    dtype_code(x.dtype), _stream()), "mmgt_softmax_rows")
     return out
+
+
+def softmax_rows_f32_bf16(x, scale, out):
+    """fp32 logits (rows, cols) -> bf16 probabilities, one pass (cols a multiple of 256, <= 8192)."""
+    _dev(x, out)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
+    assert out.shape == x.shape and out.stride(1) == 1 and out.dtype == torch.bfloat16
+    _check(lib().mmgt_softmax_rows_f32_bf16(_ptr(x), x.stride(0), _ptr(out), out.stride(0), x.shape[0], x.shape[1], scale, _stream()),
+           "mmgt_softmax_rows_f32_bf16")
+    return out
+
+
+def gemm_bf16_f32(a, w, out=None):
+    """out fp32 (M, N) = a bf16 (M, K) @ w bf16 (N, K)^T: the raw fp32 accumulators of the bf16 MFMA path (K % 64 == 0, N % 8 == 0)."""
+    _dev(a, w, out)
+    assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1] and a.stride(1) == 1 and w.stride(1) == 1
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    assert out.shape == (M, N) and out.dtype == torch.float32 and out.stride(1) == 1
+    _check(lib().mmgt_gemm_bf16_f32(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(out), out.stride(0), M, N, K, _stream()),
+           "mmgt_gemm_bf16_f32")
+    return out
+
+
+def qk_split3(qk, bias_q, bias_k):
+    """qk fp32 (rows, 4C) = [t Wq_hi^T | t Wq_lo^T | t Wk_hi^T | t Wk_lo^T] -> (Qp, Kp) bf16 (rows, 3C): [q_hi|q_hi|q_lo], [k_hi|k_lo|k_hi]
+    with q = qk0 + qk1 + bias_q, k = qk2 + qk3 + bias_k (so that Qp . Kp = q . k to ~17 bits on the bf16 MFMA path)."""
+    _dev(qk, bias_q, bias_k)
+    assert qk.dim() == 2 and qk.is_contiguous() and qk.dtype == torch.float32 and qk.shape[1] % 16 == 0
+    rows, C = qk.shape[0], qk.shape[1] // 4
+    assert bias_q.shape == (C,) and bias_k.shape == (C,) and bias_q.dtype == torch.float32 and bias_k.dtype == torch.float32
+    Qp = torch.empty((rows, 3 * C), device=qk.device, dtype=torch.bfloat16)
+    Kp = torch.empty((rows, 3 * C), device=qk.device, dtype=torch.bfloat16)
+    _check(lib().mmgt_qk_split3(_ptr(qk), _ptr(bias_q), _ptr(bias_k), _ptr(Qp), _ptr(Kp), rows, C, _stream()), "mmgt_qk_split3")
+    return Qp, Kp
 
 
 # ------------------------------------------------------------------------------------------------------------ plumbing

@@ -5,7 +5,8 @@ Mirrors what src/pipelines/pipeline_pose2vid_long.py:112-125 asks of diffusers' 
 diffusers 0.24.0 state-dict key names so `sd-vae-ft-mse` checkpoints load by name.  All frames of a clip are decoded as
 one channels-last batch (the reference loops frame by frame; every op is per-frame, so results are identical) on the same
 HIP kernels as the UNet: implicit-GEMM conv3x3 (fused nearest-2x upsample), GroupNorm+SiLU, GEMM; the single 512-wide
-attention head of the mid block uses materialised scores (GEMM -> row softmax -> GEMM), 34 GFLOP per frame.
+attention head of the mid block uses materialised scores (GEMM -> row softmax -> GEMM), 34 GFLOP per frame, whose logits keep
+~17 bits in the bf16 model through hi / lo operand pieces (`_mid_attention_split`).
 """
 from collections import OrderedDict
 
@@ -120,6 +121,7 @@ class AutoencoderKL:
         self.w = {}
         self._loaded = False
         self._has_encoder = False
+        self._split_attention = True       # False: the fp32 kernels for the mid-block attention of a bf16 model too (A/B, tests)
 
     @property
     def dtype(self):
@@ -167,11 +169,12 @@ class AutoencoderKL:
                 m = wt.reshape(wt.shape[0], -1)
                 w[p + ".w"] = self._t(pad_rows(pad_cols(m, round_up(m.shape[1], 64)), round_up(m.shape[0], 64)))
                 w[p + ".bias"] = self._f(pad_rows(b, round_up(m.shape[0], 64)))
-        f32 = lambda t: t.to(torch.float32)
         for a in ["decoder.mid_block.attentions.0"] + (["encoder.mid_block.attentions.0"] if enc_present else []):
-            # The single 512-wide head runs in the fp32 instantiation of the kernels whatever the model dtype: with real
-            # sd-vae-ft-mse weights the logits reach hundreds, where a bf16 score has an ulp of 1-2; the reference
-            # runs this block in fp16/fp32.  34 GFLOP per frame: 0.3 ms at the fp32 MFMA rate, against ~100 ms of convs.
+            # The single 512-wide head: with real sd-vae-ft-mse weights the logits reach hundreds, where a bf16 score -- or a score of
+            # bf16-rounded q / k -- has an ulp of 1-2; the reference runs this block in fp16 / fp32.
+            #   fp32 model: the fp32 instantiation of the kernels throughout (materialised scores, 34 GFLOP per frame);
+            #   bf16 model: the logits keep ~17 bits through hi / lo bf16 operand pieces on the bf16 MFMA path (_mid_attention_split):
+            #               W = W_hi + W_lo for the q / k projections, q = q_hi + q_lo and k likewise for the scores.
             w[a + ".q.w"], w[a + ".q.bias"] = self._f(sd[a + ".to_q.weight"]), self._f(sd[a + ".to_q.bias"])
             w[a + ".k.w"], w[a + ".k.bias"] = self._f(sd[a + ".to_k.weight"]), self._f(sd[a + ".to_k.bias"])
             w[a + ".v.w"] = self._f(sd[a + ".to_v.weight"])
@@ -180,6 +183,15 @@ class AutoencoderKL:
             # (W_o b_v as an fp32 GEMM with one output column, on the device like every other product of this library)
             wob = hip.gemm(w[a + ".o.w"], self._f(sd[a + ".to_v.bias"])[None, :].contiguous()).reshape(-1)
             w[a + ".o.bias"] = (wob + self._f(sd[a + ".to_out.0.bias"])).contiguous()
+            if self._dtype == torch.bfloat16:
+                def hi_lo(m):
+                    hi = m.to(torch.bfloat16)
+                    return hi, (m - hi.float()).to(torch.bfloat16)
+                qh, ql = hi_lo(w[a + ".q.w"])
+                kh, kl = hi_lo(w[a + ".k.w"])
+                w[a + ".qk.w4"] = torch.cat([qh, ql, kh, kl], 0).contiguous()            # (4C, C): rows = the four output blocks
+                w[a + ".v.wb"] = w[a + ".v.w"].to(torch.bfloat16).contiguous()
+                w[a + ".o.wb"] = w[a + ".o.w"].to(torch.bfloat16).contiguous()
         self._loaded = True
         self._has_encoder = bool(enc_present)
         return [], [k for k in sd if k not in spec]
@@ -200,6 +212,8 @@ class AutoencoderKL:
         return hip.conv3x3(hdn, self.w[p + ".conv2.w"], self.w[p + ".conv2.bias"], residual=res)
 
     def _mid_attention(self, x, a="decoder.mid_block.attentions.0"):
+        if self._split_attention and self._dtype == torch.bfloat16 and x.shape[1] * x.shape[2] % 256 == 0 and x.shape[1] * x.shape[2] <= 8192:
+            return self._mid_attention_split(x, a)
         nb, h, ww, c = x.shape
         n = h * ww
         t = self._gn(a + ".group_norm", x, False).view(nb * n, c).float()                    # fp32 from here (see load_state_dict)
@@ -214,6 +228,31 @@ class AutoencoderKL:
         hip.gemm_batched(s_, vt, out=o)
         out = hip.gemm(o.view(nb * n, c), self.w[a + ".o.w"], self.w[a + ".o.bias"], residual=x.view(nb * n, c).float())
         return out.to(self._dtype).view(nb, h, ww, c)
+
+    def _mid_attention_split(self, x, a):
+        """The bf16 model's mid-block attention on the bf16 MFMA path.  Only the logits need more than a bf16 mantissa, and they get it
+        from operand PIECES: t (bf16, exact) times [Wq_hi; Wq_lo; Wk_hi; Wk_lo] with fp32 accumulators out gives q and k to fp32 accuracy;
+        q = q_hi + q_lo, k = k_hi + k_lo then give q . k = q_hi k_hi + q_hi k_lo + q_lo k_hi (+ O(2^-17)) as ONE bf16 GEMM over the
+        concatenated reduction [q_hi | q_hi | q_lo] . [k_hi | k_lo | k_hi] (K = 3 C), fp32 logits out.  softmax -> bf16 probabilities in
+        one pass; P V and the output projection are ordinary bf16 GEMMs (their operands are in [0, 1] / activations like any other layer's)."""
+        nb, h, ww, c = x.shape
+        n = h * ww
+        w = self.w
+        t = self._gn(a + ".group_norm", x, False).view(nb * n, c)
+        qk = hip.gemm_bf16_f32(t, w[a + ".qk.w4"])                                             # (nb n, 4C) fp32
+        Qp, Kp = hip.qk_split3(qk, w[a + ".q.bias"], w[a + ".k.bias"])                         # (nb n, 3C) bf16 each
+        del qk
+        vt = torch.empty((nb, c, n), device=self._device, dtype=torch.bfloat16)
+        hip.gemm_batched_wx(w[a + ".v.wb"], t.view(nb, n, c), out=vt)                          # V^T without its bias
+        p = torch.empty((nb, n, n), device=self._device, dtype=torch.bfloat16)
+        s_ = torch.empty((n, n), device=self._device, dtype=torch.float32)
+        for f in range(nb):                                                                    # 256 tiles of 256 x 256 per frame: one per CU
+            hip.gemm_bf16_f32(Qp[f * n:(f + 1) * n], Kp[f * n:(f + 1) * n], out=s_)
+            hip.softmax_rows_f32_bf16(s_, c ** -0.5, out=p[f])
+        o = torch.empty((nb, n, c), device=self._device, dtype=torch.bfloat16)
+        hip.gemm_batched(p, vt, out=o)
+        out = hip.gemm(o.view(nb * n, c), w[a + ".o.wb"], w[a + ".o.bias"], residual=x.view(nb * n, c))
+        return out.view(nb, h, ww, c)
 
     # ------------------------------------------------------------------------------------------------ API
     def decode_nhwc(self, z):

@@ -82,6 +82,10 @@ SETS = {
         gemm_case(1536, 1280, 1280, res=True), gemm_case(1536, 1280, 5120, res=True), gemm_case(1536, 10240, 1280, act=1),
         conv_case(24, 64, 320, 320), conv_case(24, 64, 640, 320), conv_case(24, 32, 640, 640), conv_case(24, 32, 1920, 640),
         conv_case(24, 16, 1280, 1280), conv_case(24, 16, 2560, 1280), conv_case(24, 8, 1280, 1280), conv_case(24, 8, 2560, 1280)],
+    # the VAE decoder at 8 frames of 512 x 512 (tools/profile_vae.py)
+    "vae": lambda: [conv_case(8, 512, 128, 128), conv_case(8, 512, 256, 128), conv_case(8, 512, 128, 64), conv_case(8, 256, 256, 256),
+                    conv_case(8, 256, 512, 256), conv_case(8, 128, 512, 512), conv_case(8, 64, 512, 512), conv_case(8, 256, 256, 256, up=True),
+                    gemm_case(2097152, 128, 256), gemm_case(524288, 256, 512)],
     "big": lambda: [gemm_case(8192, 8192, 8192, bias=False), gemm_case(4096, 4096, 4096, bias=False)],
     "step": lambda: [
         gemm_case(196608, 2560, 320, act=1), gemm_case(49152, 5120, 640, act=1), gemm_case(12288, 10240, 1280, act=1),

@@ -21,6 +21,9 @@ def key_of(name, args, kw):
         epi = ("geglu" if kw.get("act") == hip.ACT_GEGLU else "") + ("+res" if kw.get("residual") is not None else "") + \
               ("+b2" if kw.get("bias2") is not None else "") + ("+rs" if kw.get("row_scale") is not None else "")
         return f"gemm M={a.shape[0]} N={w.shape[0]} K={a.shape[1]} {epi}", 2 * a.shape[0] * w.shape[0] * a.shape[1]
+    if name == "gemm_bf16_f32":
+        a, w = args[0], args[1]
+        return f"gemm_bf16_f32 M={a.shape[0]} N={w.shape[0]} K={a.shape[1]} (bf16 pieces -> fp32)", 2 * a.shape[0] * w.shape[0] * a.shape[1]
     if name == "gemm_post":
         a, w = args[0], args[1]
         return f"gemm_post M={a.shape[0]} N={w.shape[0]} K={a.shape[1]} +rs+post+res", 2 * a.shape[0] * w.shape[0] * a.shape[1]

@@ -22,7 +22,8 @@ def main():
     vae.load_state_dict(synth_state_dict(vae.spec, prefix="vae.", device=dev))
     lat = hash_uniform("pv.lat", (1, 4, frames, 64, 64), 1.0).to(dev)
     vae.decode_video(lat, frames_per_batch=frames)                      # warm-up
-    for n in ["gemm", "gemm_batched", "gemm_batched_wx", "conv3x3", "groupnorm", "attention", "softmax_rows", "nhwc_to_ncfhw", "ncfhw_to_nhwc"]:
+    for n in ["gemm", "gemm_batched", "gemm_batched_wx", "conv3x3", "groupnorm", "attention", "softmax_rows", "nhwc_to_ncfhw", "ncfhw_to_nhwc",
+              "gemm_bf16_f32", "qk_split3", "softmax_rows_f32_bf16"]:
         if hasattr(hip, n):
             P.wrap(n)
     torch.cuda.synchronize()
