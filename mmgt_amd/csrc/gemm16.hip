@@ -50,7 +50,7 @@ __device__ __forceinline__ acc4 mma16(s16x8 a, s16x8 b, acc4 c) {
 
 template <int MODE, int BN>
 __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __restrict__ W, long bsw, Epi ep, int M, int N,
-                                                        int K, int tiles_m, int tiles_n, unsigned long long* trace) {
+                                                        int K, int tiles_m, int tiles_n, int pb, unsigned long long* trace) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   typedef bf16_t T;
   static_assert(BN == 256 || BN == 320, "BN");
@@ -73,11 +73,22 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
     if (trace && (wid & 3) == 0 && lane == 0 && trace_n < 32) trace[(((long)blockIdx.x * 32 + trace_n) * 2 + wr) * 4 + k] = wall_clock64();
   };
 
-  auto decode = [&](int v, int& tm, int& tn) {  // XCD-aware virtual tile order (see gemm.hip)
+  // XCD-aware virtual tile order (see gemm.hip): XCD x = v & 7 walks a contiguous run of the tile sequence t.  The sequence itself is
+  // row-major in groups of `pb` row panels that are walked COLUMN-major inside: the ~32 tiles an XCD works on at any moment then cover
+  // pb panels x 32 / pb column tiles -- pb A panels + 32 / pb W panels through its 4 MB L2 instead of ~1 + min(32, tiles_n) (wide outputs:
+  // N = 5120 / 10240 GEGLU, 3840 / 1920 q|k|v re-fetched W from the fabric once per row panel).  pb = 1: plain row-major.
+  auto decode = [&](int v, int& tm, int& tn) {
     const int q = nwg >> 3, r = nwg & 7, x = v & 7;
     const int t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (v >> 3);
-    tm = t / tiles_n;
-    tn = t - tm * tiles_n;
+    if (pb <= 1) {
+      tm = t / tiles_n;
+      tn = t - tm * tiles_n;
+    } else {
+      const int gsz = pb * tiles_n, g = t / gsz, w = t - g * gsz;
+      const int pbe = min(pb, tiles_m - g * pb);
+      tn = w / pbe;
+      tm = g * pb + (w - tn * pbe);
+    }
   };
 
   // ---- LDS-DMA source addressing (as gemm.hip): wave `wid` fills the 8-row pieces g = wid * GA + i of each operand
@@ -512,6 +523,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
 }
 
 unsigned long long* g_trace = nullptr;
+int g_pb = -1;   // mmgt_tune("g16_pb", v): row panels per column-major group of the tile order (-1 = by shape, 1 = row-major)
 
 template <int MODE, int BN>
 int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
@@ -538,7 +550,9 @@ int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int
   gx = (gx + 7) / 8 * 8;
   if (gx > (long)tiles_m * tiles_n) gx = (long)tiles_m * tiles_n;
   dim3 grid((unsigned)gx, 1, batch);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, ad, reinterpret_cast<const char*>(W), bsw, ep, M, N, K, tiles_m, tiles_n, g_trace);
+  // (measured, tools/ab_cfg.py G16_PB=1,4,8: see DESIGN.md; convs and narrow outputs keep the row-major order)
+  const int pb = g_pb >= 0 ? g_pb : (MODE == 0 && tiles_n >= 8 && tiles_m >= 8) ? 8 : 1;
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, ad, reinterpret_cast<const char*>(W), bsw, ep, M, N, K, tiles_m, tiles_n, pb, g_trace);
   MMGT_LAUNCH_CHECK();
   return 0;
 }
@@ -547,6 +561,7 @@ int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int
 
 // Debug (tools/trace_gemm16.py): a device buffer of [grid][32 tiles][2 groups][4 stamps] u64 receives 100-MHz time stamps.
 extern "C" void mmgt_gemm16_set_trace(void* p) { g_trace = reinterpret_cast<unsigned long long*>(p); }
+void mmgt_gemm16_set_pb(int v) { g_pb = v; }
 
 namespace {
 

@@ -305,6 +305,30 @@ def test_groupnorm(dt, c0, c1, hw, silu):
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
 
+@pytest.mark.parametrize("M,N", [(256 * 11 + 37, 256 * 9), (256 * 8, 256 * 8 + 64), (256 * 21, 256 * 40)])
+def test_gemm16_blocked_tile_order_is_a_permutation(M, N):
+    """gemm16's tile sequence is row-major in groups of 8 row panels walked column-major (csrc/gemm16.hip `decode`): every tile is still
+    computed exactly once by the same arithmetic, so the result is bitwise the row-major one -- ragged last group, ragged last tiles."""
+    from mmgt_amd import hip
+    K = 320
+    a = rnd("pb.a", (M, K), 1.0, torch.bfloat16)
+    w = rnd("pb.w", (N, K), K ** -0.5, torch.bfloat16)
+    b = rnd("pb.b", (N,), 0.5)
+    hip.tune("gemm_cfg", 16)
+    try:
+        hip.tune("g16_pb", 1)
+        row_major = hip.gemm(a, w, b)
+        hip.tune("g16_pb", 8)
+        blocked = hip.gemm(a, w, b)
+        hip.tune("g16_pb", 5)
+        odd = hip.gemm(a, w, b)
+    finally:
+        hip.tune("g16_pb", -1)
+        hip.tune("gemm_cfg", 0)
+    assert torch.equal(row_major, blocked) and torch.equal(row_major, odd)
+    torch.testing.assert_close(row_major.double(), ref_gemm(a, w) + b.double(), **tol(torch.bfloat16))
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("c,hw,silu", [(128, 16384, True), (256, 4096, True), (512, 4096, False), (256, 1024, True), (128, 4100, True)])
 def test_groupnorm_narrow_rows(dt, c, hw, silu):

@@ -4,6 +4,7 @@ run under each forced `gemm_cfg` (0 = the dispatcher's own choice) in interleave
 
     CFGS=0,9,16 SET=step python tools/ab_cfg.py          # the denoise step's heavy shapes (profiles/r1/opshapes)
     CFGS=9,16 SET=big python tools/ab_cfg.py             # 8192^3 and friends
+    AB=g16_pb:1,4,8 SET=step python tools/ab_cfg.py      # another mmgt_tune key instead of gemm_cfg
 """
 import math
 import os
@@ -100,13 +101,17 @@ SETS = {
 
 if __name__ == "__main__":
     cfgs = [int(c) for c in os.environ.get("CFGS", "0,16").split(",")]
+    key = "gemm_cfg"
+    if os.environ.get("AB"):                       # AB=g16_pb:1,4,8 -> A/B over another mmgt_tune key instead of the tile configuration
+        key, vals = os.environ["AB"].split(":")
+        cfgs = [int(c) for c in vals.split(",")]
     rounds = int(os.environ.get("ROUNDS", "5"))
     for name, fn, flops, out in SETS[os.environ.get("SET", "step")]():
         times = {c: [] for c in cfgs}
         outs = {}
         for r in range(rounds + 1):
             for c in cfgs:
-                hip.tune("gemm_cfg", c)
+                hip.tune(key, c)
                 t = time_call(fn)
                 if r:
                     times[c].append(t)
@@ -119,4 +124,4 @@ if __name__ == "__main__":
             mn, md = min(times[c]), statistics.median(times[c])
             cells.append(f"c{c}: {mn:7.1f}/{md:7.1f}us {flops / mn / 1e6:5.0f}TF d={d:.1e}")
         print(f"{name:44s} | " + " | ".join(cells), flush=True)
-    hip.tune("gemm_cfg", 0)
+    hip.tune(key, 0 if key == "gemm_cfg" else -1)
