@@ -238,6 +238,27 @@ def extras(pipe, unet, dev, dtype):
     tf = VAE_TFLOP_PER_FRAME / (ms / 1e3)
     res["vae_decode"] = {"ms_per_frame": ms, "ms_per_24_frame_clip": ms * 24, "achieved": tf, "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": tf / PEAK_BF16_TFLOPS, "tflop_per_frame": VAE_TFLOP_PER_FRAME}
+    # the decoder's HBM-bound kernel (GroupNorm + SiLU at 512 x 512 x 128: two reads + one write of a 537 MB tensor) and the split-operand
+    # logits GEMM of its mid-block attention (q . k as three bf16 products over one 3C-long reduction, fp32 out)
+    from mmgt_amd import hip
+    x = hash_uniform("bench.vae_gn", (8, 512 * 512, 128), 1.0).to(dev).to(dtype)
+    g, b = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+    o = torch.empty_like(x)
+    gms = _time_ms(lambda: hip.groupnorm(x, g, b, 32, 1e-6, silu=True, out=o), reps=5, warm=2)
+    by = 3.0 * x.numel() * 2
+    kern = [{"kernel": "groupnorm+silu 8x262144x128 (VAE up_blocks.3)", "bound": "hbm", "ms": gms, "achieved": by / gms / 1e6, "peak": 8000.0,
+             "unit": "GB/s", "frac": by / gms / 1e6 / 8000.0}]
+    del x, o
+    if dtype == torch.bfloat16:
+        qp = hash_uniform("bench.vae_qp", (4096, 1536), 1.0).to(dev).to(dtype)
+        kp = hash_uniform("bench.vae_kp", (4096, 1536), 1.0).to(dev).to(dtype)
+        so = torch.empty((4096, 4096), device=dev, dtype=torch.float32)
+        lms = _time_ms(lambda: hip.gemm_bf16_f32(qp, kp, out=so), reps=5, warm=2)
+        fl = 2.0 * 4096 * 4096 * 1536
+        kern.append({"kernel": "gemm_bf16_f32 4096x4096x1536 (VAE attention logits, hi/lo pieces)", "bound": "mfma", "ms": lms,
+                     "achieved": fl / lms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / lms / 1e9 / PEAK_BF16_TFLOPS})
+        del qp, kp, so
+    res["vae_decode"]["kernels"] = kern
     # ---- prologue: CLIP embed, VAE encode of the reference image, ReferenceNet (banks), PoseGuider, bank K/V projection
     ref = hash_uniform("bench.ref", (1, 3, 512, 512), 1.0).to(dev)
     pix = hash_uniform("bench.clip_px", (1, 3, 224, 224), 1.5).to(dev)
