@@ -14,6 +14,9 @@ lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(_
 lib.mmgt_gemm16_set_trace.argtypes = [ctypes.c_void_p]
 cases = [(16, gemm_case(196608, 1280, 320)), (16, gemm_case(196608, 2560, 320, act=1)), (17, gemm_case(196608, 960, 320, bias=False)),
          (17, gemm_case(196608, 320, 320, res=True)), (16, gemm_case(196608, 1280, 640)), (16, gemm_case(8192, 8192, 1024, bias=False)), (16, gemm_case(196608, 1280, 1024))]
+if os.environ.get("SET") == "l1":          # the level-1 / level-2 shapes of the step (K = 640 .. 5120)
+    cases = [(16, gemm_case(49152, 5120, 640, act=1)), (16, gemm_case(12288, 10240, 1280, act=1)), (16, gemm_case(12288, 1280, 5120, res=True)),
+             (17, gemm_case(49152, 640, 2560, res=True)), (16, gemm_case(49152, 1920, 640, bias=False))]
 for cfg, (name, fn, flops, out) in cases:
     hip.tune("gemm_cfg", cfg)
     t_us = min(time_call(fn) for _ in range(3))
