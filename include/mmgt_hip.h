@@ -119,6 +119,15 @@ int mmgt_attention(const void* q, long q_bs0, long q_bs1, long q_ts, const void*
                    int nk2, int seg2_first_batch, int batch, int heads, int hd, int nq, int nk, float scale,
                    int v_transposed, int dtype, void* stream);
 
+/* mmgt_attention with a per-row output multiplier per group of `os_heads` heads, applied in fp32 with the softmax normalisation:
+ *   o[b][q][head] *= out_scale[(head / os_heads) * os_group_stride + b * nq + q]
+ * Single key segment, row-major V, bdiv == 1.  MM-HAA (attention.py:730-760): the three masked audio cross-attentions write
+ * mask_i * attn2_i(x, audio_i), so that  sum_i zero_conv_i(mask_i * to_out_i(.))  is ONE GEMM over the concatenated reduction. */
+int mmgt_attention_scaled(const void* q, long q_bs0, long q_bs1, long q_ts, const void* k, long k_bs0, long k_bs1, long k_ts,
+                          const void* v, long v_bs0, long v_bs1, long v_ts, void* o, long o_bs0, long o_bs1, long o_ts,
+                          const float* out_scale, long os_group_stride, int os_heads, int batch, int heads, int hd, int nq, int nk,
+                          float scale, int dtype, void* stream);
+
 /* Row softmax of a (rows, cols) matrix scaled by `scale` (materialised-score attention of the VAE mid block). */
 int mmgt_softmax_rows(const void* x, long ldx, void* out, long ldo, int rows, int cols, float scale, int dtype,
                       void* stream);

@@ -443,8 +443,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
   } else {
     l_tot = l_run + __shfl_xor(l_run, 32);
   }
-  const float inv = 1.f / l_tot;
+  float inv = 1.f / l_tot;
   const int qi = q0 + lr;
+  if (p.out_scale && qi < p.nq) inv *= p.out_scale[(long)(head / p.os_heads) * p.os_gs + (long)b * p.nq + qi];
   if (qi < p.nq) {
     T* orow = ob + (long)qi * p.o_ts;
 #pragma unroll
@@ -493,7 +494,7 @@ int launch_hd(AttnParams p, int batch, int heads, int vt, hipStream_t s) {
     p.nqb = (p.nq + 127) / 128;
     dim3 grid((unsigned)((long)p.nqb * batch * heads));
     const bool whole = p.nk % 64 == 0 && p.nk2 % 64 == 0;
-    if (std::is_same<T, bf16_t>::value && HD == 40 && vt && whole && p.nq % 256 == 0 && g_attn64)
+    if (std::is_same<T, bf16_t>::value && HD == 40 && vt && whole && p.nq % 256 == 0 && g_attn64 && !p.out_scale)
       return mmgt_attn64_launch(&p, batch, heads, s);
     if (vt && whole) hipLaunchKernelGGL((attn_kernel<T, HD, 4, true, 64, false>), grid, dim3(256), 0, s, p);
     else if (vt) hipLaunchKernelGGL((attn_kernel<T, HD, 4, true, 64>), grid, dim3(256), 0, s, p);
@@ -522,11 +523,12 @@ int mmgt_tattn_try(const void* q, long q_bs0, long q_bs1, long q_ts, const void*
                    const void* v, long v_bs0, long v_bs1, long v_ts, void* o, long o_bs0, long o_bs1, long o_ts, int bdiv,
                    int batch, int heads, int hd, int frames, float scale, int dtype, void* stream);
 
-extern "C" int mmgt_attention(const void* q, long q_bs0, long q_bs1, long q_ts, const void* k, long k_bs0, long k_bs1,
-                              long k_ts, const void* v, long v_bs0, long v_bs1, long v_ts, void* o, long o_bs0,
-                              long o_bs1, long o_ts, int bdiv, const void* k2, const void* v2, long k2_bs, long k2_ts,
-                              long v2_bs, long v2_ts, int k2_bdiv, int nk2, int seg2_first_batch, int batch, int heads,
-                              int hd, int nq, int nk, float scale, int v_transposed, int dtype, void* stream) {
+static int attention_entry(const void* q, long q_bs0, long q_bs1, long q_ts, const void* k, long k_bs0, long k_bs1,
+                           long k_ts, const void* v, long v_bs0, long v_bs1, long v_ts, void* o, long o_bs0,
+                           long o_bs1, long o_ts, int bdiv, const void* k2, const void* v2, long k2_bs, long k2_ts,
+                           long v2_bs, long v2_ts, int k2_bdiv, int nk2, int seg2_first_batch, int batch, int heads,
+                           int hd, int nq, int nk, float scale, int v_transposed, const float* out_scale, long os_gs, int os_heads,
+                           int dtype, void* stream) {
   MMGT_CHECK(q && k && v && o, "attention: null pointer");
   MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "attention: bad dtype %d", dtype);
   MMGT_CHECK(batch > 0 && heads > 0 && nq > 0 && nk > 0 && bdiv > 0, "attention: empty problem");
@@ -540,7 +542,9 @@ extern "C" int mmgt_attention(const void* q, long q_bs0, long q_bs1, long q_ts, 
              "attention: strides must keep 16-byte alignment");
   MMGT_CHECK(!k2 || (k2_ts % vec == 0 && k2_bs % vec == 0 && v2_ts % vec == 0 && v2_bs % vec == 0),
              "attention: segment-2 strides must keep 16-byte alignment");
-  if (nq == nk && nk <= 32 && !k2 && !v_transposed) {   // temporal pattern: the memory-stream kernel of tattn.hip
+  MMGT_CHECK(!out_scale || (os_heads > 0 && heads % os_heads == 0 && bdiv == 1 && !v_transposed),
+             "attention: out_scale needs heads %% os_heads == 0, bdiv == 1 and row-major V");
+  if (nq == nk && nk <= 32 && !k2 && !v_transposed && !out_scale) {   // temporal pattern: the memory-stream kernel of tattn.hip
     const int rc = mmgt_tattn_try(q, q_bs0, q_bs1, q_ts, k, k_bs0, k_bs1, k_ts, v, v_bs0, v_bs1, v_ts, o, o_bs0, o_bs1, o_ts, bdiv,
                                   batch, heads, hd, nq, scale, dtype, stream);
     if (rc >= 0) return rc;
@@ -554,7 +558,31 @@ extern "C" int mmgt_attention(const void* q, long q_bs0, long q_bs1, long q_ts, 
   p.bdiv = bdiv; p.k2_bdiv = k2 ? k2_bdiv : 1; p.nk2 = k2 ? nk2 : 0; p.seg2_first_batch = seg2_first_batch;
   p.nq = nq; p.nk = nk;
   p.scale_log2e = scale * 1.4426950408889634f;
+  p.out_scale = out_scale; p.os_gs = os_gs; p.os_heads = out_scale ? os_heads : 1;
   hipStream_t s = (hipStream_t)stream;
   return dtype == MMGT_BF16 ? launch_t<bf16_t>(p, batch, heads, hd, v_transposed, s)
                             : launch_t<float>(p, batch, heads, hd, v_transposed, s);
+}
+
+extern "C" int mmgt_attention(const void* q, long q_bs0, long q_bs1, long q_ts, const void* k, long k_bs0, long k_bs1,
+                              long k_ts, const void* v, long v_bs0, long v_bs1, long v_ts, void* o, long o_bs0,
+                              long o_bs1, long o_ts, int bdiv, const void* k2, const void* v2, long k2_bs, long k2_ts,
+                              long v2_bs, long v2_ts, int k2_bdiv, int nk2, int seg2_first_batch, int batch, int heads,
+                              int hd, int nq, int nk, float scale, int v_transposed, int dtype, void* stream) {
+  return attention_entry(q, q_bs0, q_bs1, q_ts, k, k_bs0, k_bs1, k_ts, v, v_bs0, v_bs1, v_ts, o, o_bs0, o_bs1, o_ts, bdiv, k2, v2, k2_bs,
+                         k2_ts, v2_bs, v2_ts, k2_bdiv, nk2, seg2_first_batch, batch, heads, hd, nq, nk, scale, v_transposed, nullptr, 0, 1,
+                         dtype, stream);
+}
+
+// The same with a per-row output multiplier per group of `os_heads` heads:  o[b][q][head] *= out_scale[(head / os_heads) * os_gs + b * nq + q]
+// (applied in fp32 with the softmax normalisation).  MM-HAA's three masked audio cross-attentions (attention.py:730-760) write
+// mask_i * attn2_i(x, audio_i) directly, so that the three  zero_conv_i(mask_i * to_out_i(.))  projections run as ONE GEMM over the
+// concatenated reduction (mmgt_amd/unet3d.py).  Single key segment, row-major V, bdiv == 1.
+extern "C" int mmgt_attention_scaled(const void* q, long q_bs0, long q_bs1, long q_ts, const void* k, long k_bs0, long k_bs1, long k_ts,
+                                     const void* v, long v_bs0, long v_bs1, long v_ts, void* o, long o_bs0, long o_bs1, long o_ts,
+                                     const float* out_scale, long os_group_stride, int os_heads, int batch, int heads, int hd, int nq, int nk,
+                                     float scale, int dtype, void* stream) {
+  MMGT_CHECK(out_scale, "attention_scaled: null out_scale");
+  return attention_entry(q, q_bs0, q_bs1, q_ts, k, k_bs0, k_bs1, k_ts, v, v_bs0, v_bs1, v_ts, o, o_bs0, o_bs1, o_ts, 1, nullptr, nullptr, 0,
+                         0, 0, 0, 1, 0, 0, batch, heads, hd, nq, nk, scale, 0, out_scale, os_group_stride, os_heads, dtype, stream);
 }

@@ -12,6 +12,10 @@ struct AttnParams {
   int nq, nk;
   int nqb, npairs, heads;
   float scale_log2e;
+  // optional per-row output multiplier (mmgt_attention_scaled): o[b][q][head] *= out_scale[(head / os_heads) * os_gs + b * nq + q]
+  const float* out_scale;
+  long os_gs;
+  int os_heads;
 };
 
 }  // namespace

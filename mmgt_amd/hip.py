@@ -39,6 +39,9 @@ _SIGS = {
                                c_long, c_long, c_void_p, c_long, c_long, c_long, c_int, c_void_p, c_void_p, c_long,
                                c_long, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                c_int, c_int, c_void_p]),
+    "mmgt_attention_scaled": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
+                                      c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                      c_int, c_void_p]),
     "mmgt_softmax_rows": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_float, c_int, c_void_p]),
     "mmgt_gemm_bf16_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p]),
     "mmgt_qk_split3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
@@ -417,9 +420,20 @@ def rowgemm320(x, wimg, N, bias=None, *, ln_gamma=None, ln_beta=None, pe_div=0, 
 # ------------------------------------------------------------------------------------------------------------ attention
 
 def attention(q, k, v, out, *, batch, heads, hd, nq, nk, scale, q_str, k_str, v_str, o_str, bdiv=1, v_transposed=False,
-              k2=None, v2=None, k2_str=(0, 0), v2_str=(0, 0), k2_bdiv=1, nk2=0, seg2_first_batch=0):
-    """Raw strided attention (see include/mmgt_hip.h).  *_str = (batch stride 0, batch stride 1, token stride)."""
-    _dev(q, k, v, out, k2, v2)
+              k2=None, v2=None, k2_str=(0, 0), v2_str=(0, 0), k2_bdiv=1, nk2=0, seg2_first_batch=0, out_scale=None, out_scale_heads=0):
+    """Raw strided attention (see include/mmgt_hip.h).  *_str = (batch stride 0, batch stride 1, token stride).
+    out_scale (groups, batch * nq) fp32 + out_scale_heads: the output rows of head group g = head // out_scale_heads are multiplied by
+    out_scale[g] (mmgt_attention_scaled: single key segment, row-major V)."""
+    _dev(q, k, v, out, k2, v2, out_scale)
+    if out_scale is not None:
+        assert k2 is None and not v_transposed and bdiv == 1 and out_scale_heads > 0 and heads % out_scale_heads == 0
+        assert out_scale.dtype == torch.float32 and out_scale.dim() == 2 and out_scale.stride(1) == 1
+        assert out_scale.shape == (heads // out_scale_heads, batch * nq)
+        _check(lib().mmgt_attention_scaled(_ptr(q), q_str[0], q_str[1], q_str[2], _ptr(k), k_str[0], k_str[1], k_str[2], _ptr(v),
+                                           v_str[0], v_str[1], v_str[2], _ptr(out), o_str[0], o_str[1], o_str[2], _ptr(out_scale),
+                                           out_scale.stride(0), out_scale_heads, batch, heads, hd, nq, nk, scale, dtype_code(q.dtype),
+                                           _stream()), "mmgt_attention_scaled")
+        return out
     _check(lib().mmgt_attention(_ptr(q), q_str[0], q_str[1], q_str[2], _ptr(k), k_str[0], k_str[1], k_str[2], _ptr(v),
                                 v_str[0], v_str[1], v_str[2], _ptr(out), o_str[0], o_str[1], o_str[2], bdiv, _ptr(k2),
                                 _ptr(v2), k2_str[0], k2_str[1], v2_str[0], v2_str[1], k2_bdiv, nk2, seg2_first_batch,

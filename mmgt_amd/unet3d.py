@@ -103,6 +103,7 @@ class UNet3DConditionModel:
         self.training = True                 # from_config leaves the module in train() mode
         self.gradient_checkpointing = False
         self._fuse_ff = os.environ.get("MMGT_NO_FUSED_FF") != "1"     # A/B switch (tools/ab_*.sh): the three-launch FeedForward
+        self._fuse_oz = os.environ.get("MMGT_NO_OZ3") != "1"          # A/B switch: the three masked audio out-projections as separate launches
         self._fuse_ln = os.environ.get("MMGT_NO_ROWGEMM") != "1"      # A/B switch: LayerNorm and q / k / v GEMMs as separate launches
         self.spec = unet3d_spec(boc, cfg["cross_attention_dim"], cfg["audio_attention_dim"], self.in_channels,
                                 self.out_channels, cfg["layers_per_block"],
@@ -357,6 +358,13 @@ class UNet3DConditionModel:
                     bo = self._f(sd[f"{t}.attn2_{i}.to_out.0.bias"])[None, :].contiguous()
                     w[f"{t}.oz{i}.w"] = self._t(hip.gemm(wz, wo_t))
                     w[f"{t}.oz{i}.bias"] = hip.gemm(wz, bo).reshape(-1).contiguous()
+            if all((f"{t}.oz{i}.w") in w for i in range(3)):
+                # the three branches as ONE GEMM over the concatenated reduction (see _audio_transformer): [Wzo_0 | Wzo_1 | Wzo_2 | Wz_i b_o,i | 0]
+                inner3 = sum(w[f"{t}.oz{i}.w"].shape[1] for i in range(3))
+                pad = torch.zeros((w[f"{t}.oz0.w"].shape[0], round_up(inner3 + 3, 64) - inner3), device=self._device, dtype=torch.float32)
+                for i in range(3):
+                    pad[:, i] = w[f"{t}.oz{i}.bias"]
+                w[t + ".oz3.w"] = torch.cat([w[f"{t}.oz{i}.w"] for i in range(3)] + [self._t(pad)], 1).contiguous()
             ff(t + ".ff")
 
         self._motion = [k[: -len(".temporal_transformer.norm.weight")] for k in self.spec
@@ -583,7 +591,7 @@ class UNet3DConditionModel:
                       o_str=(n * inner, 0, inner))
         return hip.gemm(o, self.w[t + ".attn2.o.w"], self.w[t + ".attn2.o.bias"], residual=hid)
 
-    def _audio_transformer(self, p, x, audio, masks, depth, motion_scale):
+    def _audio_transformer(self, p, x, audio, masks, depth, motion_scale, ms_cache=None):
         """MM-HAA (attention.py:649-771): self-attention, three masked audio cross-attentions through zero-convs."""
         nb, h, ww, c = x.shape
         n = h * ww
@@ -603,20 +611,49 @@ class UNet3DConditionModel:
             q3 = hip.gemm(self._ln(t + ".norm2", hid), self.w[t + ".q3.w"])
         la = audio.shape[1]
         kv3 = hip.gemm(audio.view(nb * la, -1), self.w[t + ".kv3.w"])
-        a3 = torch.empty_like(q3)
-        hip.attention(q3, kv3, kv3[:, 3 * inner:], a3, batch=nb, heads=3 * self.heads, hd=hd, nq=n, nk=la,
-                      scale=hd ** -0.5, q_str=(n * 3 * inner, 0, 3 * inner), k_str=(la * 6 * inner, 0, 6 * inner),
-                      v_str=(la * 6 * inner, 0, 6 * inner), o_str=(n * 3 * inner, 0, 3 * inner))
-        for i in range(3):
-            mask = masks[i][depth].reshape(-1).to(device=self._device, dtype=torch.float32).contiguous()
-            if mask.numel() != m:
-                raise RuntimeError(f"mask level {depth} has {mask.numel()} entries, block has {m} tokens")
-            s = 1.0 if motion_scale is None else float(motion_scale[i])
-            key = (f"{t}.z{i}", s)
+        scales = tuple(1.0 if motion_scale is None else float(motion_scale[i]) for i in range(3))
+        if self._fuse_oz and (t + ".oz3.w") in self.w and ms_cache is not None:
+            # sum_i zero_conv_i(mask_i * to_out_i(a_i)) as ONE GEMM: the attention writes mask_i s_i a_i (fp32 multiplier in its softmax
+            # normalisation), three extra columns of the operand hold mask_i s_i against the merged biases Wz_i b_o,i in the weight
+            # image, and the residual stream is read and written once instead of three times (attention.py:730-760)
+            k3 = 3 * inner
+            kp = self.w[t + ".oz3.w"].shape[1]
+            ck = (depth, k3)
+            if ck not in ms_cache:                     # once per forward and level: the masks do not change between its modules
+                rows = []
+                for i in range(3):
+                    mask = masks[i][depth].reshape(-1).to(device=self._device, dtype=torch.float32)
+                    if mask.numel() != m:
+                        raise RuntimeError(f"mask level {depth} has {mask.numel()} entries, block has {m} tokens")
+                    rows.append(mask if scales[i] == 1.0 else mask * scales[i])
+                rs = torch.stack(rows).contiguous()                                   # (3, m) fp32
+                buf = torch.empty((m, kp), device=self._device, dtype=self._dtype)
+                buf[:, k3:] = 0
+                buf[:, k3:k3 + 3] = rs.t()
+                ms_cache[ck] = (rs, buf)
+            rs, a3 = ms_cache[ck]
+            hip.attention(q3, kv3, kv3[:, k3:], a3, batch=nb, heads=3 * self.heads, hd=hd, nq=n, nk=la, scale=hd ** -0.5,
+                          q_str=(n * k3, 0, k3), k_str=(la * 2 * k3, 0, 2 * k3), v_str=(la * 2 * k3, 0, 2 * k3), o_str=(n * kp, 0, kp),
+                          out_scale=rs, out_scale_heads=self.heads)
+            key = (t + ".zsum", scales)
             if key not in self._zbias:
-                self._zbias[key] = (self.w[f"{t}.z{i}.bias"] * s).contiguous()
-            hid = hip.gemm_post(a3[:, i * inner:(i + 1) * inner], self.w[f"{t}.oz{i}.w"], self.w[f"{t}.oz{i}.bias"], mask, s,
-                                self._zbias[key], hid)
+                self._zbias[key] = sum(self.w[f"{t}.z{i}.bias"] * scales[i] for i in range(3)).contiguous()
+            hid = hip.gemm(a3, self.w[t + ".oz3.w"], self._zbias[key], residual=hid)
+        else:
+            a3 = torch.empty_like(q3)
+            hip.attention(q3, kv3, kv3[:, 3 * inner:], a3, batch=nb, heads=3 * self.heads, hd=hd, nq=n, nk=la,
+                          scale=hd ** -0.5, q_str=(n * 3 * inner, 0, 3 * inner), k_str=(la * 6 * inner, 0, 6 * inner),
+                          v_str=(la * 6 * inner, 0, 6 * inner), o_str=(n * 3 * inner, 0, 3 * inner))
+            for i in range(3):
+                mask = masks[i][depth].reshape(-1).to(device=self._device, dtype=torch.float32).contiguous()
+                if mask.numel() != m:
+                    raise RuntimeError(f"mask level {depth} has {mask.numel()} entries, block has {m} tokens")
+                s = scales[i]
+                key = (f"{t}.z{i}", s)
+                if key not in self._zbias:
+                    self._zbias[key] = (self.w[f"{t}.z{i}.bias"] * s).contiguous()
+                hid = hip.gemm_post(a3[:, i * inner:(i + 1) * inner], self.w[f"{t}.oz{i}.w"], self.w[f"{t}.oz{i}.bias"], mask, s,
+                                    self._zbias[key], hid)
         out = self._norm_ff_proj_out(t + ".ff", t + ".norm3", hid, p, x.view(m, c))
         return out.view(nb, h, ww, c)
 
@@ -716,6 +753,7 @@ class UNet3DConditionModel:
             audio = audio_embedding.to(device=self._device, dtype=self._dtype).reshape(b * f, *audio_embedding.shape[2:])
             audio = audio.contiguous()
         masks = (full_mask, face_mask, body_mask)
+        ms_cache = {}                                   # per-forward mask rows / operand buffers of the audio modules, by level
         ehs = encoder_hidden_states.to(self._device)
 
         skips = [x]
@@ -726,7 +764,7 @@ class UNet3DConditionModel:
                 if i < 3:
                     x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs, f, cfg_row=cfg_row)
                     if f"{p}.audio_modules.{j}" in self._audio:
-                        x = self._audio_transformer(f"{p}.audio_modules.{j}", x, audio, masks, i, ms)
+                        x = self._audio_transformer(f"{p}.audio_modules.{j}", x, audio, masks, i, ms, ms_cache)
                 x = self._motion_module(f"{p}.motion_modules.{j}", x, f)
                 skips.append(x)
             if i != 3:
