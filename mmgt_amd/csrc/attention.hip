@@ -68,7 +68,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
   {
     const int nqb = p.nqb, npairs = p.npairs;
     const int id = blockIdx.x;
-    if ((npairs & 7) == 0) {
+    if (p.heads_inner && ((npairs / p.heads) & 7) == 0) {
+      // few keys, heads packed in the row (MM-HAA's 24-head audio cross-attention: 80-byte head segments of 1920-byte rows): all heads of
+      // one (batch entry, query block) run back to back on ONE XCD, so a row's cache lines cross the fabric once, not once per head
+      const int xcd = id & 7, slot = id >> 3, per = nqb * p.heads;
+      const int bb = xcd + 8 * (slot / per), r = slot - (slot / per) * per;
+      qblk = r / p.heads;
+      pair = bb * p.heads + (r - qblk * p.heads);
+    } else if ((npairs & 7) == 0) {
       const int xcd = id & 7, slot = id >> 3;
       pair = xcd + 8 * (slot / nqb);
       qblk = slot % nqb;
@@ -470,11 +477,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && HD <= 40) ? 3 : 2) void attn_k
   }
 }
 
+int g_heads_inner = 1;   // mmgt_tune("attn_heads_inner", 0 / 1): A/B switch of the heads-inner workgroup order (few keys, packed heads)
 int g_attn64 = 1;   // mmgt_tune("attn64", 0 / 1): the 64-queries-per-wave kernel of attn64.hip (A/B switch)
 
 }  // namespace
 int mmgt_attn64_launch(const void* params, int batch, int heads, void* stream);
 void mmgt_attn_set64(int v) { g_attn64 = v; }
+void mmgt_attn_set_heads_inner(int v) { g_heads_inner = v; }
 namespace {
 
 template <typename T, int HD>
@@ -559,6 +568,7 @@ static int attention_entry(const void* q, long q_bs0, long q_bs1, long q_ts, con
   p.nq = nq; p.nk = nk;
   p.scale_log2e = scale * 1.4426950408889634f;
   p.out_scale = out_scale; p.os_gs = os_gs; p.os_heads = out_scale ? os_heads : 1;
+  p.heads_inner = g_heads_inner && !k2 && !v_transposed && nk <= 32 && nq > 32 && q_bs1 == 0 && o_bs1 == 0 && heads > 1;
   hipStream_t s = (hipStream_t)stream;
   return dtype == MMGT_BF16 ? launch_t<bf16_t>(p, batch, heads, hd, v_transposed, s)
                             : launch_t<float>(p, batch, heads, hd, v_transposed, s);

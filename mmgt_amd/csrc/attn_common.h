@@ -16,6 +16,7 @@ struct AttnParams {
   const float* out_scale;
   long os_gs;
   int os_heads;
+  int heads_inner;    // workgroup order: heads innermost per (batch entry, query block) on one XCD (attention.hip)
 };
 
 }  // namespace

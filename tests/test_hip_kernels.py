@@ -563,12 +563,12 @@ def test_attention_cross_audio_24_heads(dt):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("nq", [64, 200])
-def test_attention_scaled_rows_into_a_padded_operand(dt, nq):
+@pytest.mark.parametrize("nq,bf", [(64, 3), (200, 3), (200, 8), (384, 16)])
+def test_attention_scaled_rows_into_a_padded_operand(dt, nq, bf):
     """mmgt_attention_scaled: the three MM-HAA branches write mask_i * attn_i straight into the (rows, 3 inner + pad) operand of the merged
     out-projection (mmgt_amd/unet3d.py _audio_transformer); the pad columns are not touched."""
     from mmgt_amd import hip
-    hd, bf = 40, 3
+    hd = 40
     inner = 8 * hd
     k3, kp = 3 * inner, 3 * inner + 64
     q3 = rnd("sq3", (bf, nq, k3), 1.0, dt)
@@ -583,6 +583,16 @@ def test_attention_scaled_rows_into_a_padded_operand(dt, nq):
     ref = ref * rs.double().reshape(3, bf, nq).permute(1, 2, 0).repeat_interleave(8, dim=2)[..., None]
     torch.testing.assert_close(out[..., :k3].double(), ref.reshape(bf, nq, k3), **tol(dt))
     assert (out[..., k3:] == 7.0).all()
+    # bf % 8 == 0: the heads-inner workgroup order (all 24 heads of a query block back to back on one XCD) is a permutation of the grid
+    hip.tune("attn_heads_inner", 0)
+    try:
+        plain = torch.full((bf, nq, kp), 7.0, device=dev(), dtype=dt)
+        hip.attention(q3, kv, kv[..., k3:], plain, batch=bf, heads=24, hd=hd, nq=nq, nk=32, scale=hd ** -0.5,
+                      q_str=(nq * k3, 0, k3), k_str=(32 * 2 * k3, 0, 2 * k3), v_str=(32 * 2 * k3, 0, 2 * k3), o_str=(nq * kp, 0, kp),
+                      out_scale=rs, out_scale_heads=8)
+    finally:
+        hip.tune("attn_heads_inner", 1)
+    assert torch.equal(out, plain)
 
 
 def test_softmax_rows_and_plumbing():
