@@ -11,10 +11,12 @@ is None), `decode=False`, `window_group=` / `cfg_split=` (window-parallel sampli
 `output_type="uint8"` returns the frames as uint8 (b, f, H, W, 3), converted on the device (what save_videos_grid writes).
 """
 import math
+import os
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Union
 
 import numpy as np
+
 import torch
 
 from . import hip, parallel
@@ -180,6 +182,8 @@ class Pose2VideoPipeline:
                     lat_w = lat_w.repeat(2, 1, 1, 1, 1)
                 else:
                     cd, kw = unit_cond(w, row), dict(cfg_row=row)
+                if hasattr(self.denoising_unet, "boc") and os.environ.get("MMGT_NO_WINDOW_STATE") != "1":   # the HIP operator memoises what it derives from the step-invariant inputs (A/B switch)
+                    kw["window_state"] = cd.setdefault("state", {})
                 return self.denoising_unet.denoise_window(
                     lat_w, t, encoder_hidden_states=encoder_hidden_states, audio_embedding=cd["audio"],
                     pose_cond_fea=cd["pose"], full_mask=cd["full"], face_mask=cd["face"], body_mask=cd["lips"],

@@ -610,7 +610,12 @@ class UNet3DConditionModel:
         else:
             q3 = hip.gemm(self._ln(t + ".norm2", hid), self.w[t + ".q3.w"])
         la = audio.shape[1]
-        kv3 = hip.gemm(audio.view(nb * la, -1), self.w[t + ".kv3.w"])
+        state = ms_cache.get("state") if ms_cache is not None else None
+        kv3 = state.get(("kv3", t)) if state is not None else None
+        if kv3 is None:
+            kv3 = hip.gemm(audio.view(nb * la, -1), self.w[t + ".kv3.w"])
+            if state is not None:
+                state[("kv3", t)] = kv3
         scales = tuple(1.0 if motion_scale is None else float(motion_scale[i]) for i in range(3))
         if self._fuse_oz and (t + ".oz3.w") in self.w and ms_cache is not None:
             # sum_i zero_conv_i(mask_i * to_out_i(a_i)) as ONE GEMM: the attention writes mask_i s_i a_i (fp32 multiplier in its softmax
@@ -620,16 +625,23 @@ class UNet3DConditionModel:
             kp = self.w[t + ".oz3.w"].shape[1]
             ck = (depth, k3)
             if ck not in ms_cache:                     # once per forward and level: the masks do not change between its modules
-                rows = []
-                for i in range(3):
-                    mask = masks[i][depth].reshape(-1).to(device=self._device, dtype=torch.float32)
-                    if mask.numel() != m:
-                        raise RuntimeError(f"mask level {depth} has {mask.numel()} entries, block has {m} tokens")
-                    rows.append(mask if scales[i] == 1.0 else mask * scales[i])
-                rs = torch.stack(rows).contiguous()                                   # (3, m) fp32
-                buf = torch.empty((m, kp), device=self._device, dtype=self._dtype)
-                buf[:, k3:] = 0
-                buf[:, k3:k3 + 3] = rs.t()
+                kept = state.get(("mask_rows", depth, kp - k3, scales)) if state is not None else None
+                if kept is None:
+                    rows = []
+                    for i in range(3):
+                        mask = masks[i][depth].reshape(-1).to(device=self._device, dtype=torch.float32)
+                        if mask.numel() != m:
+                            raise RuntimeError(f"mask level {depth} has {mask.numel()} entries, block has {m} tokens")
+                        rows.append(mask if scales[i] == 1.0 else mask * scales[i])
+                    rs = torch.stack(rows).contiguous()                               # (3, m) fp32
+                    cols = torch.zeros((m, kp - k3), device=self._device, dtype=self._dtype)
+                    cols[:, :3] = rs.t()
+                    kept = (rs, cols)
+                    if state is not None:
+                        state[("mask_rows", depth, kp - k3, scales)] = kept
+                rs, cols = kept
+                buf = torch.empty((m, kp), device=self._device, dtype=self._dtype)   # scratch operand: not kept between steps
+                buf[:, k3:] = cols
                 ms_cache[ck] = (rs, buf)
             rs, a3 = ms_cache[ck]
             hip.attention(q3, kv3, kv3[:, k3:], a3, batch=nb, heads=3 * self.heads, hd=hd, nq=n, nk=la, scale=hd ** -0.5,
@@ -718,9 +730,13 @@ class UNet3DConditionModel:
     __call__ = forward
 
     def denoise_window(self, sample, timestep, encoder_hidden_states, audio_embedding=None, pose_cond_fea=None,
-                       full_mask=None, face_mask=None, body_mask=None, motion_scale=None, cfg_row=None):
+                       full_mask=None, face_mask=None, body_mask=None, motion_scale=None, cfg_row=None, window_state=None):
         """The operator body; returns the prediction channels-last ((b f), h, w, 64) with the first 4 channels valid
         (what mmgt_accumulate_window consumes, so the sampler never converts layouts).
+        window_state: a dict the CALLER owns, one per (window, CFG row) whose audio / masks / motion_scale do not change between
+        DDIM steps (the sampler's windows never move, pipeline_pose2vid_long.py:534-543): the operator keeps what it derives from those
+        inputs alone in it -- the audio K / V projections of the six audio modules, the mask rows of MM-HAA -- instead of recomputing
+        them at every step.  None: nothing is kept.
         cfg_row (0 or 1): `sample`, the audio, pose and masks hold ONE CFG row (b = 1) -- the unconditional row never reads
         the reference banks, the conditional row reads them in every frame; `encoder_hidden_states` stays the (2, 1, 768)
         pair.  The window-parallel sampler deals the two rows of a window to different GPUs."""
@@ -753,7 +769,7 @@ class UNet3DConditionModel:
             audio = audio_embedding.to(device=self._device, dtype=self._dtype).reshape(b * f, *audio_embedding.shape[2:])
             audio = audio.contiguous()
         masks = (full_mask, face_mask, body_mask)
-        ms_cache = {}                                   # per-forward mask rows / operand buffers of the audio modules, by level
+        ms_cache = {"state": window_state}              # per-forward mask rows / operand buffers of the audio modules, by level
         ehs = encoder_hidden_states.to(self._device)
 
         skips = [x]

@@ -96,6 +96,32 @@ def test_unet_bf16_forward_is_bitwise_reproducible(full_sd):
     assert torch.equal(a, b)
 
 
+def test_unet_window_state_keeps_step_invariant_work(full_sd):
+    """denoise_window(window_state=...): the audio K / V projections and the MM-HAA mask rows are derived once per window and kept in the
+    CALLER's dict; later steps reuse them -- bitwise the stateless result, at a different timestep too -- and a different window's inputs
+    with their own dict are not affected."""
+    from mmgt_amd.unet3d import UNet3DConditionModel
+    sd_gpu, _ = full_sd
+    m = UNet3DConditionModel(device="cuda:0", dtype=torch.bfloat16)
+    m.load_state_dict(sd_gpu)
+    m.enable_gradient_checkpointing()
+    inp = _to_dev(gc.unet_inputs(gc.UNET_CASES["full_cfg1"]))
+    m.set_banks(inp["banks"])
+
+    def run(ts, audio, state):
+        return m.denoise_window(inp["sample"], ts, inp["ehs"], audio, inp["pose"], inp["full"], inp["face"], inp["lips"],
+                                inp["motion_scale"], window_state=state).clone()
+    t0, t1 = inp["timestep"], inp["timestep"] * 0 + 321
+    state = {}
+    first = run(t0, inp["audio"], state)
+    assert any(k[0] == "kv3" for k in state) and any(k[0] == "mask_rows" for k in state)
+    assert torch.equal(first, run(t0, inp["audio"], None))
+    assert torch.equal(run(t1, inp["audio"], state), run(t1, inp["audio"], None))
+    other = inp["audio"] * 0.5                                        # another window: its own dict
+    assert torch.equal(run(t0, other, {}), run(t0, other, None))
+    assert not torch.equal(run(t0, other, None), first)
+
+
 def test_unet_fp32_mode_eval_semantics(full_sd):
     """eval() => motion_scale ignored."""
     sd_gpu, sd_cpu = full_sd
