@@ -10,7 +10,8 @@ constexpr int GN_MAXC = 2560;
 
 int g_gn_interleave = -1;   // mmgt_tune("gn_interleave", v): -1 = the default (interleaved), 0 / 1 = force the row mapping (GnRows below)
 int g_gn_lpr0 = 8;          // mmgt_tune("gn_lpr0", v): smallest lanes-per-row tried (benchmarking only)
-int g_gn_narrow = 1;        // mmgt_tune("gn_narrow", 0): the general two-pass kernels for every shape (A/B)
+int g_gn_narrow = 2;        // mmgt_tune("gn_narrow", v): 0 = the general two-pass kernels for every shape, 1 = lane-per-vector kernels where the
+                            // vectors of a row divide 64 (the VAE), 2 = also for 33..64 vectors, one row per wave (C = 320) (A/B)
 int g_gn_rows = 0;   // mmgt_tune("gn_rows", v): force the rows per workgroup (0 = the measured choice below; benchmarking only)
 // Upper bound of the chunk count for an image of HW pixels: what callers size the workspace with (mmgt_groupnorm_chunks).
 inline int gn_chunks(int HW) {
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(256) void gn_stats_narrow_kernel(const T* __restric
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int rpw = 64 / nvec, sub = lane / nvec, li = lane - sub * nvec, c = li * VEC;
+  const bool act = sub < rpw;                           // nvec that does not divide 64 (C = 320: 40 vectors, one row per wave, 24 lanes idle)
   const T* img = x + (long)n * HW * C;
   float pv[VEC], s[VEC], q[VEC];
 #pragma unroll
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(256) void gn_stats_narrow_kernel(const T* __restric
   }
   const int RS = 4 * rpw;
   for (int r = chunk * RS * U + wid * rpw + sub; r < HW; r += chunks * RS * U) {
+    if (!act) continue;
     float f[U][VEC];
 #pragma unroll
     for (int u = 0; u < U; ++u) VecIO<T>::load(img + (long)(r + u * RS) * C + c, f[u]);
@@ -271,9 +274,11 @@ __global__ __launch_bounds__(256) void gn_stats_narrow_kernel(const T* __restric
 #pragma unroll
       for (int e = 0; e < VEC; ++e) { const float d = f[u][e] - pv[e]; s[e] += d; q[e] += d * d; }
   }
-  for (int o = nvec; o < 64; o <<= 1) {                 // the wave's row slots (fixed xor tree)
+  if (rpw > 1) {                                        // (then nvec divides 64)
+    for (int o = nvec; o < 64; o <<= 1) {               // the wave's row slots (fixed xor tree)
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { s[e] += __shfl_xor(s[e], o); q[e] += __shfl_xor(q[e], o); }
+      for (int e = 0; e < VEC; ++e) { s[e] += __shfl_xor(s[e], o); q[e] += __shfl_xor(q[e], o); }
+    }
   }
   if (sub == 0) {
 #pragma unroll
@@ -304,6 +309,7 @@ __global__ __launch_bounds__(256) void gn_apply_narrow_kernel(const T* __restric
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int rpw = 64 / nvec, sub = lane / nvec, li = lane - sub * nvec, c = li * VEC;
+  const bool act = sub < rpw;
   const T* img = x + (long)n * HW * C;
   T* dst = out + (long)n * HW * C;
   {
@@ -321,6 +327,7 @@ __global__ __launch_bounds__(256) void gn_apply_narrow_kernel(const T* __restric
   }
   const int RS = 4 * rpw;
   for (int r = chunk * RS * U + wid * rpw + sub; r < HW; r += chunks * RS * U) {
+    if (!act) continue;
     float f[U][VEC];
 #pragma unroll
     for (int u = 0; u < U; ++u) VecIO<T>::load(img + (long)(r + u * RS) * C + c, f[u]);
@@ -518,6 +525,25 @@ void mmgt_gn_set_rows(int v) { g_gn_rows = v; }
 void mmgt_gn_set_interleave(int v) { g_gn_interleave = v; }
 void mmgt_gn_set_lpr0(int v) { g_gn_lpr0 = v; }
 void mmgt_gn_set_narrow(int v) { g_gn_narrow = v; }
+
+namespace {
+constexpr int GN_NARROW_U = 4;
+// the lane-per-vector kernels (gn_*_narrow_kernel): one source, nvec = C / VEC <= 64 vectors per row that either divide 64 or leave
+// one row per wave (C = 320: 40 lanes of 64 -- g_gn_narrow >= 2), whole workgroup steps
+inline bool gn_narrow_fits(int nvec, int C1, int HW) {
+  return g_gn_narrow && C1 == 0 && nvec >= 8 && nvec <= 64 && (64 % nvec == 0 || (nvec > 32 && g_gn_narrow >= 2)) &&
+         HW % (4 * (64 / nvec) * GN_NARROW_U) == 0;
+}
+inline int gn_narrow_chunks(int HW, int NB, int nvec) {
+  const int step = 4 * (64 / nvec) * GN_NARROW_U;
+  int rows = g_gn_rows > 0 ? g_gn_rows : 64;     // 8 x 4096 x 512: 64-128 rows 29 us, 256 rows 46 us; larger images: ~2048 workgroups in all
+  if (g_gn_rows <= 0) rows = max(rows, (int)(((long)HW * NB + 2047) / 2048));
+  rows = (rows + step - 1) / step * step;
+  int chunks = (HW + rows - 1) / rows;
+  const int cap = gn_chunks(HW);
+  return chunks < 1 ? 1 : (chunks > cap ? cap : chunks);
+}
+}  // namespace
 extern "C" int mmgt_groupnorm_chunks(int HW) { return gn_chunks(HW); }
 
 extern "C" int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta,
@@ -549,16 +575,10 @@ extern "C" int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C
   }
   const int nvec = C / vec;
   {
-    // narrow rows (the VAE): a lane per channel vector, see gn_stats_narrow_kernel
-    constexpr int U = 4;
-    const bool fits = C1 == 0 && nvec >= 8 && nvec <= 64 && 64 % nvec == 0 && HW % (4 * (64 / (nvec > 0 ? nvec : 1)) * U) == 0;
-    if (fits && g_gn_narrow) {
-      int rows = g_gn_rows > 0 ? g_gn_rows : 64;     // 8 x 4096 x 512: 64-128 rows 29 us, 256 rows 46 us; larger images: ~2048 workgroups in all
-      if (g_gn_rows <= 0) rows = max(rows, (int)(((long)HW * NB + 2047) / 2048));
-      rows = (rows + 4 * (64 / nvec) * U - 1) / (4 * (64 / nvec) * U) * (4 * (64 / nvec) * U);
-      int chunks = (HW + rows - 1) / rows;
-      const int cap = gn_chunks(HW);
-      chunks = chunks < 1 ? 1 : (chunks > cap ? cap : chunks);
+    // narrow rows (the VAE; C = 320 of the UNet): a lane per channel vector, see gn_stats_narrow_kernel
+    constexpr int U = GN_NARROW_U;
+    if (gn_narrow_fits(nvec, C1, HW)) {
+      const int chunks = gn_narrow_chunks(HW, NB, nvec);
       dim3 grid(chunks, NB);
       if (dtype == MMGT_BF16) {
         hipLaunchKernelGGL((gn_stats_narrow_kernel<bf16_t, U>), grid, dim3(256), 0, s, (const bf16_t*)x0, workspace, C, HW, G, chunks);
@@ -605,9 +625,22 @@ extern "C" int mmgt_groupnorm_affine(const void* x, int C, const float* gamma, c
   MMGT_CHECK(C <= GN_MAXC && C % G == 0 && G <= 64 && C % vec == 0, "groupnorm_affine: unsupported channels C=%d G=%d", C, G);
   MMGT_CHECK(NB > 0 && HW > 0 && NB <= 65535, "groupnorm_affine: bad NB=%d HW=%d", NB, HW);
   hipStream_t s = (hipStream_t)stream;
+  const int nvec = C / vec, maxs = GN_MAXC / (vec * 64);
+  if (gn_narrow_fits(nvec, 0, HW)) {
+    const int chunks = gn_narrow_chunks(HW, NB, nvec);
+    dim3 grid(chunks, NB);
+    if (dtype == MMGT_BF16) {
+      hipLaunchKernelGGL((gn_stats_narrow_kernel<bf16_t, GN_NARROW_U>), grid, dim3(256), 0, s, (const bf16_t*)x, workspace, C, HW, G, chunks);
+      hipLaunchKernelGGL(gn_affine_kernel<bf16_t>, dim3(NB), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, workspace, scale, shift, C, HW, G, chunks, eps);
+    } else {
+      hipLaunchKernelGGL((gn_stats_narrow_kernel<float, GN_NARROW_U>), grid, dim3(256), 0, s, (const float*)x, workspace, C, HW, G, chunks);
+      hipLaunchKernelGGL(gn_affine_kernel<float>, dim3(NB), dim3(256), 0, s, (const float*)x, gamma, beta, workspace, scale, shift, C, HW, G, chunks, eps);
+    }
+    MMGT_LAUNCH_CHECK();
+    return 0;
+  }
   const int chunks = gn_chunks_used(HW, C, NB);
   dim3 grid(chunks, NB);
-  const int nvec = C / vec, maxs = GN_MAXC / (vec * 64);
   int lpr = g_gn_lpr0;
   while (lpr < 64 && (lpr * maxs < nvec || nvec % lpr != 0)) lpr <<= 1;
   const int il = g_gn_interleave >= 0 ? g_gn_interleave : 1;

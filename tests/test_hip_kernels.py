@@ -330,10 +330,12 @@ def test_gemm16_blocked_tile_order_is_a_permutation(M, N):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("c,hw,silu", [(128, 16384, True), (256, 4096, True), (512, 4096, False), (256, 1024, True), (128, 4100, True)])
+@pytest.mark.parametrize("c,hw,silu", [(128, 16384, True), (256, 4096, True), (512, 4096, False), (256, 1024, True), (128, 4100, True),
+                                       (320, 4096, True), (320, 1024, False), (448, 2048, True)])
 def test_groupnorm_narrow_rows(dt, c, hw, silu):
-    """The VAE decoder's shapes (C / VEC in {16, 32, 64}: csrc/norm.hip gn_*_narrow_kernel; hw = 4100 and the fp32 C = 512 case fall back
-    to the general kernels) against torch in fp64, and against the general two-pass kernels on the same input."""
+    """The VAE decoder's shapes (C / VEC in {16, 32, 64}) and rows of 33..64 vectors that leave one row per wave (C = 320 / 448 in bf16:
+    csrc/norm.hip gn_*_narrow_kernel; hw = 4100 and the wide fp32 cases fall back to the general kernels) against torch in fp64, and
+    against the general two-pass kernels on the same input."""
     from mmgt_amd import hip
     nb = 2
     x = rnd("nx", (nb, hw, c), 1.5, dt) + rnd("nx.mean", (c,), 2.0).to(dt)
@@ -349,7 +351,7 @@ def test_groupnorm_narrow_rows(dt, c, hw, silu):
     try:
         general = hip.groupnorm(x, g, b, 32, 1e-6, silu=silu)
     finally:
-        hip.tune("gn_narrow", 1)
+        hip.tune("gn_narrow", 2)
     torch.testing.assert_close(out.double(), general.double(), **tol(dt))
 
 

@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmgt_amd import hip  # noqa: E402
 
 dev = torch.device("cuda:0")
+if os.environ.get("GN_NARROW"):
+    hip.tune("gn_narrow", int(os.environ["GN_NARROW"]))
 if os.environ.get("GN_LPR0"):
     hip.tune("gn_lpr0", int(os.environ["GN_LPR0"]))
 
@@ -38,6 +40,9 @@ for nb, hw, c in (VAE if os.environ.get("SHAPES") == "vae" else UNET):
             hip.tune("gn_rows", rows)
             us = t_us(lambda: hip.groupnorm(x, g, b, 32, 1e-5, silu=True, out=o))
             print(f"groupnorm nb={nb} hw={hw} c={c} interleave={il} rows/wg={rows}: {us:7.1f} us  {3 * x.numel() * 2 / us / 1e6:6.2f} TB/s (3 passes)")
+            if c % 8 == 0 and hw >= 1024 and c <= 1280:
+                ua = t_us(lambda: hip.groupnorm_affine(x, g, b, 32, 1e-5))
+                print(f"   statistics only (groupnorm_affine): {ua:7.1f} us  {x.numel() * 2 / ua / 1e6:6.2f} TB/s")
 hip.tune("gn_interleave", -1)
 hip.tune("gn_rows", 0)
 for rows, c in [(196608, 320), (49152, 640), (12288, 1280)]:
