@@ -145,6 +145,10 @@ class Pose2VideoPipeline:
                 full=[t.view(2, video_length, -1)[:, c].reshape(-1, t.shape[-1]).contiguous() for t in full_masks],
                 face=[t.view(2, video_length, -1)[:, c].reshape(-1, t.shape[-1]).contiguous() for t in face_masks],
                 lips=[t.view(2, video_length, -1)[:, c].reshape(-1, t.shape[-1]).contiguous() for t in lip_masks]))
+        # the reference's unconditional audio row is zeros_like(audio) (:484-485): checked once here (one device sync per clip), and the
+        # operator then skips that row's audio cross-attention, whose result is exactly zero
+        uncond_audio_zero = os.environ.get("MMGT_NO_ZERO_AUDIO_SKIP") != "1" and audio_tensor_pre.shape[0] == 2 and \
+            not bool(audio_tensor_pre[0].ne(0).any())
         C = latents.shape[1]
         group = world = rank = None
         units = [(w, None) for w in range(len(windows))]
@@ -184,6 +188,8 @@ class Pose2VideoPipeline:
                     cd, kw = unit_cond(w, row), dict(cfg_row=row)
                 if hasattr(self.denoising_unet, "boc") and os.environ.get("MMGT_NO_WINDOW_STATE") != "1":   # the HIP operator memoises what it derives from the step-invariant inputs (A/B switch)
                     kw["window_state"] = cd.setdefault("state", {})
+                if hasattr(self.denoising_unet, "boc") and uncond_audio_zero:
+                    kw["audio_zero_rows"] = 1 if row in (None, 0) else 0
                 return self.denoising_unet.denoise_window(
                     lat_w, t, encoder_hidden_states=encoder_hidden_states, audio_embedding=cd["audio"],
                     pose_cond_fea=cd["pose"], full_mask=cd["full"], face_mask=cd["face"], body_mask=cd["lips"],

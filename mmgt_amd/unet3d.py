@@ -365,6 +365,7 @@ class UNet3DConditionModel:
                 for i in range(3):
                     pad[:, i] = w[f"{t}.oz{i}.bias"]
                 w[t + ".oz3.w"] = torch.cat([w[f"{t}.oz{i}.w"] for i in range(3)] + [self._t(pad)], 1).contiguous()
+                w[t + ".oz3.wb"] = self._t(pad).contiguous()          # the bias columns alone: rows whose attention output is zero
             ff(t + ".ff")
 
         self._motion = [k[: -len(".temporal_transformer.norm.weight")] for k in self.spec
@@ -605,19 +606,28 @@ class UNet3DConditionModel:
         else:
             o = self._self_attention(t + ".attn1", self._ln(t + ".norm1", hid), nb, n, inner)
         hid = hip.gemm(o, self.w[t + ".attn1.o.w"], self.w[t + ".attn1.o.bias"], residual=hid)
-        if (t + ".q3_img") in self.w:
-            q3, _ = hip.rowgemm320(hid, self.w[t + ".q3_img"], 3 * inner, ln_gamma=self.w[t + ".norm2.g"], ln_beta=self.w[t + ".norm2.b"])
-        else:
-            q3 = hip.gemm(self._ln(t + ".norm2", hid), self.w[t + ".q3.w"])
         la = audio.shape[1]
         state = ms_cache.get("state") if ms_cache is not None else None
-        kv3 = state.get(("kv3", t)) if state is not None else None
-        if kv3 is None:
-            kv3 = hip.gemm(audio.view(nb * la, -1), self.w[t + ".kv3.w"])
-            if state is not None:
-                state[("kv3", t)] = kv3
+        fused = self._fuse_oz and (t + ".oz3.w") in self.w and ms_cache is not None
+        # images whose audio embedding is ALL ZERO (the unconditional CFG row: pipeline_pose2vid_long.py:484-485): to_k / to_v carry no bias,
+        # so their keys and values are zero, every score is 0, the softmax is uniform and the attention output is exactly 0 -- their q
+        # projection and attention are not computed, their rows of the merged operand stay zero (only the bias / mask terms remain)
+        nb0 = min(nb, ms_cache.get("zero_images", 0)) if fused else 0
+        m0 = nb0 * n
+        q3 = kv3 = None
+        if nb0 < nb:
+            hid_c = hid[m0:]
+            if (t + ".q3_img") in self.w:
+                q3, _ = hip.rowgemm320(hid_c, self.w[t + ".q3_img"], 3 * inner, ln_gamma=self.w[t + ".norm2.g"], ln_beta=self.w[t + ".norm2.b"])
+            else:
+                q3 = hip.gemm(self._ln(t + ".norm2", hid_c), self.w[t + ".q3.w"])
+            kv3 = state.get(("kv3", t, nb0)) if state is not None else None
+            if kv3 is None:
+                kv3 = hip.gemm(audio[nb0:].reshape((nb - nb0) * la, -1), self.w[t + ".kv3.w"])
+                if state is not None:
+                    state[("kv3", t, nb0)] = kv3
         scales = tuple(1.0 if motion_scale is None else float(motion_scale[i]) for i in range(3))
-        if self._fuse_oz and (t + ".oz3.w") in self.w and ms_cache is not None:
+        if fused:
             # sum_i zero_conv_i(mask_i * to_out_i(a_i)) as ONE GEMM: the attention writes mask_i s_i a_i (fp32 multiplier in its softmax
             # normalisation), three extra columns of the operand hold mask_i s_i against the merged biases Wz_i b_o,i in the weight
             # image, and the residual stream is read and written once instead of three times (attention.py:730-760)
@@ -642,15 +652,27 @@ class UNet3DConditionModel:
                 rs, cols = kept
                 buf = torch.empty((m, kp), device=self._device, dtype=self._dtype)   # scratch operand: not kept between steps
                 buf[:, k3:] = cols
+                if m0:
+                    buf[:m0, :k3] = 0
                 ms_cache[ck] = (rs, buf)
             rs, a3 = ms_cache[ck]
-            hip.attention(q3, kv3, kv3[:, k3:], a3, batch=nb, heads=3 * self.heads, hd=hd, nq=n, nk=la, scale=hd ** -0.5,
-                          q_str=(n * k3, 0, k3), k_str=(la * 2 * k3, 0, 2 * k3), v_str=(la * 2 * k3, 0, 2 * k3), o_str=(n * kp, 0, kp),
-                          out_scale=rs, out_scale_heads=self.heads)
+            if nb0 < nb:
+                hip.attention(q3, kv3, kv3[:, k3:], a3[m0:], batch=nb - nb0, heads=3 * self.heads, hd=hd, nq=n, nk=la, scale=hd ** -0.5,
+                              q_str=(n * k3, 0, k3), k_str=(la * 2 * k3, 0, 2 * k3), v_str=(la * 2 * k3, 0, 2 * k3), o_str=(n * kp, 0, kp),
+                              out_scale=rs[:, m0:], out_scale_heads=self.heads)
             key = (t + ".zsum", scales)
             if key not in self._zbias:
                 self._zbias[key] = sum(self.w[f"{t}.z{i}.bias"] * scales[i] for i in range(3)).contiguous()
-            hid = hip.gemm(a3, self.w[t + ".oz3.w"], self._zbias[key], residual=hid)
+            if 0 < m0 < m:
+                # zero-audio rows: their operand is zero up to the mask columns -- a K = 64 GEMM against the bias columns of the weight image
+                out = torch.empty_like(hid)
+                hip.gemm(a3[:m0, k3:], self.w[t + ".oz3.wb"], self._zbias[key], residual=hid[:m0], out=out[:m0])
+                hip.gemm(a3[m0:], self.w[t + ".oz3.w"], self._zbias[key], residual=hid[m0:], out=out[m0:])
+                hid = out
+            elif m0 == m:
+                hid = hip.gemm(a3[:, k3:], self.w[t + ".oz3.wb"], self._zbias[key], residual=hid)
+            else:
+                hid = hip.gemm(a3, self.w[t + ".oz3.w"], self._zbias[key], residual=hid)
         else:
             a3 = torch.empty_like(q3)
             hip.attention(q3, kv3, kv3[:, 3 * inner:], a3, batch=nb, heads=3 * self.heads, hd=hd, nq=n, nk=la,
@@ -730,13 +752,16 @@ class UNet3DConditionModel:
     __call__ = forward
 
     def denoise_window(self, sample, timestep, encoder_hidden_states, audio_embedding=None, pose_cond_fea=None,
-                       full_mask=None, face_mask=None, body_mask=None, motion_scale=None, cfg_row=None, window_state=None):
+                       full_mask=None, face_mask=None, body_mask=None, motion_scale=None, cfg_row=None, window_state=None,
+                       audio_zero_rows=0):
         """The operator body; returns the prediction channels-last ((b f), h, w, 64) with the first 4 channels valid
         (what mmgt_accumulate_window consumes, so the sampler never converts layouts).
         window_state: a dict the CALLER owns, one per (window, CFG row) whose audio / masks / motion_scale do not change between
         DDIM steps (the sampler's windows never move, pipeline_pose2vid_long.py:534-543): the operator keeps what it derives from those
         inputs alone in it -- the audio K / V projections of the six audio modules, the mask rows of MM-HAA -- instead of recomputing
         them at every step.  None: nothing is kept.
+        audio_zero_rows: the CALLER's statement that the audio embedding of the first `audio_zero_rows` batch rows is all zero (the
+        unconditional CFG row, pipeline_pose2vid_long.py:484-485); their audio cross-attention is exactly 0 and is not computed.
         cfg_row (0 or 1): `sample`, the audio, pose and masks hold ONE CFG row (b = 1) -- the unconditional row never reads
         the reference banks, the conditional row reads them in every frame; `encoder_hidden_states` stays the (2, 1, 768)
         pair.  The window-parallel sampler deals the two rows of a window to different GPUs."""
@@ -769,7 +794,10 @@ class UNet3DConditionModel:
             audio = audio_embedding.to(device=self._device, dtype=self._dtype).reshape(b * f, *audio_embedding.shape[2:])
             audio = audio.contiguous()
         masks = (full_mask, face_mask, body_mask)
-        ms_cache = {"state": window_state}              # per-forward mask rows / operand buffers of the audio modules, by level
+        if not 0 <= int(audio_zero_rows) <= b:
+            raise RuntimeError(f"audio_zero_rows = {audio_zero_rows} outside 0..{b}")
+        # per-forward mask rows / operand buffers of the audio modules, by level
+        ms_cache = {"state": window_state, "zero_images": int(audio_zero_rows) * f}
         ehs = encoder_hidden_states.to(self._device)
 
         skips = [x]

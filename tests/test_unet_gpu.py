@@ -122,6 +122,39 @@ def test_unet_window_state_keeps_step_invariant_work(full_sd):
     assert not torch.equal(run(t0, other, None), first)
 
 
+def test_unet_zero_audio_rows_are_skipped_exactly(full_sd):
+    """audio_zero_rows = 1 (the unconditional CFG row, whose audio embedding the reference sets to zeros): that row's audio cross-attention is
+    exactly zero, so not computing it gives bitwise the result of computing it -- in the CFG pair and for the rows run alone (cfg_row)."""
+    from mmgt_amd.unet3d import UNet3DConditionModel
+    sd_gpu, _ = full_sd
+    m = UNet3DConditionModel(device="cuda:0", dtype=torch.bfloat16)
+    m.load_state_dict(sd_gpu)
+    m.enable_gradient_checkpointing()
+    inp = _to_dev(gc.unet_inputs(gc.UNET_CASES["full_cfg1"]))
+    m.set_banks(inp["banks"])
+    audio = inp["audio"].clone()
+    assert audio.shape[0] == 2
+    audio[0] = 0
+
+    def run(zero_rows, **kw):
+        return m.denoise_window(inp["sample"], inp["timestep"], inp["ehs"], audio, inp["pose"], inp["full"], inp["face"], inp["lips"],
+                                inp["motion_scale"], audio_zero_rows=zero_rows, **kw).clone()
+    full = run(0)
+    assert torch.equal(run(1), full)
+    assert torch.equal(run(1, window_state={}), full)
+    f = inp["sample"].shape[2]
+    half = lambda t: t.view(2, f, -1)[0].contiguous()
+    row0 = dict(sample=inp["sample"][:1], audio=audio[:1], pose=inp["pose"][:1], full=[half(t) for t in inp["full"]],
+                face=[half(t) for t in inp["face"]], lips=[half(t) for t in inp["lips"]])
+
+    def run_row0(zero_rows):
+        return m.denoise_window(row0["sample"], inp["timestep"], inp["ehs"], row0["audio"], row0["pose"], row0["full"], row0["face"],
+                                row0["lips"], inp["motion_scale"], cfg_row=0, audio_zero_rows=zero_rows).clone()
+    assert torch.equal(run_row0(1), run_row0(0))
+    with pytest.raises(RuntimeError, match="audio_zero_rows"):
+        run(3)
+
+
 def test_unet_fp32_mode_eval_semantics(full_sd):
     """eval() => motion_scale ignored."""
     sd_gpu, sd_cpu = full_sd
