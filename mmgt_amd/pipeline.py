@@ -190,6 +190,8 @@ class Pose2VideoPipeline:
                     kw["window_state"] = cd.setdefault("state", {})
                 if hasattr(self.denoising_unet, "boc") and uncond_audio_zero:
                     kw["audio_zero_rows"] = 1 if row in (None, 0) else 0
+                if hasattr(self.denoising_unet, "boc") and row is None:
+                    kw["cfg_rows_share_input"] = True            # lat_w.repeat(2 ...) above, pose.repeat(2 ...) in _pose_window
                 return self.denoising_unet.denoise_window(
                     lat_w, t, encoder_hidden_states=encoder_hidden_states, audio_embedding=cd["audio"],
                     pose_cond_fea=cd["pose"], full_mask=cd["full"], face_mask=cd["face"], body_mask=cd["lips"],

@@ -103,6 +103,7 @@ class UNet3DConditionModel:
         self.training = True                 # from_config leaves the module in train() mode
         self.gradient_checkpointing = False
         self._fuse_ff = os.environ.get("MMGT_NO_FUSED_FF") != "1"     # A/B switch (tools/ab_*.sh): the three-launch FeedForward
+        self._share_rows = os.environ.get("MMGT_NO_SHARED_ROWS") != "1"   # A/B switch: conv_in + first resnet once for both CFG rows
         self._fuse_oz = os.environ.get("MMGT_NO_OZ3") != "1"          # A/B switch: the three masked audio out-projections as separate launches
         self._fuse_ln = os.environ.get("MMGT_NO_ROWGEMM") != "1"      # A/B switch: LayerNorm and q / k / v GEMMs as separate launches
         self.spec = unet3d_spec(boc, cfg["cross_attention_dim"], cfg["audio_attention_dim"], self.in_channels,
@@ -474,7 +475,7 @@ class UNet3DConditionModel:
         hid = self._norm_ff(p, norm, hid)
         return hip.gemm(hid, self.w[q + ".proj_out.w"], self.w.get(q + ".proj_out.bias"), residual=x_res)
 
-    def _resnet(self, p, x, temb, skip=None):
+    def _resnet(self, p, x, temb, skip=None, out=None):
         """ResnetBlock3D (resnet.py:217-247); `skip` = the UNet skip tensor that the reference concatenates first."""
         nb, h, ww, c0 = x.shape
         hw = h * ww
@@ -495,7 +496,7 @@ class UNet3DConditionModel:
         else:
             assert skip is None
             res = x
-        return hip.conv3x3(hdn, self.w[p + ".conv2.w"], self.w[p + ".conv2.bias"], residual=res)
+        return hip.conv3x3(hdn, self.w[p + ".conv2.w"], self.w[p + ".conv2.bias"], residual=res, out=out)
 
     def _sc_split(self, p, c0, which):
         key = f"{p}.sc.w.{which}"
@@ -753,13 +754,15 @@ class UNet3DConditionModel:
 
     def denoise_window(self, sample, timestep, encoder_hidden_states, audio_embedding=None, pose_cond_fea=None,
                        full_mask=None, face_mask=None, body_mask=None, motion_scale=None, cfg_row=None, window_state=None,
-                       audio_zero_rows=0):
+                       audio_zero_rows=0, cfg_rows_share_input=False):
         """The operator body; returns the prediction channels-last ((b f), h, w, 64) with the first 4 channels valid
         (what mmgt_accumulate_window consumes, so the sampler never converts layouts).
         window_state: a dict the CALLER owns, one per (window, CFG row) whose audio / masks / motion_scale do not change between
         DDIM steps (the sampler's windows never move, pipeline_pose2vid_long.py:534-543): the operator keeps what it derives from those
         inputs alone in it -- the audio K / V projections of the six audio modules, the mask rows of MM-HAA -- instead of recomputing
         them at every step.  None: nothing is kept.
+        cfg_rows_share_input: the CALLER's statement that the two rows of `sample` (and of the pose features) are copies of each other, as
+        the sampler builds them; conv_in and the first resnet then run once.
         audio_zero_rows: the CALLER's statement that the audio embedding of the first `audio_zero_rows` batch rows is all zero (the
         unconditional CFG row, pipeline_pose2vid_long.py:484-485); their audio cross-attention is exactly 0 and is not computed.
         cfg_row (0 or 1): `sample`, the audio, pose and masks hold ONE CFG row (b = 1) -- the unconditional row never reads
@@ -788,7 +791,16 @@ class UNet3DConditionModel:
                 pose = pose_cond_fea.to(self._dtype).contiguous()
             else:
                 pose = hip.ncfhw_to_nhwc(pose_cond_fea.to(torch.float32).contiguous(), self.boc[0], self._dtype)
-        x = hip.conv3x3(x, self.w["conv_in.w"], self.w["conv_in.bias"], residual=pose)
+        # The two CFG rows of a pair enter with the SAME latents, pose features and timestep (the caller says so: cfg_rows_share_input);
+        # they stay identical until the first transformer reads the per-row conditioning, so conv_in and the first ResnetBlock3D are
+        # computed once for the f frames and duplicated (pipeline_pose2vid_long.py:554-580: `latent_model_input = latents.repeat(2 ...)`).
+        shared = bool(cfg_rows_share_input) and b == 2 and cfg_row is None and self._share_rows
+        if shared:
+            x2 = torch.empty((2 * f, hh, ww, self.boc[0]), device=self._device, dtype=self._dtype)
+            x = hip.conv3x3(x[:f], self.w["conv_in.w"], self.w["conv_in.bias"], residual=None if pose is None else pose[:f], out=x2[:f])
+            x2[f:].copy_(x)                             # (one half-tensor copy; torch.cat would read and write both halves)
+        else:
+            x = hip.conv3x3(x, self.w["conv_in.w"], self.w["conv_in.bias"], residual=pose)
         audio = None
         if audio_embedding is not None:
             audio = audio_embedding.to(device=self._device, dtype=self._dtype).reshape(b * f, *audio_embedding.shape[2:])
@@ -800,11 +812,18 @@ class UNet3DConditionModel:
         ms_cache = {"state": window_state, "zero_images": int(audio_zero_rows) * f}
         ehs = encoder_hidden_states.to(self._device)
 
-        skips = [x]
+        skips = [x2 if shared else x]
         for i in range(4):
             p = f"down_blocks.{i}"
             for j in range(lpb):
-                x = self._resnet(f"{p}.resnets.{j}", x, temb)
+                if shared and i == 0 and j == 0:
+                    r = f"{p}.resnets.0"
+                    x2 = torch.empty((2 * f,) + tuple(x.shape[1:3]) + (self.spec[r + ".conv1.weight"][0],), device=self._device, dtype=self._dtype)
+                    x = self._resnet(r, x, {r: temb[r][:1]}, out=x2[:f])
+                    x2[f:].copy_(x)
+                    x = x2
+                else:
+                    x = self._resnet(f"{p}.resnets.{j}", x, temb)
                 if i < 3:
                     x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs, f, cfg_row=cfg_row)
                     if f"{p}.audio_modules.{j}" in self._audio:

@@ -155,6 +155,34 @@ def test_unet_zero_audio_rows_are_skipped_exactly(full_sd):
         run(3)
 
 
+def test_unet_cfg_rows_share_input(full_sd):
+    """cfg_rows_share_input: with identical latents / pose in both CFG rows, conv_in and the first resnet run once and are duplicated.
+    Bitwise the full computation when the convs take the same reduction order (tail split off: 24 frames of rows fill the persistent grid
+    differently from 48), at rounding level otherwise."""
+    from mmgt_amd import hip
+    from mmgt_amd.unet3d import UNet3DConditionModel
+    sd_gpu, _ = full_sd
+    m = UNet3DConditionModel(device="cuda:0", dtype=torch.bfloat16)
+    m.load_state_dict(sd_gpu)
+    m.enable_gradient_checkpointing()
+    inp = _to_dev(gc.unet_inputs(gc.UNET_CASES["full_cfg1"]))
+    m.set_banks(inp["banks"])
+    sample = inp["sample"][:1].repeat(2, 1, 1, 1, 1)
+    pose = inp["pose"][:1].repeat(2, 1, 1, 1, 1)
+
+    def run(share):
+        return m.denoise_window(sample, inp["timestep"], inp["ehs"], inp["audio"], pose, inp["full"], inp["face"], inp["lips"],
+                                inp["motion_scale"], cfg_rows_share_input=share).float()
+    hip.tune("tailsplit", 0)
+    try:
+        assert torch.equal(run(True), run(False))
+    finally:
+        hip.tune("tailsplit", 1)
+    a, b = run(True), run(False)
+    d = (a - b).abs()
+    assert d.max() <= 0.05 * b.abs().max() and d.mean() <= 5e-3 * b.abs().mean().clamp_min(1e-3), (d.max().item(), d.mean().item())
+
+
 def test_unet_fp32_mode_eval_semantics(full_sd):
     """eval() => motion_scale ignored."""
     sd_gpu, sd_cpu = full_sd
