@@ -481,8 +481,10 @@ class UNet3DConditionModel:
         hw = h * ww
         cout = self.spec[p + ".conv1.weight"][0]
         hdn = self._gn(p + ".norm1", x, self.config.norm_eps, silu=True, x1=skip)
-        hdn = hip.conv3x3(hdn, self.w[p + ".conv1.w"], self.w[p + ".conv1.bias"], bias2=temb[p],
-                          bias2_rows=(nb // temb[p].shape[0]) * hw)
+        b2rows = (nb // temb[p].shape[0]) * hw
+        if temb[p].shape[0] == 1:
+            b2rows = max(b2rows, 256)       # one row for every output row: any count >= M is the same sum, and >= 256 keeps the vectorised epilogue
+        hdn = hip.conv3x3(hdn, self.w[p + ".conv1.w"], self.w[p + ".conv1.bias"], bias2=temb[p], bias2_rows=b2rows)
         hdn = self._gn(p + ".norm2", hdn, self.config.norm_eps, silu=True)
         if (p + ".sc.w") in self.w:
             wsc = self.w[p + ".sc.w"]
@@ -727,6 +729,8 @@ class UNet3DConditionModel:
             ts = torch.tensor([float(timestep)], dtype=torch.float32, device=self._device)
         else:
             ts = timestep.to(device=self._device, dtype=torch.float32).reshape(-1)
+        if ts.numel() == 1:
+            batch = 1                 # one timestep for every row (the sampler's case): one embedding row, and its per-resnet slices are views
         ts = ts.expand(batch).contiguous()
         feat = hip.timestep_features(ts, self.boc[0], self._dtype)
         e = self._lin("time_embedding.linear_1", feat, act=hip.ACT_SILU)
