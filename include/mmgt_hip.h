@@ -128,6 +128,16 @@ int mmgt_attention_scaled(const void* q, long q_bs0, long q_bs1, long q_ts, cons
                           const float* out_scale, long os_group_stride, int os_heads, int batch, int heads, int hd, int nq, int nk,
                           float scale, int dtype, void* stream);
 
+/* mmgt_attention whose every batch entry reads the second key segment, with a TWIN output: o_twin (o's strides) receives the attention over
+ * the FIRST segment alone -- the state of the online softmax after its last tile --, o the attention over both.  The CFG pair of the first
+ * reference-attention reader (mutual_self_attention.py:160-230): both rows enter with the same hidden states, the conditional row attends
+ * [x | bank], the unconditional row [x]; one pass over x serves both.  bf16, head_dim 40, V transposed, nq % 256 == 0, nk % 64 == 0,
+ * nk2 % 64 == 0 only (csrc/attn64.hip); anything else is an error. */
+int mmgt_attention_twin(const void* q, long q_bs0, long q_bs1, long q_ts, const void* k, long k_bs0, long k_bs1, long k_ts,
+                        const void* v, long v_bs0, long v_bs1, long v_ts, void* o, void* o_twin, long o_bs0, long o_bs1, long o_ts,
+                        int bdiv, const void* k2, const void* v2, long k2_bs, long k2_ts, long v2_bs, long v2_ts, int k2_bdiv,
+                        int nk2, int batch, int heads, int hd, int nq, int nk, float scale, int dtype, void* stream);
+
 /* Row softmax of a (rows, cols) matrix scaled by `scale` (materialised-score attention of the VAE mid block). */
 int mmgt_softmax_rows(const void* x, long ldx, void* out, long ldo, int rows, int cols, float scale, int dtype,
                       void* stream);

@@ -537,7 +537,7 @@ static int attention_entry(const void* q, long q_bs0, long q_bs1, long q_ts, con
                            long o_bs1, long o_ts, int bdiv, const void* k2, const void* v2, long k2_bs, long k2_ts,
                            long v2_bs, long v2_ts, int k2_bdiv, int nk2, int seg2_first_batch, int batch, int heads,
                            int hd, int nq, int nk, float scale, int v_transposed, const float* out_scale, long os_gs, int os_heads,
-                           int dtype, void* stream) {
+                           void* o_twin, int dtype, void* stream) {
   MMGT_CHECK(q && k && v && o, "attention: null pointer");
   MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "attention: bad dtype %d", dtype);
   MMGT_CHECK(batch > 0 && heads > 0 && nq > 0 && nk > 0 && bdiv > 0, "attention: empty problem");
@@ -568,6 +568,11 @@ static int attention_entry(const void* q, long q_bs0, long q_bs1, long q_ts, con
   p.nq = nq; p.nk = nk;
   p.scale_log2e = scale * 1.4426950408889634f;
   p.out_scale = out_scale; p.os_gs = os_gs; p.os_heads = out_scale ? os_heads : 1;
+  p.o_twin = (char*)o_twin;
+  MMGT_CHECK(!o_twin || (k2 && nk2 > 0 && seg2_first_batch == 0 && !out_scale && dtype == MMGT_BF16 && hd == 40 && v_transposed && nq % 256 == 0 &&
+                         nk % 64 == 0 && nk2 % 64 == 0 && nq > 32 && g_attn64),
+             "attention_twin: needs the 64-queries-per-wave kernel (bf16, head_dim 40, V transposed, nq %% 256 == 0, whole 64-key tiles) and a second "
+             "key segment read by every batch entry");
   p.heads_inner = g_heads_inner && !k2 && !v_transposed && nk <= 32 && nq > 32 && q_bs1 == 0 && o_bs1 == 0 && heads > 1;
   hipStream_t s = (hipStream_t)stream;
   return dtype == MMGT_BF16 ? launch_t<bf16_t>(p, batch, heads, hd, v_transposed, s)
@@ -581,7 +586,7 @@ extern "C" int mmgt_attention(const void* q, long q_bs0, long q_bs1, long q_ts, 
                               int hd, int nq, int nk, float scale, int v_transposed, int dtype, void* stream) {
   return attention_entry(q, q_bs0, q_bs1, q_ts, k, k_bs0, k_bs1, k_ts, v, v_bs0, v_bs1, v_ts, o, o_bs0, o_bs1, o_ts, bdiv, k2, v2, k2_bs,
                          k2_ts, v2_bs, v2_ts, k2_bdiv, nk2, seg2_first_batch, batch, heads, hd, nq, nk, scale, v_transposed, nullptr, 0, 1,
-                         dtype, stream);
+                         nullptr, dtype, stream);
 }
 
 // The same with a per-row output multiplier per group of `os_heads` heads:  o[b][q][head] *= out_scale[(head / os_heads) * os_gs + b * nq + q]
@@ -594,5 +599,19 @@ extern "C" int mmgt_attention_scaled(const void* q, long q_bs0, long q_bs1, long
                                      float scale, int dtype, void* stream) {
   MMGT_CHECK(out_scale, "attention_scaled: null out_scale");
   return attention_entry(q, q_bs0, q_bs1, q_ts, k, k_bs0, k_bs1, k_ts, v, v_bs0, v_bs1, v_ts, o, o_bs0, o_bs1, o_ts, 1, nullptr, nullptr, 0,
-                         0, 0, 0, 1, 0, 0, batch, heads, hd, nq, nk, scale, 0, out_scale, os_group_stride, os_heads, dtype, stream);
+                         0, 0, 0, 1, 0, 0, batch, heads, hd, nq, nk, scale, 0, out_scale, os_group_stride, os_heads, nullptr, dtype, stream);
+}
+
+// mmgt_attention whose every batch entry reads a second key segment, with a TWIN output: the attention over the first segment alone
+// (the state of the online softmax after its last tile) is written to o_twin with o's strides, the attention over both segments to o.
+// The CFG pair of the first reference-attention reader (mutual_self_attention.py:160-230): both rows enter with the same hidden states, the
+// conditional row attends [x | bank], the unconditional row [x] -- one pass over x serves both.  bf16, head_dim 40, V transposed,
+// nq % 256 == 0, nk % 64 == 0, nk2 % 64 == 0 (the 64-queries-per-wave kernel of attn64.hip); anything else is an error.
+extern "C" int mmgt_attention_twin(const void* q, long q_bs0, long q_bs1, long q_ts, const void* k, long k_bs0, long k_bs1, long k_ts,
+                                   const void* v, long v_bs0, long v_bs1, long v_ts, void* o, void* o_twin, long o_bs0, long o_bs1, long o_ts,
+                                   int bdiv, const void* k2, const void* v2, long k2_bs, long k2_ts, long v2_bs, long v2_ts, int k2_bdiv,
+                                   int nk2, int batch, int heads, int hd, int nq, int nk, float scale, int dtype, void* stream) {
+  MMGT_CHECK(o_twin, "attention_twin: null o_twin");
+  return attention_entry(q, q_bs0, q_bs1, q_ts, k, k_bs0, k_bs1, k_ts, v, v_bs0, v_bs1, v_ts, o, o_bs0, o_bs1, o_ts, bdiv, k2, v2, k2_bs,
+                         k2_ts, v2_bs, v2_ts, k2_bdiv, nk2, 0, batch, heads, hd, nq, nk, scale, 1, nullptr, 0, 1, o_twin, dtype, stream);
 }

@@ -167,6 +167,32 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
     }
   };
 
+  // ---- normalise and store: lane (q, half) owns d = 32 dt + 8 g + 4 half + (0..3); row 40 of O^T is the denominator ----
+  auto store_out = [&](T* base) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      constexpr int R = HD % 32, REG = (R & 3) + 4 * (R >> 3), LHS = (R >> 2) & 1;
+      const float mine = o[qb][HD / 32][REG], other = __shfl_xor(mine, 32);
+      const float inv = 1.f / (lh == LHS ? mine : other);
+      T* orow = base + (long)(q0 + 32 * qb + lr) * p.o_ts;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * lh;
+          if (d < HD) {
+            union { bf16_t e[4]; u32x2 u; } pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk.e[e] = f32_to_bf16(o[qb][dt][4 * g + e] * inv);
+            *reinterpret_cast<u32x2*>(orow + d) = pk.u;
+          }
+        }
+    }
+  };
+  // mmgt_attention_twin: the state after the last tile of segment 0 IS the attention over the own keys alone -- what the batch entry's
+  // twin without a second segment (the unconditional CFG row: same q, k, v) would compute; it is written there and the loop goes on
+  T* ob_twin = p.o_twin ? reinterpret_cast<T*>(p.o_twin) + bo * p.o_bs0 + bi * p.o_bs1 + (long)head * HD : nullptr;
+
   const char* lK = smem;
   const char* lV = smem + KT * RSK;
   prefetch(0);
@@ -251,28 +277,10 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
           for (int qb = 0; qb < QB; ++qb) { mma32(o[qb][dt], cv.f, pf[qb]); pace_pv(); }
         }
       }
+    if (ob_twin && it == nt0 - 1) store_out(ob_twin);
   }
 
-  // ---- normalise and store: lane (q, half) owns d = 32 dt + 8 g + 4 half + (0..3); row 40 of O^T is the denominator ----
-#pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    constexpr int R = HD % 32, REG = (R & 3) + 4 * (R >> 3), LHS = (R >> 2) & 1;
-    const float mine = o[qb][HD / 32][REG], other = __shfl_xor(mine, 32);
-    const float inv = 1.f / (lh == LHS ? mine : other);
-    T* orow = ob + (long)(q0 + 32 * qb + lr) * p.o_ts;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = dt * 32 + 8 * g + 4 * lh;
-        if (d < HD) {
-          union { bf16_t e[4]; u32x2 u; } pk;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pk.e[e] = f32_to_bf16(o[qb][dt][4 * g + e] * inv);
-          *reinterpret_cast<u32x2*>(orow + d) = pk.u;
-        }
-      }
-  }
+  store_out(ob);
 }
 
 }  // namespace

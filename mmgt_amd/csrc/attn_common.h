@@ -16,6 +16,7 @@ struct AttnParams {
   const float* out_scale;
   long os_gs;
   int os_heads;
+  char* o_twin;       // attn64 only: the output after the LAST tile of key segment 0 also goes here (same strides as o): mmgt_attention_twin
   int heads_inner;    // workgroup order: heads innermost per (batch entry, query block) on one XCD (attention.hip)
 };
 

@@ -42,6 +42,9 @@ _SIGS = {
     "mmgt_attention_scaled": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
                                       c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                       c_int, c_void_p]),
+    "mmgt_attention_twin": (c_int, [c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long, c_void_p, c_long, c_long, c_long,
+                                    c_void_p, c_void_p, c_long, c_long, c_long, c_int, c_void_p, c_void_p, c_long, c_long, c_long, c_long,
+                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "mmgt_softmax_rows": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_float, c_int, c_void_p]),
     "mmgt_gemm_bf16_f32": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p]),
     "mmgt_qk_split3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p]),
@@ -420,11 +423,20 @@ def rowgemm320(x, wimg, N, bias=None, *, ln_gamma=None, ln_beta=None, pe_div=0, 
 # ------------------------------------------------------------------------------------------------------------ attention
 
 def attention(q, k, v, out, *, batch, heads, hd, nq, nk, scale, q_str, k_str, v_str, o_str, bdiv=1, v_transposed=False,
-              k2=None, v2=None, k2_str=(0, 0), v2_str=(0, 0), k2_bdiv=1, nk2=0, seg2_first_batch=0, out_scale=None, out_scale_heads=0):
+              k2=None, v2=None, k2_str=(0, 0), v2_str=(0, 0), k2_bdiv=1, nk2=0, seg2_first_batch=0, out_scale=None, out_scale_heads=0,
+              twin_out=None):
     """Raw strided attention (see include/mmgt_hip.h).  *_str = (batch stride 0, batch stride 1, token stride).
     out_scale (groups, batch * nq) fp32 + out_scale_heads: the output rows of head group g = head // out_scale_heads are multiplied by
     out_scale[g] (mmgt_attention_scaled: single key segment, row-major V)."""
-    _dev(q, k, v, out, k2, v2, out_scale)
+    _dev(q, k, v, out, k2, v2, out_scale, twin_out)
+    if twin_out is not None:
+        # every batch entry reads (k2, v2); twin_out (out's strides) receives the attention over (k, v) alone (mmgt_attention_twin)
+        assert k2 is not None and v_transposed and seg2_first_batch == 0 and out_scale is None and twin_out.dtype == out.dtype
+        _check(lib().mmgt_attention_twin(_ptr(q), q_str[0], q_str[1], q_str[2], _ptr(k), k_str[0], k_str[1], k_str[2], _ptr(v),
+                                         v_str[0], v_str[1], v_str[2], _ptr(out), _ptr(twin_out), o_str[0], o_str[1], o_str[2], bdiv,
+                                         _ptr(k2), _ptr(v2), k2_str[0], k2_str[1], v2_str[0], v2_str[1], k2_bdiv, nk2, batch, heads, hd,
+                                         nq, nk, scale, dtype_code(q.dtype), _stream()), "mmgt_attention_twin")
+        return out
     if out_scale is not None:
         assert k2 is None and not v_transposed and bdiv == 1 and out_scale_heads > 0 and heads % out_scale_heads == 0
         assert out_scale.dtype == torch.float32 and out_scale.dim() == 2 and out_scale.stride(1) == 1

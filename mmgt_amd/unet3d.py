@@ -103,6 +103,7 @@ class UNet3DConditionModel:
         self.training = True                 # from_config leaves the module in train() mode
         self.gradient_checkpointing = False
         self._fuse_ff = os.environ.get("MMGT_NO_FUSED_FF") != "1"     # A/B switch (tools/ab_*.sh): the three-launch FeedForward
+        self._twin = os.environ.get("MMGT_NO_TWIN_ATTENTION") != "1"      # A/B switch: one attention pass for both rows of the first reader
         self._share_rows = os.environ.get("MMGT_NO_SHARED_ROWS") != "1"   # A/B switch: conv_in + first resnet once for both CFG rows
         self._fuse_oz = os.environ.get("MMGT_NO_OZ3") != "1"          # A/B switch: the three masked audio out-projections as separate launches
         self._fuse_ln = os.environ.get("MMGT_NO_ROWGEMM") != "1"      # A/B switch: LayerNorm and q / k / v GEMMs as separate launches
@@ -565,6 +566,42 @@ class UNet3DConditionModel:
         out = self._norm_ff_proj_out(t + ".ff", t + ".norm3", hid, p, x.view(m, c))
         return out.view(nb, h, ww, c)
 
+    def _spatial_transformer_twin(self, p, x2, ehs, frames):
+        """The first reference-attention reader of a CFG pair whose rows entered with the same input (`cfg_rows_share_input`): x2 =
+        ((2 f), h, w, c) with identical halves.  GroupNorm, proj_in, LayerNorm and q | k | V^T are computed for the f frames once; ONE
+        attention pass over the frames' own keys serves both rows -- the unconditional row's output [x] is the state of the conditional
+        row's [x | bank] pass after its last own-key tile (mmgt_attention_twin) -- and the rows part at the out-projection, which adds the
+        per-row CLIP constant.  Returns None when the shape has no twin kernel (the caller then runs the batched block)."""
+        nb, h, ww, c = x2.shape
+        f, n = nb // 2, h * ww
+        t = p + ".transformer_blocks.0"
+        bank = self._banks.get(p)
+        inner = self.w[t + ".attn1.o.w"].shape[1]
+        hd = inner // self.heads
+        if bank is None or (t + ".attn1.qkv_img") not in self.w or ehs.shape[1] != 1 or self._dtype != torch.bfloat16 or hd != 40 \
+                or n % 256 or bank[2] % 64 or nb % 2:
+            return None
+        hid = self._norm_proj_in(p, x2[:f])                                              # (f n, inner)
+        npad = round_up(n, 8)
+        vt = torch.empty((f, inner, npad), device=self._device, dtype=self._dtype)
+        qk, _ = hip.rowgemm320(hid, self.w[t + ".attn1.qkv_img"], 3 * inner, ln_gamma=self.w[t + ".norm1.g"], ln_beta=self.w[t + ".norm1.b"],
+                               n1=2 * inner, n_tok=n, out_t=vt)
+        kb, vbt, nkb = bank
+        kb, vbt = kb[1:], vbt[1:]                       # the conditional row's reference features (SURVEY App. C-6)
+        o = torch.empty((nb * n, inner), device=self._device, dtype=self._dtype)
+        hip.attention(qk, qk[:, inner:], vt, o[f * n:], batch=f, heads=self.heads, hd=hd, nq=n, nk=n, scale=hd ** -0.5,
+                      q_str=(n * 2 * inner, 0, 2 * inner), k_str=(n * 2 * inner, 0, 2 * inner), v_str=(inner * npad, 0, npad),
+                      o_str=(n * inner, 0, inner), v_transposed=True, k2=kb, v2=vbt, k2_str=(kb.stride(0), kb.stride(1)),
+                      v2_str=(vbt.stride(0), vbt.stride(1)), k2_bdiv=frames, nk2=nkb, seg2_first_batch=0, twin_out=o[:f * n])
+        cvec = self._clip_vector(t, ehs)                                                 # (2, inner) fp32: row 0 unconditional
+        hid2 = torch.empty((nb * n, inner), device=self._device, dtype=self._dtype)
+        for row in (0, 1):
+            sl = slice(row * f * n, (row + 1) * f * n)
+            hip.gemm(o[sl], self.w[t + ".attn1.o.w"], self.w[t + ".attn1.o.bias"], residual=hid, bias2=cvec[row:row + 1],
+                     bias2_rows=max(f * n, 256), out=hid2[sl])
+        out = self._norm_ff_proj_out(t + ".ff", t + ".norm3", hid2, p, x2.view(nb * n, c))
+        return out.view(nb, h, ww, c)
+
     def _clip_vector(self, t, ehs):
         """to_out(to_v(e)) of the one-token CLIP cross-attention, per CFG row, fp32.  It depends on the weights and on
         `encoder_hidden_states` only, which the sampler passes unchanged at every step: cached while the caller keeps
@@ -829,7 +866,8 @@ class UNet3DConditionModel:
                 else:
                     x = self._resnet(f"{p}.resnets.{j}", x, temb)
                 if i < 3:
-                    x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs, f, cfg_row=cfg_row)
+                    y = self._spatial_transformer_twin(f"{p}.attentions.{j}", x, ehs, f) if (shared and i == 0 and j == 0 and self._twin) else None
+                    x = y if y is not None else self._spatial_transformer(f"{p}.attentions.{j}", x, ehs, f, cfg_row=cfg_row)
                     if f"{p}.audio_modules.{j}" in self._audio:
                         x = self._audio_transformer(f"{p}.audio_modules.{j}", x, audio, masks, i, ms, ms_cache)
                 x = self._motion_module(f"{p}.motion_modules.{j}", x, f)

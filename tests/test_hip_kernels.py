@@ -547,6 +547,38 @@ def test_attention_temporal_layout(dt, hd, frames, hw):
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
 
+@pytest.mark.parametrize("nq,nk2,frames", [(256, 128, 2), (512, 256, 3)])
+def test_attention_twin_output_is_the_own_key_attention(nq, nk2, frames):
+    """mmgt_attention_twin: one pass over [own keys | bank] per frame writes the attention over both segments AND, as the state after the
+    last own-key tile, the attention over the own keys alone -- bitwise what two separate launches compute (the CFG pair of the first
+    reference-attention reader: mmgt_amd/unet3d.py _spatial_transformer_twin)."""
+    from mmgt_amd import hip
+    dt, hd, heads = torch.bfloat16, 40, 8
+    inner = heads * hd
+    qk = rnd("tw.qk", (frames, nq, 2 * inner), 1.0, dt)
+    v = rnd("tw.v", (frames, nq, inner), 1.0, dt)
+    kbank = rnd("tw.kb", (1, nk2, inner), 1.0, dt)
+    vbank = rnd("tw.vb", (1, nk2, inner), 1.0, dt)
+    vt = v.transpose(1, 2).contiguous()
+    v2t = vbank.transpose(1, 2).contiguous()
+    common = dict(batch=frames, heads=heads, hd=hd, nq=nq, nk=nq, scale=hd ** -0.5, q_str=(nq * 2 * inner, 0, 2 * inner),
+                  k_str=(nq * 2 * inner, 0, 2 * inner), v_str=(inner * nq, 0, nq), o_str=(nq * inner, 0, inner), v_transposed=True)
+    seg2 = dict(k2=kbank, v2=v2t, k2_str=(kbank.stride(0), kbank.stride(1)), v2_str=(v2t.stride(0), v2t.stride(1)), k2_bdiv=frames, nk2=nk2,
+                seg2_first_batch=0)
+    both = torch.empty((frames, nq, inner), device=dev(), dtype=dt)
+    twin = torch.empty_like(both)
+    hip.attention(qk, qk[..., inner:], vt, both, twin_out=twin, **common, **seg2)
+    ref_both, ref_own = torch.empty_like(both), torch.empty_like(both)
+    hip.attention(qk, qk[..., inner:], vt, ref_both, **common, **seg2)
+    hip.attention(qk, qk[..., inner:], vt, ref_own, **common)
+    assert torch.equal(both, ref_both) and torch.equal(twin, ref_own)
+    sp = lambda t, n: t.double().reshape(frames, n, heads, hd).permute(0, 2, 1, 3)
+    want = _ref_attn(sp(qk[..., :inner], nq), sp(qk[..., inner:], nq), sp(v, nq), hd ** -0.5).permute(0, 2, 1, 3).reshape(frames, nq, inner)
+    torch.testing.assert_close(twin.double(), want, **tol(dt))
+    with pytest.raises(RuntimeError, match="attention_twin"):                 # no twin kernel for this shape: an error, not a fallback
+        hip.attention(qk[:, :200], qk[:, :200, inner:], vt, both[:, :200], twin_out=twin[:, :200], **dict(common, nq=200), **seg2)
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_attention_cross_audio_24_heads(dt):
     """MM-HAA: three cross-attention branches to 32 audio tokens run as one 24-head problem over fused projections."""

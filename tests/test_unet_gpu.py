@@ -175,7 +175,10 @@ def test_unet_cfg_rows_share_input(full_sd):
                                 inp["motion_scale"], cfg_rows_share_input=share).float()
     hip.tune("tailsplit", 0)
     try:
+        assert torch.equal(run(True), run(False))       # includes the first reference-attention reader on ONE attention pass (twin)
+        m._twin = False
         assert torch.equal(run(True), run(False))
+        m._twin = True
     finally:
         hip.tune("tailsplit", 1)
     a, b = run(True), run(False)
