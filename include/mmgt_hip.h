@@ -48,6 +48,10 @@ const char* mmgt_last_error(void);
  *               as a second launch with the reduction split in two (A/B switch).
  *   "ffn_ver"  = 4 (default): single-role kernel of mmgt_ff_fused, 3: the producer / consumer kernel (A/B measurements). */
 int mmgt_tune(const char* key, int value);
+/* Host-side switches kept in the same table (what mmgt_amd/unet3d.py, pipeline.py and smga.py consult; all default 1, 0 = the
+ * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "zero_audio_skip",
+ * "window_state", "smga_graph", "gn_fused_stats".  mmgt_tune sets them, mmgt_tune_get reads them: one state describes a run. */
+int mmgt_tune_get(const char* key, int* value);
 /* Debug only (tools/trace_gemm16.py): p = device buffer of u64 [grid][32 tiles][2 wave groups][4] that gemm16's workgroups fill
  * with 100-MHz stamps at their tile phases; NULL (the default) switches the stamps off. */
 void mmgt_gemm16_set_trace(void* p);

@@ -907,7 +907,33 @@ void mmgt_ffn_set_dbg(int v);
 void mmgt_ffn_set_ver(int v);
 void mmgt_rowgemm_set_dbg(int v);
 void mmgt_attn64_set_pad(int v);
+// Switches of the HOST side of the operator (mmgt_amd/unet3d.py, pipeline.py, smga.py read them through mmgt_tune_get): they live here,
+// beside the kernel knobs, so that ONE state -- this table -- describes what a run executed (MMGT_TUNE="twin_attention=0,splitk=0").
+namespace {
+struct HostSwitch { const char* key; int value; };
+HostSwitch g_host[] = {
+    {"fused_ff", 1},         // LayerNorm -> FeedForward (-> proj_out) as one launch (0: three launches)
+    {"twin_attention", 1},   // one attention pass for both CFG rows of the first reference reader
+    {"shared_rows", 1},      // conv_in + first resnet once when the CFG rows share their input
+    {"oz3", 1},              // the three masked audio out-projections as one GEMM
+    {"rowgemm", 1},          // row-stationary LayerNorm / GroupNorm -> projection launches
+    {"zero_audio_skip", 1},  // skip the audio cross-attention of an all-zero (unconditional) audio row
+    {"window_state", 1},     // keep what a window's audio / masks determine across the steps of a clip
+    {"smga_graph", 1},       // replay the SMGA sampler loop as a HIP graph
+    {"gn_fused_stats", 1},   // GroupNorm statistics from the producing conv's epilogue
+};
+}  // namespace
+extern "C" int mmgt_tune_get(const char* key, int* value) {
+  if (key && value)
+    for (const HostSwitch& h : g_host)
+      if (!strcmp(key, h.key)) { *value = h.value; return 0; }
+  mmgt_set_error("tune_get: unknown key");
+  return 1;
+}
 extern "C" int mmgt_tune(const char* key, int value) {
+  if (key)
+    for (HostSwitch& h : g_host)
+      if (!strcmp(key, h.key)) { h.value = value; return 0; }
   if (key && !strcmp(key, "gemm_cfg")) { g_gemm_cfg = value; return 0; }
   if (key && !strcmp(key, "attn64")) { mmgt_attn_set64(value); return 0; }
   if (key && !strcmp(key, "attn_heads_inner")) { mmgt_attn_set_heads_inner(value); return 0; }

@@ -597,33 +597,57 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       (u32x4){pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]), pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3])};
 }
 
-float* g_splitk_ws = nullptr;
-size_t g_splitk_bytes = 0;
+// Partial-sum workspace of the split-K / tail-split launches: one buffer per device, owned by the library.  It grows only OUTSIDE a
+// stream capture (hipMalloc / hipFree inside one would invalidate the capture), and a buffer that a capture has recorded is never
+// freed: a graph replays with the pointer it captured, so a later growth retires that buffer instead of releasing it.
+constexpr int MAX_DEV = 16;
+struct SplitkWs { float* p = nullptr; size_t bytes = 0; bool captured = false; };
+SplitkWs g_splitk_ws[MAX_DEV];
+
+float* splitk_workspace(size_t need, hipStream_t s) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) {
+    mmgt_set_error("gemm16 split-K: device query failed");
+    return nullptr;
+  }
+  SplitkWs& w = g_splitk_ws[dev];
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+  if (need > w.bytes) {
+    if (capturing) {
+      mmgt_set_error("gemm16 split-K: the partial-sum workspace would have to grow to %zu bytes inside a stream capture; run the "
+                     "shape once outside the capture (warm-up) first", need);
+      return nullptr;
+    }
+    if (w.p && !w.captured) (void)hipFree(w.p);       // (synchronises the device: nothing is reading the old buffer afterwards)
+    w = SplitkWs{};
+    if (hipMalloc(reinterpret_cast<void**>(&w.p), need) != hipSuccess) {
+      w = SplitkWs{};
+      mmgt_set_error("gemm16 split-K: cannot allocate %zu bytes of partial sums", need);
+      return nullptr;
+    }
+    w.bytes = need;
+  }
+  if (capturing) w.captured = true;
+  return w.p;
+}
 
 }  // namespace
 
 // Split-K entry for gemm.hip's dispatcher: bf16, one problem (batch 1), no activation / row scale / post-scale bias, N % 8 == 0,
-// (K / 64) % S == 0.  Returns 0 on success; the partial slabs live in a library-owned device buffer that grows on demand (work on
-// one stream at a time: the buffer is reused by the next call).
+// (K / 64) % S == 0.  Returns 0 on success; the partial slabs live in the library-owned per-device buffer above (work on one stream
+// at a time per device: the buffer is reused by the next call).
 int mmgt_gemm16_splitk(int mode, int bn, const void* adp, const void* W, const void* epp, int M, int N, int K, int S, void* stream, int m0) {
   ADesc ad = *reinterpret_cast<const ADesc*>(adp);
   const Epi& ep = *reinterpret_cast<const Epi*>(epp);
   hipStream_t s = (hipStream_t)stream;
   const size_t need = (size_t)S * M * N * sizeof(float);
-  if (need > g_splitk_bytes) {
-    if (g_splitk_ws) (void)hipFree(g_splitk_ws);       // (synchronises the device: nothing is reading the old buffer afterwards)
-    g_splitk_ws = nullptr;
-    g_splitk_bytes = 0;
-    if (hipMalloc(reinterpret_cast<void**>(&g_splitk_ws), need) != hipSuccess) {
-      mmgt_set_error("gemm16 split-K: cannot allocate %zu bytes of partial sums", need);
-      return 2;
-    }
-    g_splitk_bytes = need;
-  }
+  float* ws = splitk_workspace(need, s);
+  if (!ws) return 2;
   ad.ksplit = 1;
   ad.ldw = K;
   Epi pe{};
-  pe.out = reinterpret_cast<char*>(g_splitk_ws);
+  pe.out = reinterpret_cast<char*>(ws);
   pe.ldo = N;
   pe.bso = (long)M * N;
   pe.alpha = 1.f;
@@ -634,7 +658,7 @@ int mmgt_gemm16_splitk(int mode, int bn, const void* adp, const void* W, const v
   else rc = mode == 0 ? launch16<0, 256>(ad, W, 0, pe, M, N, ks, S, s) : launch16<1, 256>(ad, W, 0, pe, M, N, ks, S, s);
   if (rc) return rc;
   const long nthr = (long)M * (N / 8);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, g_splitk_ws, S, (long)M * N, ep.bias, ep.bias2,
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, ws, S, (long)M * N, ep.bias, ep.bias2,
                      ep.bias2 ? ep.bias2_rows : 1, reinterpret_cast<const bf16_t*>(ep.residual), ep.ldr, reinterpret_cast<bf16_t*>(ep.out), ep.ldo, M, N, m0);
   MMGT_LAUNCH_CHECK();
   return 0;

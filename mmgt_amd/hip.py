@@ -16,11 +16,13 @@ F32, BF16 = 0, 1
 ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_RELU, ACT_QUICK_GELU, ACT_GELU, ACT_MISH = 0, 1, 2, 3, 4, 5, 6
 
 _lib = None
+DMA_LIMIT = (1 << 31) - 1        # the kernels address every operand through 32-bit LDS-DMA offsets: 2 GiB per tensor
 
 _SIGS = {
     "mmgt_abi_version": (c_int, []),
     "mmgt_last_error": (ctypes.c_char_p, []),
     "mmgt_tune": (c_int, [ctypes.c_char_p, c_int]),
+    "mmgt_tune_get": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_int)]),
     "mmgt_gemm16_set_trace": (None, [c_void_p]),
     "mmgt_ffn_set_trace": (None, [c_void_p]),
     "mmgt_gemm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_long,
@@ -118,6 +120,13 @@ def tune(key, value):
     _check(lib().mmgt_tune(key.encode(), int(value)), "mmgt_tune")
 
 
+def tune_get(key):
+    """A host-side switch of the library's table (include/mmgt_hip.h: mmgt_tune_get)."""
+    v = c_int(0)
+    _check(lib().mmgt_tune_get(key.encode(), ctypes.byref(v)), "mmgt_tune_get")
+    return v.value
+
+
 def dtype_code(dt):
     if dt == torch.bfloat16:
         return BF16
@@ -149,7 +158,7 @@ def _f32(t, name):
 # ------------------------------------------------------------------------------------------------------------ GEMM
 
 def gemm(a, w, bias=None, *, out=None, residual=None, bias2=None, bias2_rows=0, row_scale=None, alpha=1.0,
-         act=ACT_NONE, out_cols=None):
+         act=ACT_NONE):
     """out[M, Nout] = epilogue(a[M, K] @ w[N, K]^T).  a may be a strided 2-D view (row stride, unit column stride)."""
     _dev(a, w, bias, out, residual, bias2, row_scale)
     assert a.dim() == 2 and w.dim() == 2 and a.stride(1) == 1 and w.is_contiguous() and a.dtype == w.dtype
@@ -162,15 +171,26 @@ def gemm(a, w, bias=None, *, out=None, residual=None, bias2=None, bias2_rows=0, 
     assert out.shape == (M, n_out) and out.stride(1) == 1 and out.dtype == a.dtype
     if residual is not None:
         assert residual.shape == (M, n_out) and residual.stride(1) == 1 and residual.dtype == a.dtype
-    lim = (1 << 31) - 1                # 32-bit LDS-DMA offsets: an operand of 2 GiB or more is worked in runs of rows
+    lim = DMA_LIMIT                    # an operand of 2 GiB or more is worked in runs of rows
     if M * a.stride(0) * a.element_size() > lim and M > 1:
         step = max(1, lim // (a.stride(0) * a.element_size()))
-        if bias2 is not None:
-            step = max(bias2_rows, step // bias2_rows * bias2_rows)
+        # bias2 row groups: a run must start on a group boundary -- unless ONE row serves every output row (bias2_rows >= M: the
+        # time embedding / the twin CLIP vector), which every run then takes as it is
+        one_row = bias2 is not None and bias2_rows >= M
+        if bias2 is not None and not one_row:
+            step = step // bias2_rows * bias2_rows
+            if step == 0:
+                raise RuntimeError("gemm: a bias2 row group exceeds the 2 GiB range of the 32-bit LDS-DMA offsets")
+        assert 0 < step < M
         for m0 in range(0, M, step):
             m1 = min(M, m0 + step)
-            gemm(a[m0:m1], w, bias, out=out[m0:m1], residual=None if residual is None else residual[m0:m1],
-                 bias2=None if bias2 is None else bias2[m0 // bias2_rows:(m1 + bias2_rows - 1) // bias2_rows], bias2_rows=bias2_rows,
+            if bias2 is None:
+                b2, b2r = None, 0
+            elif one_row:
+                b2, b2r = bias2[:1], max(m1 - m0, bias2_rows)
+            else:
+                b2, b2r = bias2[m0 // bias2_rows:(m1 + bias2_rows - 1) // bias2_rows], bias2_rows
+            gemm(a[m0:m1], w, bias, out=out[m0:m1], residual=None if residual is None else residual[m0:m1], bias2=b2, bias2_rows=b2r,
                  row_scale=None if row_scale is None else row_scale[m0:m1], alpha=alpha, act=act)
         return out
     _check(lib().mmgt_gemm(_ptr(a), a.stride(0), _ptr(w), _ptr(_f32(bias, "bias")), _ptr(_f32(bias2, "bias2")),
@@ -242,19 +262,22 @@ def conv3x3(x, wp, bias=None, *, stride=1, upsample=False, bias2=None, bias2_row
         assert residual.shape == out.shape and residual.is_contiguous()
     # The kernels address every operand through 32-bit LDS-DMA offsets (2 GiB per tensor).  Larger tensors -- the PoseGuider and
     # VAE convs of a 96-frame 512 x 512 clip -- are worked in runs of whole images: images are independent in a conv.
-    lim = (1 << 31) - 1
+    lim = DMA_LIMIT
     per_img = max(t.numel() // NB * t.element_size() for t in (x, out, x1, residual) if t is not None)
     if per_img * NB > lim and NB > 1:
         step = max(1, lim // per_img)
         for n0 in range(0, NB, step):
             n1 = min(NB, n0 + step)
-            b2 = None
+            b2, b2r = None, bias2_rows
             if bias2 is not None:
                 m0, m1 = n0 * oh * ow, n1 * oh * ow
-                if m0 % bias2_rows:
+                if bias2_rows >= NB * oh * ow:              # ONE row for every output row (see gemm)
+                    b2, b2r = bias2[:1], max(m1 - m0, bias2_rows)
+                elif m0 % bias2_rows:
                     raise RuntimeError("conv3x3: a batch split inside a bias2 row group is not supported")
-                b2 = bias2[m0 // bias2_rows:(m1 + bias2_rows - 1) // bias2_rows]
-            conv3x3(x[n0:n1], wp, bias, stride=stride, upsample=upsample, bias2=b2, bias2_rows=bias2_rows,
+                else:
+                    b2 = bias2[m0 // bias2_rows:(m1 + bias2_rows - 1) // bias2_rows]
+            conv3x3(x[n0:n1], wp, bias, stride=stride, upsample=upsample, bias2=b2, bias2_rows=b2r,
                     residual=None if residual is None else residual[n0:n1], act=act, x1=None if x1 is None else x1[n0:n1],
                     out=out[n0:n1], pad_high_only=pad_high_only)
         return out

@@ -11,7 +11,6 @@ is None), `decode=False`, `window_group=` / `cfg_split=` (window-parallel sampli
 `output_type="uint8"` returns the frames as uint8 (b, f, H, W, 3), converted on the device (what save_videos_grid writes).
 """
 import math
-import os
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Union
 
@@ -147,8 +146,10 @@ class Pose2VideoPipeline:
                 lips=[t.view(2, video_length, -1)[:, c].reshape(-1, t.shape[-1]).contiguous() for t in lip_masks]))
         # the reference's unconditional audio row is zeros_like(audio) (:484-485): checked once here (one device sync per clip), and the
         # operator then skips that row's audio cross-attention, whose result is exactly zero
-        uncond_audio_zero = os.environ.get("MMGT_NO_ZERO_AUDIO_SKIP") != "1" and audio_tensor_pre.shape[0] == 2 and \
+        hip_op = hasattr(self.denoising_unet, "boc")                # the HIP operator (CPU doubles of the tests take no extras)
+        uncond_audio_zero = hip_op and hip.tune_get("zero_audio_skip") and audio_tensor_pre.shape[0] == 2 and \
             not bool(audio_tensor_pre[0].ne(0).any())
+        keep_window_state = hip_op and bool(hip.tune_get("window_state"))
         C = latents.shape[1]
         group = world = rank = None
         units = [(w, None) for w in range(len(windows))]
@@ -186,11 +187,11 @@ class Pose2VideoPipeline:
                     lat_w = lat_w.repeat(2, 1, 1, 1, 1)
                 else:
                     cd, kw = unit_cond(w, row), dict(cfg_row=row)
-                if hasattr(self.denoising_unet, "boc") and os.environ.get("MMGT_NO_WINDOW_STATE") != "1":   # the HIP operator memoises what it derives from the step-invariant inputs (A/B switch)
+                if keep_window_state:                            # the HIP operator memoises what it derives from the step-invariant inputs
                     kw["window_state"] = cd.setdefault("state", {})
-                if hasattr(self.denoising_unet, "boc") and uncond_audio_zero:
+                if uncond_audio_zero:
                     kw["audio_zero_rows"] = 1 if row in (None, 0) else 0
-                if hasattr(self.denoising_unet, "boc") and row is None:
+                if hip_op and row is None:
                     kw["cfg_rows_share_input"] = True            # lat_w.repeat(2 ...) above, pose.repeat(2 ...) in _pose_window
                 return self.denoising_unet.denoise_window(
                     lat_w, t, encoder_hidden_states=encoder_hidden_states, audio_embedding=cd["audio"],

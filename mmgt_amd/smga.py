@@ -93,6 +93,7 @@ class GestureDecoder:
         self.w: Dict[str, torch.Tensor] = {}
         self._loaded = False
         self._prep = None
+        self.weights_generation = 0     # bumped by load_state_dict: captured HIP graphs hold raw pointers into self.w
 
     @property
     def device(self):
@@ -195,6 +196,7 @@ class GestureDecoder:
         w["time_table"] = self._t(torch.cat((tt.sin(), tt.cos()), dim=-1))
         self._loaded = True
         self._prep = None
+        self.weights_generation += 1
         return [], []
 
     # ------------------------------------------------------------------------------------------ blocks
@@ -388,14 +390,13 @@ class GestureDiffusion:
 
         The loop is ~5000 small launches (50 steps x ~100 kernels over 80 x 512 activations): launch-bound.  Without injected noises it
         is captured ONCE per shape into a HIP graph -- condition preparation, 50 decoder passes and updates -- over static input / noise
-        buffers and replayed (same kernels, same draw order: bitwise the eager result; MMGT_NO_SMGA_GRAPH=1 keeps the eager loop)."""
-        import os
+        buffers and replayed (same kernels, same draw order: bitwise the eager result; hip.tune("smga_graph", 0) keeps the eager loop)."""
         m = self.model
         dev = m.device
         b = shape[0]
         pairs = self.time_pairs()
         ndraw = sum(1 for _, tn in pairs if tn >= 0)
-        if noises is not None or os.environ.get("MMGT_NO_SMGA_GRAPH") == "1" or torch.device(dev).type != "cuda":
+        if noises is not None or torch.device(dev).type != "cuda" or not hip.tune_get("smga_graph"):
             prep = m.prepare(cond_frame, cond)
             it = iter(noises) if noises is not None else None
             draw = (lambda: next(it).to(dev).float().contiguous()) if noises is not None else \
@@ -403,11 +404,17 @@ class GestureDiffusion:
             x = draw()
             times_dev = [torch.full((b,), t, device=dev, dtype=torch.long) for t, _ in pairs]
             return self._loop(x, prep, times_dev, lambda k: draw())
-        key = (tuple(shape), tuple(cond_frame.shape), tuple(cond.shape))
-        g = self._graphs.get(key) if hasattr(self, "_graphs") else None
+        # A captured graph bakes in the raw pointers of the model's weight tensors and the host constants of the loop (guidance
+        # weight, eta, the time table): all of them are part of the key, a weight reload drops every older entry (its tensors may
+        # be freed), and the entry keeps the weight dict it was captured over alive.
+        key = (tuple(shape), tuple(cond_frame.shape), tuple(cond.shape), m.weights_generation, str(m.dtype), self.guidance_weight,
+               self.eta, self.sampling_timesteps, self.n_timestep)
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        for k_old in [k for k in self._graphs if k[3] != m.weights_generation]:
+            del self._graphs[k_old]
+        g = self._graphs.get(key)
         if g is None:
-            if not hasattr(self, "_graphs"):
-                self._graphs = {}
             st = dict(cf=torch.zeros(tuple(cond_frame.shape), device=dev, dtype=torch.float32),
                       cond=torch.zeros(tuple(cond.shape), device=dev, dtype=torch.float32),
                       x0=torch.zeros(shape, device=dev, dtype=torch.float32),
@@ -425,6 +432,7 @@ class GestureDiffusion:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 st["out"] = body()
+            st["weights"] = dict(m.w)                    # the captured pointers stay valid while this entry lives
             g = self._graphs[key] = (graph, st)
         graph, st = g
         st["cf"].copy_(cond_frame.to(dev).float())

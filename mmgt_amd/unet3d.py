@@ -13,7 +13,6 @@ Work the reference does and this implementation does not (results identical, SUR
     to_out(to_v(e)) added in the attn1 output epilogue (attention.py:455-462).
 """
 import math
-import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Union
 
@@ -72,6 +71,18 @@ def default_init(spec, seed=0):
     return out
 
 
+def mask_bias_columns(rs, ncols, dtype):
+    """Operand columns of MM-HAA's merged out-projection that meet the merged biases in the weight image (`.oz3.w` / `.oz3.wb`):
+    rs (3, m) fp32 = mask_i * motion_scale_i per token -> (m, ncols) `dtype`, per branch [m_hi | m_hi | m_lo] against the image's
+    [b_hi | b_lo | b_hi], so that the product keeps fp32 accuracy in bf16 storage (lo x lo, 2^-16 relative, dropped)."""
+    cols = torch.zeros((rs.shape[1], ncols), device=rs.device, dtype=dtype)
+    rs_hi = rs.to(dtype)
+    rs_lo = (rs - rs_hi.float()).to(dtype)
+    for i in range(3):
+        cols[:, 3 * i], cols[:, 3 * i + 1], cols[:, 3 * i + 2] = rs_hi[i], rs_hi[i], rs_lo[i]
+    return cols
+
+
 class UNet3DConditionModel:
     _supports_gradient_checkpointing = True
 
@@ -102,11 +113,14 @@ class UNet3DConditionModel:
         hip.dtype_code(dtype)
         self.training = True                 # from_config leaves the module in train() mode
         self.gradient_checkpointing = False
-        self._fuse_ff = os.environ.get("MMGT_NO_FUSED_FF") != "1"     # A/B switch (tools/ab_*.sh): the three-launch FeedForward
-        self._twin = os.environ.get("MMGT_NO_TWIN_ATTENTION") != "1"      # A/B switch: one attention pass for both rows of the first reader
-        self._share_rows = os.environ.get("MMGT_NO_SHARED_ROWS") != "1"   # A/B switch: conv_in + first resnet once for both CFG rows
-        self._fuse_oz = os.environ.get("MMGT_NO_OZ3") != "1"          # A/B switch: the three masked audio out-projections as separate launches
-        self._fuse_ln = os.environ.get("MMGT_NO_ROWGEMM") != "1"      # A/B switch: LayerNorm and q / k / v GEMMs as separate launches
+        # A/B switches of the host side live in the library's mmgt_tune table (hip.tune("fused_ff", 0) / MMGT_TUNE="fused_ff=0"), read
+        # once here: one state describes a run
+        self._fuse_ff = bool(hip.tune_get("fused_ff"))            # 0: the three-launch FeedForward
+        self._twin = bool(hip.tune_get("twin_attention"))         # one attention pass for both rows of the first reader
+        self._share_rows = bool(hip.tune_get("shared_rows"))      # conv_in + first resnet once for both CFG rows
+        self._fuse_oz = bool(hip.tune_get("oz3"))                 # 0: the three masked audio out-projections as separate launches
+        self._fuse_ln = bool(hip.tune_get("rowgemm"))             # 0: LayerNorm and q / k / v GEMMs as separate launches
+        self._gn_fused = bool(hip.tune_get("gn_fused_stats"))     # GroupNorm statistics from the producing conv's epilogue
         self.spec = unet3d_spec(boc, cfg["cross_attention_dim"], cfg["audio_attention_dim"], self.in_channels,
                                 self.out_channels, cfg["layers_per_block"],
                                 cfg["motion_module_kwargs"].get("temporal_position_encoding_max_len", 32))
@@ -362,10 +376,16 @@ class UNet3DConditionModel:
                     w[f"{t}.oz{i}.bias"] = hip.gemm(wz, bo).reshape(-1).contiguous()
             if all((f"{t}.oz{i}.w") in w for i in range(3)):
                 # the three branches as ONE GEMM over the concatenated reduction (see _audio_transformer): [Wzo_0 | Wzo_1 | Wzo_2 | Wz_i b_o,i | 0]
+                # The bias term mask_i s_i (Wz_i b_o,i) keeps fp32 accuracy on the bf16 path: both factors are split into a storage-
+                # dtype head and tail, three operand columns [m_hi | m_hi | m_lo] per branch against [b_hi | b_lo | b_hi] (the lo x lo
+                # term, 2^-16 relative, is dropped; in fp32 storage the tails are zero) -- the unfused path multiplies the fp32 mask
+                # with the fp32 bias, and blurred masks are not 8-bit values
                 inner3 = sum(w[f"{t}.oz{i}.w"].shape[1] for i in range(3))
-                pad = torch.zeros((w[f"{t}.oz0.w"].shape[0], round_up(inner3 + 3, 64) - inner3), device=self._device, dtype=torch.float32)
+                pad = torch.zeros((w[f"{t}.oz0.w"].shape[0], round_up(inner3 + 9, 64) - inner3), device=self._device, dtype=torch.float32)
                 for i in range(3):
-                    pad[:, i] = w[f"{t}.oz{i}.bias"]
+                    b = w[f"{t}.oz{i}.bias"]
+                    b_hi = b.to(self._dtype).float()
+                    pad[:, 3 * i], pad[:, 3 * i + 1], pad[:, 3 * i + 2] = b_hi, b - b_hi, b_hi
                 w[t + ".oz3.w"] = torch.cat([w[f"{t}.oz{i}.w"] for i in range(3)] + [self._t(pad)], 1).contiguous()
                 w[t + ".oz3.wb"] = self._t(pad).contiguous()          # the bias columns alone: rows whose attention output is zero
             ff(t + ".ff")
@@ -684,8 +704,7 @@ class UNet3DConditionModel:
                             raise RuntimeError(f"mask level {depth} has {mask.numel()} entries, block has {m} tokens")
                         rows.append(mask if scales[i] == 1.0 else mask * scales[i])
                     rs = torch.stack(rows).contiguous()                               # (3, m) fp32
-                    cols = torch.zeros((m, kp - k3), device=self._device, dtype=self._dtype)
-                    cols[:, :3] = rs.t()
+                    cols = mask_bias_columns(rs, kp - k3, self._dtype)
                     kept = (rs, cols)
                     if state is not None:
                         state[("mask_rows", depth, kp - k3, scales)] = kept

@@ -3,15 +3,17 @@
 The oracle's CPU forward is most of those tests' wall time (a 6-window, 2-step sampler run of the CPU UNet takes 1.5 minutes
 even on the GPU box's 128 cores).  An entry holds what `fn()` returned together with a key = SHA-256 over the sources it depends on
 (oracle/*.py, the synthetic-weight generator, the test-case tables), the SOURCE TEXT of the functions that produce the entry
-(`deps`: the oracle drivers of the test modules, their input builders, the spec functions of the side models) and the torch
-version: if any of them changes the key no longer matches and the test simply recomputes the oracle instead of comparing against
+(`deps`: the oracle drivers of the test modules, their input builders, the spec functions of the side models; hashed as a
+normalised syntax tree, so comments and layout do not count): if any of them changes the key no longer matches and the test simply recomputes the oracle instead of comparing against
 a stale entry.  Entries are written by
 `python tools/gen_oracle_cache.py` (CPU only; it calls the very functions the tests call) and committed; nothing under
 mmgt_amd/ reads them."""
+import ast
 import glob
 import hashlib
 import inspect
 import os
+import textwrap
 
 import torch
 
@@ -38,11 +40,24 @@ def _key(name, extra):
     return hashlib.sha256((_base + "|" + name + "|" + extra).encode()).hexdigest()
 
 
+def _normalised(fn):
+    """The function's abstract syntax tree without docstrings, comments or layout: a cosmetic edit does not change the key."""
+    tree = ast.parse(textwrap.dedent(inspect.getsource(fn)))
+    for node in ast.walk(tree):
+        body = getattr(node, "body", None)
+        if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef, ast.Module)) and body and \
+                isinstance(body[0], ast.Expr) and isinstance(body[0].value, ast.Constant) and isinstance(body[0].value.value, str):
+            node.body = body[1:] or [ast.Pass()]
+    return ast.dump(tree, annotate_fields=False, include_attributes=False)
+
+
 def _deps_digest(deps):
-    h = hashlib.sha256(torch.__version__.encode())
+    # (no torch version in the key: the entries are compared at tolerances far above kernel-to-kernel rounding differences of CPU
+    # PyTorch builds, and a key that changes with the build would turn the CPU suite's currency check into a failure -- ADVICE r3)
+    h = hashlib.sha256()
     for d in deps:
         h.update(getattr(d, "__qualname__", repr(d)).encode())
-        h.update(inspect.getsource(d).encode())
+        h.update(_normalised(d).encode())
     return h.hexdigest()
 
 

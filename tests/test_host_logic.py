@@ -440,3 +440,49 @@ def test_inputs_read_frames_and_checkpoints(tmp_path):
     assert set(inputs.load_checkpoint(tmp_path / "unet")) == {"w"}
     with pytest.raises(RuntimeError, match="unexpected key"):
         inputs.split_net_checkpoint({"vae.x": torch.ones(1)})
+
+
+class _RecordingLib:
+    """Stands in for libmmgt_hip.so in host-logic tests of mmgt_amd.hip's row / image splits: records every launch, computes nothing."""
+
+    def __init__(self):
+        self.calls = []
+
+    def mmgt_gemm(self, *a):
+        self.calls.append(("gemm", a))
+        return 0
+
+    def mmgt_conv3x3_nhwc(self, *a):
+        self.calls.append(("conv", a))
+        return 0
+
+
+def test_two_gib_split_keeps_a_single_bias2_row_for_every_run(monkeypatch):
+    """with the one-row bias2 convention (bias2_rows >= M: time embedding, twin CLIP vector) the 2 GiB row split recursed
+    on the same rows for ever; a conv split raised.  Every run must get the one row, cover the rows exactly once, and terminate."""
+    from mmgt_amd import hip
+    rec = _RecordingLib()
+    monkeypatch.setattr(hip, "lib", lambda: rec)
+    monkeypatch.setattr(hip, "_dev", lambda *ts: None)
+    monkeypatch.setattr(hip, "_stream", lambda: 0)
+    M, K, N = 1000, 64, 32
+    a, w = torch.zeros((M, K)), torch.zeros((N, K))
+    b2 = torch.zeros((1, N))
+    monkeypatch.setattr(hip, "DMA_LIMIT", 300 * K * 4)                # 300 rows per run
+    out = hip.gemm(a, w, None, bias2=b2, bias2_rows=max(M, 256))
+    rows = [(c[1][12], c[1][5]) for c in rec.calls]                   # (M of the run, bias2_rows)
+    assert sum(r for r, _ in rows) == M and len(rows) == 4 and all(b >= r for r, b in rows) and out.shape == (M, N)
+    assert all(c[1][4] == b2.data_ptr() for c in rec.calls)           # the same row for every run
+    # row groups: runs start on group boundaries and take their own rows of the table
+    rec.calls.clear()
+    b2g = torch.zeros((10, N))
+    hip.gemm(a, w, None, bias2=b2g, bias2_rows=100)
+    assert [c[1][12] for c in rec.calls] == [300, 300, 300, 100]
+    assert [c[1][4] - b2g.data_ptr() for c in rec.calls] == [0, 3 * N * 4, 6 * N * 4, 9 * N * 4]
+    # conv: whole images per run, the one row again
+    rec.calls.clear()
+    x, wp = torch.zeros((6, 8, 8, 16)), torch.zeros((16, 3, 3, 16))
+    monkeypatch.setattr(hip, "DMA_LIMIT", 2 * 8 * 8 * 16 * 4)         # two images per run
+    t1 = torch.zeros((1, 16))
+    hip.conv3x3(x, wp, None, bias2=t1, bias2_rows=max(6 * 64, 256))
+    assert [c[1][4] for c in rec.calls] == [2, 2, 2] and all(c[1][11] == t1.data_ptr() and c[1][12] >= 128 for c in rec.calls)

@@ -49,8 +49,8 @@ def test_oracle_schedule_and_sampler_match_reference_golden(gold, spec):
     inp = sc.smga_inputs()
     with torch.no_grad():
         out = R.ddim_sample(sd, cfg, inp["cond_frame"][:1], inp["cond"][:1], sc.sampler_noises())
-    # 50 stochastic DDIM steps with x0 clipped to [-1, 1]: fp32 summation-order differences stay far below the tolerance
-    torch.testing.assert_close(out, gold["ddim_sample"], rtol=1e-3, atol=1e-3)
+    # 50 stochastic DDIM steps with x0 clipped to [-1, 1]: fp32 summation-order differences stay below the north-star tolerance
+    torch.testing.assert_close(out, gold["ddim_sample"], rtol=1e-3, atol=1e-4)
 
 
 # ------------------------------------------------------------------------------------------------ HIP path
@@ -104,7 +104,7 @@ def test_hip_ddim_sampler_matches_reference_golden(gold, spec):
     out = GestureDiffusion(m, 80, 402).ddim_sample((1, 80, 402), inp["cond_frame"][:1].cuda(), inp["cond"][:1].cuda(), noises=noises)
     d = (out.cpu() - gold["ddim_sample"]).abs()
     print(f"SMGA sampler fp32 mode vs reference: max|d| {d.max().item():.3e}")
-    torch.testing.assert_close(out.cpu(), gold["ddim_sample"], rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out.cpu(), gold["ddim_sample"], rtol=1e-3, atol=1e-4)
     m16 = _hip_model(spec, torch.bfloat16)
     out16 = GestureDiffusion(m16, 80, 402).ddim_sample((1, 80, 402), inp["cond_frame"][:1].cuda(), inp["cond"][:1].cuda(), noises=noises)
     d16 = (out16.cpu() - gold["ddim_sample"]).abs()
@@ -121,8 +121,8 @@ def test_hip_ddim_sampler_matches_reference_golden(gold, spec):
 def test_hip_ddim_sampler_graph_replay_equals_the_eager_loop(spec):
     """Without injected noises the 50-step loop is captured into a HIP graph (launch-bound: ~5000 small kernels) and replayed over static
     buffers: same kernels, same draw order -> bitwise the eager loop, also on a second replay with other inputs; and it is faster."""
-    import os
     import time
+    from mmgt_amd import hip
     from mmgt_amd.smga import GestureDiffusion
     inp = sc.smga_inputs()
     m = _hip_model(spec, torch.bfloat16)
@@ -131,7 +131,7 @@ def test_hip_ddim_sampler_graph_replay_equals_the_eager_loop(spec):
     def sample(row, seed, eager):
         gen = torch.Generator(device="cuda").manual_seed(seed)
         if eager:
-            os.environ["MMGT_NO_SMGA_GRAPH"] = "1"
+            hip.tune("smga_graph", 0)
         try:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -139,7 +139,7 @@ def test_hip_ddim_sampler_graph_replay_equals_the_eager_loop(spec):
             torch.cuda.synchronize()
             return out.cpu(), time.perf_counter() - t0
         finally:
-            os.environ.pop("MMGT_NO_SMGA_GRAPH", None)
+            hip.tune("smga_graph", 1)
     e0, te = sample(0, 5, True)
     sample(0, 5, False)                                   # builds the graph
     g0, tg = sample(0, 5, False)
@@ -149,6 +149,44 @@ def test_hip_ddim_sampler_graph_replay_equals_the_eager_loop(spec):
     assert torch.equal(g1, e1) and not torch.equal(g1, g0)
     print(f"SMGA 50-step sample: eager {te * 1e3:.1f} ms, graph replay {tg * 1e3:.1f} ms")
     assert tg < te
+
+
+@pytest.mark.gpu
+def test_hip_ddim_sampler_graph_is_rebuilt_after_a_weight_reload_or_a_constant_change(spec):
+    """A captured graph holds raw pointers into the model's weight tensors and the loop's host constants: after
+    load_state_dict with other weights, or a change of guidance_weight / eta, the replay path must equal the eager loop on the NEW
+    state, not replay the stale capture."""
+    from mmgt_amd import hip
+    from mmgt_amd.smga import GestureDiffusion
+    inp = sc.smga_inputs()
+    m = _hip_model(spec, torch.bfloat16)
+    diff = GestureDiffusion(m, 80, 402)
+    cf, ce = inp["cond_frame"][:1].cuda(), inp["cond"][:1].cuda()
+
+    def sample(eager):
+        gen = torch.Generator(device="cuda").manual_seed(3)
+        if eager:
+            hip.tune("smga_graph", 0)
+        try:
+            return diff.ddim_sample((1, 80, 402), cf, ce, generator=gen).cpu()
+        finally:
+            hip.tune("smga_graph", 1)
+    g0 = sample(False)
+    assert torch.equal(sample(False), g0) and len(diff._graphs) == 1
+    sd2 = {k: (v * 0.5 if v.is_floating_point() and v.dim() >= 2 else v) for k, v in sc.smga_state_dict(spec).items()}
+    m.load_state_dict(sd2)
+    torch.cuda.empty_cache()                              # the old weight blocks really go back to the driver
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(64)]   # ... or are recycled with poison
+    g1, e1 = sample(False), sample(True)
+    assert torch.isfinite(g1).all() and torch.equal(g1, e1) and not torch.equal(g1, g0)
+    assert len(diff._graphs) == 1                         # the stale entry is gone
+    del junk
+    diff.guidance_weight = 1.0
+    g2, e2 = sample(False), sample(True)
+    assert torch.equal(g2, e2) and not torch.equal(g2, g1)
+    diff.eta = 0.5
+    g3, e3 = sample(False), sample(True)
+    assert torch.equal(g3, e3) and not torch.equal(g3, g2)
 
 
 @pytest.mark.gpu

@@ -276,3 +276,35 @@ def test_unet_benchmarked_shape_512x512x24_matches_reference_golden(full_sd, gol
     assert d16.max() <= FLOOR_SLACK * fmax and d16.mean() <= FLOOR_SLACK * fmean
     # the production configuration twice: bitwise reproducible (persistent workgroups walking many tiles, 64-query attention)
     assert torch.equal(_run_hip(sd_gpu, case, torch.bfloat16), out16)
+
+
+def test_mmhaa_merged_bias_term_keeps_fp32_accuracy_with_blurred_masks(full_sd):
+    """in the merged MM-HAA out-projection the term sum_i mask_i s_i (Wz_i b_o,i) met a bf16-rounded mask and a bf16-rounded
+    bias (2^-8 relative) where the three-launch path multiplies fp32 by fp32.  With the head / tail columns the bf16 GEMM of the bias
+    columns alone (what a zero-audio row consists of) reproduces the fp32 product to ~2^-15 of its scale, for non-binary masks."""
+    from mmgt_amd import hip
+    from mmgt_amd.unet3d import UNet3DConditionModel, mask_bias_columns
+    sd_gpu, _ = full_sd
+    m = UNet3DConditionModel(device="cuda:0", dtype=torch.bfloat16)
+    m.load_state_dict(sd_gpu)
+    t = m._audio[0] + ".transformer_blocks.0"
+    wb = m.w[t + ".oz3.wb"]
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rows = 4096
+    masks = torch.rand((3, rows), device="cuda", generator=g) ** 2               # blurred: anything in [0, 1], not 8-bit values
+    scales = torch.tensor([1.0, 1.0, 2.0], device="cuda")
+    rs = (masks * scales[:, None]).contiguous()
+    cols = mask_bias_columns(rs, wb.shape[1], torch.bfloat16)
+    zero = torch.zeros((rows, wb.shape[0]), device="cuda", dtype=torch.bfloat16)
+    got = hip.gemm(cols, wb, None, residual=zero).double()
+    bias = torch.stack([m.w[f"{t}.oz{i}.bias"] for i in range(3)]).double()      # (3, C) fp32 merged biases Wz_i b_o,i
+    ref = rs.double().t() @ bias
+    scale = ref.abs().max()
+    err = (got - ref).abs().max() / scale
+    naive = ((rs.bfloat16().double().t() @ bias.float().bfloat16().double()) - ref).abs().max() / scale
+    got32 = hip.gemm(cols.float(), wb.float(), None).double()                    # the operand columns carry the fp32 product ...
+    err32 = (got32 - ref).abs().max() / scale
+    print(f"merged bias term: max err / scale {err.item():.2e} bf16 out, {err32.item():.2e} fp32 out (one bf16 column per branch: "
+          f"{naive.item():.2e})")
+    assert err32 <= 2 ** -14 and naive >= 8 * err32
+    assert err <= 2 ** -8 * 1.01                                                 # ... and the bf16 output adds its one rounding
