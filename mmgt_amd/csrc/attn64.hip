@@ -33,7 +33,24 @@ __device__ __forceinline__ void pace_pv() {
   if (ATTN_PACE == 4) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 7"); __builtin_amdgcn_sched_barrier(0); }
 }
 
+// ATTN_TRACE (diagnostic build only: `make -C mmgt_amd/csrc trace` -> libmmgt_hip_trace.so, tools/trace_attn64.py): every wave sums the
+// shader-clock time of the six segments of a tile iteration into scalar registers and stores the sums once at the end.  The stamps fence
+// the scheduler (no overlap across segment borders), so the build's SHARES are what to read, not its run time.
+#ifndef ATTN_TRACE
+#define ATTN_TRACE 0
+#endif
+#if ATTN_TRACE
+#define SEG(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                    __builtin_amdgcn_sched_barrier(0); seg[k] += t_ - t_prev; t_prev = t_; } while (0)
+#else
+#define SEG(k) do { } while (0)
+#endif
+
+#if ATTN_TRACE
+__global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p, unsigned long long* trace) {
+#else
 __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
+#endif
   typedef bf16_t T;
   // (Double-buffered tiles -- tile t + 1 written at the end of tile t's work, one barrier per tile -- measured 1 % slower;
   // 128-key staged tiles worked as two 64-key blocks, half the barriers per key: +0.8 %.)
@@ -196,11 +213,21 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
   const char* lK = smem;
   const char* lV = smem + KT * RSK;
   prefetch(0);
+#if ATTN_TRACE
+  unsigned long long seg[7] = {0, 0, 0, 0, 0, 0, 0}, t_prev, t_begin, r_begin;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_begin), "=s"(r_begin) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  t_prev = t_begin;
+#endif
   for (int it = 0; it < ntiles; ++it) {
     __syncthreads();   // every wave has finished reading the previous tile (and the padding constants are in place)
+    SEG(0);            // [0] wait for the workgroup's slowest wave of the previous tile
     commit(0);
     __syncthreads();
+    SEG(1);            // [1] vmcnt wait of the prefetched tile + its LDS writes + barrier
     if (it + 1 < ntiles) prefetch(it + 1);
+    SEG(2);            // [2] issue of the next tile's global loads
 
     // ---- S^T - M = K . Q'^T for both query blocks: the tile's K fragments are read once ----
     f32x16 s[QB][NSUB];
@@ -222,6 +249,7 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
 #pragma unroll
           for (int qb = 0; qb < QB; ++qb) { mma32(s[qb][sub], kf[sub][ks], qf[qb][ks]); pace_qk(); }
     }
+    SEG(3);            // [3] 6 K fragment reads + ISSUE of the 12 score MFMAs (their completion is waited for in [4])
     // ---- tile maxima of both query blocks, one (rare) rescale branch for the wave ----
     float mt[QB];
 #pragma unroll
@@ -255,6 +283,7 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
         for (int sub = 0; sub < NSUB; ++sub) s[qb][sub] -= delta;
       }
     }
+    SEG(4);            // [4] drain of the score MFMAs + 34 v_max3 + 2 permlane + decision (+ the rare rescale)
     // ---- O^T += V^T . P^T, 16 keys at a time: exponentials of the group -> P fragments of both blocks -> one read of each V^T
     // fragment feeding both.  One basic block: a group's MFMAs can run under the next group's exponentials.
 #pragma unroll
@@ -277,8 +306,26 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
           for (int qb = 0; qb < QB; ++qb) { mma32(o[qb][dt], cv.f, pf[qb]); pace_pv(); }
         }
       }
+    SEG(5);            // [5] 64 v_exp + 32 cvt_pk + 8 V^T fragment reads + ISSUE of the 16 P.V MFMAs
     if (ob_twin && it == nt0 - 1) store_out(ob_twin);
   }
+#if ATTN_TRACE
+  {
+    unsigned long long t_end, r_end;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end), "=s"(r_end) :: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (trace && lane == 0) {
+      unsigned long long* dst = trace + ((long)blockIdx.x * NW + wid) * 16;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dst[k] = seg[k];
+      dst[6] = t_end - t_begin;      // shader cycles of the whole loop
+      dst[7] = r_end - r_begin;      // the same span on the 100-MHz clock
+      dst[8] = (unsigned long long)ntiles;
+      dst[9] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20);   // HW_REG_XCC_ID[3:0]
+    }
+  }
+#endif
 
   store_out(ob);
 }
@@ -289,13 +336,22 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
 int g_attn64_lds_pad = 0;   // mmgt_tune("attn64_pad", bytes): extra dynamic LDS per workgroup (experiment: 96 KiB forces one workgroup per CU)
 void mmgt_attn64_set_pad(int v) { g_attn64_lds_pad = v; }
 
+#if ATTN_TRACE
+namespace { unsigned long long* g_attn64_trace = nullptr; }
+extern "C" void mmgt_attn64_set_trace(void* p) { g_attn64_trace = reinterpret_cast<unsigned long long*>(p); }
+#endif
+
 int mmgt_attn64_launch(const void* params, int batch, int heads, void* stream) {
   AttnParams p = *reinterpret_cast<const AttnParams*>(params);
   p.heads = heads;
   p.npairs = batch * heads;
   p.nqb = p.nq / (32 * QB * NW);
   if (g_attn64_lds_pad > 65536 - 16384) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, g_attn64_lds_pad);
+#if ATTN_TRACE
+  hipLaunchKernelGGL(attn64_kernel, dim3((unsigned)((long)p.nqb * batch * heads)), dim3(NT), (size_t)g_attn64_lds_pad, (hipStream_t)stream, p, g_attn64_trace);
+#else
   hipLaunchKernelGGL(attn64_kernel, dim3((unsigned)((long)p.nqb * batch * heads)), dim3(NT), (size_t)g_attn64_lds_pad, (hipStream_t)stream, p);
+#endif
   MMGT_LAUNCH_CHECK();
   return 0;
 }

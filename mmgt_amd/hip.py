@@ -10,7 +10,7 @@ from ctypes import c_float, c_int, c_long, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmgt_hip.so")
+LIB_PATH = os.environ.get("MMGT_LIB") or os.path.join(_HERE, "libmmgt_hip.so")    # MMGT_LIB: a diagnostic build (make trace), tools only
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GEGLU, ACT_SILU, ACT_RELU, ACT_QUICK_GELU, ACT_GELU, ACT_MISH = 0, 1, 2, 3, 4, 5, 6
