@@ -8,6 +8,7 @@
 // chains are independent (one block's exponentials can issue beside the other's MFMAs).  The price is two waves per SIMD
 // instead of three (o and s for two blocks: 128 registers).  Dispatched for whole-tile key sets with nq % 256 == 0.
 #include "common.h"
+#include "gemm_common.h"
 #include "attn_common.h"
 #include "mmgt_hip.h"
 
@@ -330,9 +331,681 @@ __global__ __launch_bounds__(NT, 2) void attn64_kernel(AttnParams p) {
   store_out(ob);
 }
 
+
+// ---- attn64p_kernel (round 4): the same tile, LDS image, fragments and numerics, software-pipelined over 32-key HALF tiles ----------------
+// What the stamps and the gap model of round 4 showed (profiles/r4/attn64_gap_trace.txt, gapfill_r4.txt): attn64_kernel's stream is PHASED -- 12
+// score MFMAs with nothing to issue beside them, then the maxima, then 64 exponentials around 16 P.V MFMAs -- and two such waves on a SIMD take
+// the SUM of their stand-alone times (3336 cycles per tile pair against 2 x 1542), while a stream that deals the same multiset out one gap at a
+// time runs at ~76 cycles per MFMA pair for two waves (95 phased).  The exponentials that could fill the score MFMAs' gaps depend on them, so
+// the fillers have to come from the PREVIOUS half tile:
+//   body(j):  S(j + 1) = K(j + 1) . Q'^T  (6 MFMAs)   ||   P(j) = exp2(S(j)),  O += V(j) . P(j)  (32 exp, 16 cvt_pk, 8 MFMAs)   ||   max S(j + 1)
+// with the score registers of half tile j + 1 in the 32 registers that half tile j - 1 left (64 in all, as before: two waves per SIMD).  The lazy
+// rescale is decided per 32 keys at the end of a body (o, the new scores and the -M columns of Q' are adjusted together, exactly as before).
+// LDS: a ring of three 64-key tiles, tile t + 2 written at the top of iteration t after ONE barrier per tile (its buffer was last read in
+// iteration t - 1; its first reader is the second body of iteration t + 1, behind that iteration's barrier); global loads one tile further ahead.
+
+// ABL (timing ablations, mmgt_tune("attn64_abl", bits); results are garbage for ABL != 0): 1 no barrier in the loop, 2 no commit / prefetch in
+// the loop (32: no prefetch only, 64: no commit only), 4 v_mul in place of v_exp, 8 no maxima, 16 no LDS fragment reads in the loop.
+template <int ABL, int NWV>
+__global__ __launch_bounds__(NWV * 64, 2) void attn64p_kernel(AttnParams p) {
+  typedef bf16_t T;
+  constexpr int NB = 3, NT = NWV * 64, NW = NWV;   // (shadow the file's 4-wave constants: 8 waves = one workgroup per CU, a tile staged once per 512 queries)
+  constexpr int KVEC = (KT * NVK + NT - 1) / NT, VVEC = (HD * NVV + NT - 1) / NT;
+  __shared__ __attribute__((aligned(16))) char smem[NB * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  int pair, qblk;
+  {
+    const int nqb = p.nqb, id = blockIdx.x;
+    if ((p.npairs & 7) == 0) {
+      const int xcd = id & 7, slot = id >> 3;
+      pair = xcd + 8 * (slot / nqb);
+      qblk = slot % nqb;
+    } else {
+      pair = id / nqb;
+      qblk = id - pair * nqb;
+    }
+  }
+  pair = p.npairs - 1 - pair;   // longest first (see attn64_kernel)
+  const int b = pair / p.heads, head = pair - b * p.heads;
+  const int bo = b / p.bdiv, bi = b - bo * p.bdiv;
+  const int q0 = (qblk * NW + wid) * (32 * QB);
+  const T* qb_ = reinterpret_cast<const T*>(p.q) + bo * p.q_bs0 + bi * p.q_bs1 + (long)head * HD;
+  T* ob = reinterpret_cast<T*>(p.o) + bo * p.o_bs0 + bi * p.o_bs1 + (long)head * HD;
+
+  Frag<T> qf[QB][KSQ];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const T* qrow = qb_ + (long)(q0 + 32 * qb + lr) * p.q_ts;
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      const int d = 16 * ks + 8 * lh;
+      if (d < HD) {
+        frag_load(qf[qb][ks], qrow + d);
+        float q8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q8[j] = frag_get(qf[qb][ks], j) * p.scale_log2e;
+        frag_set8(qf[qb][ks], q8);
+      } else {
+        qf[qb][ks].zero();
+      }
+    }
+  }
+  f32x16 o[QB][DT];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[qb][i] = (f32x16)(0.f);
+  float m_run[QB] = {0.f, 0.f};
+
+  const bool has2 = p.k2 != nullptr && p.nk2 > 0 && b >= p.seg2_first_batch;
+  const int nt0 = p.nk / KT;
+  const int ntiles = nt0 + (has2 ? p.nk2 / KT : 0);
+  const T* kb0 = reinterpret_cast<const T*>(p.k) + bo * p.k_bs0 + bi * p.k_bs1 + (long)head * HD;
+  const T* vb0 = reinterpret_cast<const T*>(p.v) + bo * p.v_bs0 + bi * p.v_bs1;
+  const int b2 = b / p.k2_bdiv;
+  const T* kb1 = has2 ? reinterpret_cast<const T*>(p.k2) + b2 * p.k2_bs + (long)head * HD : kb0;
+  const T* vb1 = has2 ? reinterpret_cast<const T*>(p.v2) + b2 * p.v2_bs : vb0;
+
+  for (int i = tid * 16; i < NB * TILE_BYTES; i += NT * 16) *reinterpret_cast<u32x4*>(smem + i) = (u32x4)(0u);
+  __syncthreads();
+  if (tid < NB * KT) {
+    char* bt = smem + (tid / KT) * TILE_BYTES;
+    const int r = tid % KT;
+    Elem<T>::st(reinterpret_cast<T*>(bt + r * RSK) + HD, 1.f);
+    Elem<T>::st(reinterpret_cast<T*>(bt + r * RSK) + HD + 1, 1.f);
+    Elem<T>::st(reinterpret_cast<T*>(bt + KT * RSK + HD * RSV) + r, 1.f);
+  }
+
+  u32x4 rk[KVEC], rv[VVEC];
+  const T* pk[KVEC];
+  const T* pv[VVEC];
+  auto prefetch = [&](int it) {     // tiles strictly in order, one call per tile (running pointers)
+    const bool s1 = it >= nt0;
+    const int kt = (s1 ? it - nt0 : it) * KT;
+    const long kts = s1 ? p.k2_ts : p.k_ts, vts = s1 ? p.v2_ts : p.v_ts;
+    if (kt == 0) {
+      const T* kb = s1 ? kb1 : kb0;
+      const T* vb = s1 ? vb1 : vb0;
+#pragma unroll
+      for (int i = 0; i < KVEC; ++i) {
+        const int idx = tid + i * NT, row = idx / NVK, vc = idx - row * NVK;
+        pk[i] = kb + (long)row * kts + vc * 8;
+      }
+#pragma unroll
+      for (int i = 0; i < VVEC; ++i) {
+        const int idx = tid + i * NT, row = idx / NVV, vc = idx - row * NVV;
+        pv[i] = vb + ((long)head * HD + row) * vts + vc * 8;
+      }
+    }
+    const long kstep = (long)KT * kts;
+#pragma unroll
+    for (int i = 0; i < KVEC; ++i) {
+      if ((i + 1) * NT <= KT * NVK || tid + i * NT < KT * NVK) rk[i] = *reinterpret_cast<const u32x4*>(pk[i]);
+      pk[i] += kstep;
+    }
+#pragma unroll
+    for (int i = 0; i < VVEC; ++i) {
+      if ((i + 1) * NT <= HD * NVV || tid + i * NT < HD * NVV) rv[i] = *reinterpret_cast<const u32x4*>(pv[i]);
+      pv[i] += KT;
+    }
+  };
+  auto commit = [&](int buf) {
+    char* bK = smem + buf * TILE_BYTES;
+    char* bV = bK + KT * RSK;
+#pragma unroll
+    for (int i = 0; i < KVEC; ++i) {
+      const int idx = tid + i * NT;
+      if ((i + 1) * NT <= KT * NVK || idx < KT * NVK) {
+        const int row = idx / NVK, vc = idx - row * NVK;
+        *reinterpret_cast<u32x4*>(bK + row * RSK + vc * 16) = rk[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VVEC; ++i) {
+      const int idx = tid + i * NT;
+      if ((i + 1) * NT <= HD * NVV || idx < HD * NVV) {
+        const int row = idx / NVV, vc = idx - row * NVV;
+        u32x2* dst = reinterpret_cast<u32x2*>(bV + row * RSV + (vc >> 1) * 32 + (vc & 1) * 8);
+        dst[0] = (u32x2){rv[i][0], rv[i][1]};
+        dst[2] = (u32x2){rv[i][2], rv[i][3]};
+      }
+    }
+  };
+  auto store_out = [&](T* base) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      constexpr int R = HD % 32, REG = (R & 3) + 4 * (R >> 3), LHS = (R >> 2) & 1;
+      const float mine = o[qb][HD / 32][REG], other = __shfl_xor(mine, 32);
+      const float inv = 1.f / (lh == LHS ? mine : other);
+      T* orow = base + (long)(q0 + 32 * qb + lr) * p.o_ts;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * lh;
+          if (d < HD) {
+            union { bf16_t e[4]; u32x2 u; } pk4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk4.e[e] = f32_to_bf16(o[qb][dt][4 * g + e] * inv);
+            *reinterpret_cast<u32x2*>(orow + d) = pk4.u;
+          }
+        }
+    }
+  };
+  T* ob_twin = p.o_twin ? reinterpret_cast<T*>(p.o_twin) + bo * p.o_bs0 + bi * p.o_bs1 + (long)head * HD : nullptr;
+
+  // the (rare) rescale of a half tile's decision: o, the NEW scores and the -M columns of Q' move together
+  auto rescale = [&](f32x16 (&sn)[QB], const float (&mt)[QB], bool first) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float delta = first ? mt[qb] : fmaxf(mt[qb], 0.f);
+      const float m_new = m_run[qb] + delta;
+      const float hi = Elem<T>::cvt(m_new), lo = Elem<T>::cvt(m_new - hi);
+      delta = (hi + lo) - m_run[qb];
+      if (lh == 1) {
+        qf[qb][KSQ - 1].set(0, -hi);
+        qf[qb][KSQ - 1].set(1, -lo);
+      }
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      m_run[qb] += delta;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) o[qb][i] *= alpha;
+      sn[qb] -= delta;
+    }
+  };
+  auto tile_max = [&](const f32x16 (&sn)[QB], float (&mt)[QB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float m1 = fmaxf(fmaxf(sn[qb][0], sn[qb][1]), sn[qb][2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) m1 = fmaxf(fmaxf(m1, sn[qb][r]), sn[qb][r + 1]);
+      m1 = fmaxf(m1, sn[qb][15]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m1), __float_as_uint(m1), false, false);
+      mt[qb] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+  };
+
+  // ---- prologue: tiles 0 and 1 into the ring, tile 2 into the staging registers, the scores of half tile 0 ----
+  prefetch(0);
+  commit(0);
+  if (ntiles > 1) { prefetch(1); commit(1); }
+  if (ntiles > 2) prefetch(2);
+  __syncthreads();
+  f32x16 sA[QB], sB[QB];
+  {
+    Frag<T> kf[KSQ];
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) frag_load(kf[ks], reinterpret_cast<const T*>(smem + lr * RSK + lh * 16 + ks * 32));
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) sA[qb] = (f32x16)(0.f);
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) mma32(sA[qb], kf[ks], qf[qb][ks]);
+    float mt[QB];
+    tile_max(sA, mt);
+    rescale(sA, mt, true);
+  }
+
+  // One body: sp = scores of the half tile to exponentiate (V^T columns at vcol), sn = scores to compute from the K rows at krow.
+  // decide: the half tile behind sn exists.  twin: the state after sp is the twin output (written in front of sn's decision).
+  // Issue order.  hipcc's sched_group_barrier pipeline gave up on this block (all exponentials first, then runs of MFMAs), and a plain
+  // sched_barrier(0) fences only what has side effects: pure instructions (v_exp, v_cvt_pk, MFMA) float to their first user when the
+  // block is linearised.  So every chunk {1 MFMA + its fillers} pins its inputs and outputs through EMPTY volatile asm statements (no
+  // instruction, an ordering edge) between two fences: the order below IS the issue order.
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+#define PIN(x) asm volatile("" : "+v"(x))
+  auto body = [&](f32x16 (&sp)[QB], f32x16 (&sn)[QB], const char* krow, const char* vcol, bool decide, bool twin) __attribute__((always_inline)) {
+    Frag<T> kf[KSQ];
+    union VF { u32x4 u; Frag<T> f; } vf[2][DT];
+    if (ABL & 16) {
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) kf[ks] = qf[0][ks];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) vf[s2][dt].f = qf[1][dt];
+    } else {
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) frag_load(kf[ks], reinterpret_cast<const T*>(krow + ks * 32));
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vf[0][dt].u = *reinterpret_cast<const u32x4*>(vcol + dt * 32 * RSV);
+    }
+    float ex[2][16];                 // [query block][register of the half tile]: the exponentials
+    Frag<T> pf[2][QB];               // [s2][query block]
+    // exponentials e0 .. e1 - 1 of the 16 of group s2 (qb = e / 8), packs as they complete: inputs pinned in front, results behind (one
+    // pin per exponential would put the one-wait-state TRANS hazard's s_nop behind every v_exp)
+    auto exps = [&](int e0, int e1, int s2) __attribute__((always_inline)) {
+#pragma unroll
+      for (int e = e0; e < e1; ++e) PIN(sp[e >> 3][8 * s2 + (e & 7)]);
+#pragma unroll
+      for (int e = e0; e < e1; ++e)
+        ex[e >> 3][8 * s2 + (e & 7)] = (ABL & 4) ? sp[e >> 3][8 * s2 + (e & 7)] * 1.5f : __builtin_amdgcn_exp2f(sp[e >> 3][8 * s2 + (e & 7)]);
+#pragma unroll
+      for (int e = e0; e < e1; ++e) {
+        const int eq = e >> 3;
+        if ((e & 7) == 7) {
+          float p8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) p8[j] = ex[eq][8 * s2 + j];
+          frag_set8(pf[s2][eq], p8);
+          PIN(pf[s2][eq].v);
+        } else if (e == e1 - 1 || (e & 7) < 6 || true) {
+          PIN(ex[eq][8 * s2 + (e & 7)]);
+        }
+      }
+    };
+    FENCE();
+    // chunks 0..5: the six score MFMAs of the NEXT half tile, the first 16 exponentials of this one (3 3 2 3 3 2) dealt out behind them
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int ks = c >> 1, qb = c & 1;
+      if (qb == 0) PIN(kf[ks].v);
+      if (ks == 0) sn[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0].v, qf[qb][0].v, (f32x16)(0.f), 0, 0, 0);
+      else mma32(sn[qb], kf[ks], qf[qb][ks]);
+      PIN(sn[qb]);
+      exps((16 * c + 3) / 6, (16 * (c + 1) + 3) / 6, 0);
+      FENCE();
+    }
+    if (!(ABL & 16)) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vf[1][dt].u = *reinterpret_cast<const u32x4*>(vcol + dt * 32 * RSV + 32);
+    }
+    // chunks 6..9: P.V of the first 16 keys, the second 16 exponentials (4 each) behind them
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int dt = c >> 1, qb = c & 1;
+      mma32(o[qb][dt], vf[0][dt].f, pf[0][qb]);
+      PIN(o[qb][dt]);
+      exps(4 * c, 4 * c + 4, 1);
+      FENCE();
+    }
+    // chunks 10..13: P.V of the second 16 keys beside the maxima of the new scores (one query block's chain per gap pair)
+    float mt[QB];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int dt = c >> 1, qb = c & 1;
+      mma32(o[qb][dt], vf[1][dt].f, pf[1][qb]);
+      PIN(o[qb][dt]);
+      if (ABL & 8) {
+        if (c < 2) mt[c] = sn[c][0];
+      } else if (c < 2) {
+        PIN(sn[c]);
+        float m1 = fmaxf(fmaxf(sn[c][0], sn[c][1]), sn[c][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) m1 = fmaxf(fmaxf(m1, sn[c][r]), sn[c][r + 1]);
+        m1 = fmaxf(m1, sn[c][15]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m1), __float_as_uint(m1), false, false);
+        mt[c] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        PIN(mt[c]);
+      }
+      FENCE();
+    }
+    if (twin) store_out(ob_twin);
+    if (decide && __any(fmaxf(mt[0], mt[1]) > RESCALE_LAG)) rescale(sn, mt, false);
+  };
+#undef PIN
+#undef FENCE
+
+  int cur = 0;                                         // ring slot of tile `it`
+  for (int it = 0; it < ntiles; ++it) {
+    const int nxt = cur == NB - 1 ? 0 : cur + 1;
+    if (it > 0 && !(ABL & 1)) __syncthreads();         // every wave has finished iteration it - 1: slot (it + 2) % 3 = (it - 1) % 3 is free
+    if (!(ABL & 2)) {
+      if (it + 2 < ntiles && !(ABL & 64)) commit(nxt == NB - 1 ? 0 : nxt + 1);
+      if (it + 3 < ntiles && !(ABL & 32)) prefetch(it + 3);
+    }
+    const char* tK = smem + cur * TILE_BYTES + lr * RSK + lh * 16;
+    const char* tV = smem + cur * TILE_BYTES + KT * RSK + lr * RSV + lh * 16;
+    body(sA, sB, tK + 32 * RSK, tV, true, false);                                                        // S(it, 1) || P.V(it, 0)
+    body(sB, sA, smem + nxt * TILE_BYTES + lr * RSK + lh * 16, tV + 64, it + 1 < ntiles, ob_twin && it == nt0 - 1);   // S(it + 1, 0) || P.V(it, 1)
+    cur = nxt;
+  }
+  store_out(ob);
+}
+
+
+// ---- attn64d_kernel (round 4): attn64p's pipeline with the tiles staged by LDS-DMA ------------------------------------------------------
+// The timing ablations of attn64p (tools/abl_attn64.py, profiles/r4/abl_attn64_r4.txt) price the register staging of a tile at 17 % of the
+// kernel (the ds_write pass alone 10 %: 10 KB per workgroup and tile through the VGPR -> LDS store path, plus the vmcnt(0) in front of it) and
+// the fragment reads at 15 %.  Here a tile goes global -> LDS by `buffer_load_dwordx4 ... lds` (ten 1-KiB pieces per tile, two or three per
+// wave), TWO tiles ahead of its first reader, into a ring of four slots; no staging registers, no LDS stores, a counted vmcnt.
+// LDS image of a slot (the DMA writes 64 lanes x 16 B contiguously, so every layout decision sits in the per-lane SOURCE offset):
+//   K    64 rows x 80 B, packed.  Row i holds key pi(i) = i with bits 2 and 3 swapped: the score MFMA's output row (r & 3) + 8 (r >> 2) + 4 half
+//        then puts keys 8 half .. 8 half + 7 of a 16-key step into registers 8 s2 .. 8 s2 + 7 -- the P fragment is contiguous in the KEY
+//        order of V^T, which can therefore stay unpermuted.  The -M / zero padding of the third K-step (d = 40 .. 47) is one constant 16-byte
+//        vector that every upper-half lane reads (broadcast).  80-byte rows: the sixteen lanes of a ds_read_b128 group hit sixteen granules.
+//   V^T  40 rows x 128 B, 16-byte chunk c of row d at position c ^ ((d >> 1) & 7) (conflict-free for rows d = 32 dt + lane); the ones row
+//        (d = 40, the softmax denominator) and the zero rows above it are two more constant vectors inside the slot.
+constexpr int SLOT_K = KT * HD * 2, SLOT_V = HD * KT * 2, SLOT_CONST = SLOT_K + SLOT_V, SLOT_BYTES = SLOT_CONST + 64, NSLOT = 4;
+
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+#define PIN(x) asm volatile("" : "+v"(x))
+__global__ __launch_bounds__(NT, 2) void attn64d_kernel(AttnParams p) {
+  typedef bf16_t T;
+  __shared__ __attribute__((aligned(1024))) char smem[NSLOT * SLOT_BYTES + 1024];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  int pair, qblk;
+  {
+    const int nqb = p.nqb, id = blockIdx.x;
+    if ((p.npairs & 7) == 0) {
+      const int xcd = id & 7, slot = id >> 3;
+      pair = xcd + 8 * (slot / nqb);
+      qblk = slot % nqb;
+    } else {
+      pair = id / nqb;
+      qblk = id - pair * nqb;
+    }
+  }
+  pair = p.npairs - 1 - pair;   // longest first (see attn64_kernel)
+  const int b = pair / p.heads, head = pair - b * p.heads;
+  const int bo = b / p.bdiv, bi = b - bo * p.bdiv;
+  const int q0 = (qblk * NW + wid) * (32 * QB);
+  const T* qb_ = reinterpret_cast<const T*>(p.q) + bo * p.q_bs0 + bi * p.q_bs1 + (long)head * HD;
+  T* ob = reinterpret_cast<T*>(p.o) + bo * p.o_bs0 + bi * p.o_bs1 + (long)head * HD;
+
+  Frag<T> qf[QB][KSQ];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const T* qrow = qb_ + (long)(q0 + 32 * qb + lr) * p.q_ts;
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      const int d = 16 * ks + 8 * lh;
+      if (d < HD) {
+        frag_load(qf[qb][ks], qrow + d);
+        float q8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q8[j] = frag_get(qf[qb][ks], j) * p.scale_log2e;
+        frag_set8(qf[qb][ks], q8);
+      } else {
+        qf[qb][ks].zero();
+      }
+    }
+  }
+  f32x16 o[QB][DT];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int i = 0; i < DT; ++i) o[qb][i] = (f32x16)(0.f);
+  float m_run[QB] = {0.f, 0.f};
+
+  const bool has2 = p.k2 != nullptr && p.nk2 > 0 && b >= p.seg2_first_batch;
+  const int nt0 = p.nk / KT;
+  const int ntiles = nt0 + (has2 ? p.nk2 / KT : 0);
+  const T* kb0 = reinterpret_cast<const T*>(p.k) + bo * p.k_bs0 + bi * p.k_bs1 + (long)head * HD;
+  const T* vb0 = reinterpret_cast<const T*>(p.v) + bo * p.v_bs0 + bi * p.v_bs1 + (long)head * HD * p.v_ts;
+  const int b2 = b / p.k2_bdiv;
+  const T* kb1 = has2 ? reinterpret_cast<const T*>(p.k2) + b2 * p.k2_bs + (long)head * HD : kb0;
+  const T* vb1 = has2 ? reinterpret_cast<const T*>(p.v2) + b2 * p.v2_bs + (long)head * HD * p.v2_ts : vb0;
+  // (descriptors are built at the point of use from wave-uniform 64-bit bases: a SELECT between two descriptors makes hipcc keep them in
+  // memory and wrap every DMA in a waterfall loop with a full vmcnt(0) -- guide T20)
+  auto uni = [](const T* ptr) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return reinterpret_cast<const T*>(((unsigned long long)hi << 32) | lo);
+  };
+  const T* kseg = uni(kb0);
+  const T* vseg = uni(vb0);
+  int kts2 = __builtin_amdgcn_readfirstlane((int)p.k_ts * 2);     // bytes per key row of the current segment
+
+  // constants of every slot: [1 1 0 0 0 0 0 0] (K padding against -M), eight ones (V^T row 40), zeros (rows 41 ..)
+  if (tid < NSLOT * 12) {
+    const int sl = tid / 12, w = tid % 12;
+    unsigned v = 0;
+    if (w == 0) v = 0x3F803F80u;                       // two bf16 ones
+    if (w >= 4 && w < 8) v = 0x3F803F80u;
+    *reinterpret_cast<unsigned*>(smem + sl * SLOT_BYTES + SLOT_CONST + 4 * w) = v;
+  }
+
+  // ---- DMA pieces of this wave: K piece `wid`, V^T piece `wid`, and the fifth K / V^T piece on waves 0 / 1.  Per-lane source offsets
+  // (bytes from the segment's base; the tile's position goes into the scalar offset).
+  unsigned offK = 0, offV = 0, offX = 0;
+  auto seg_offsets = [&](bool s1) {
+    const long kts = s1 ? p.k2_ts : p.k_ts, vts = s1 ? p.v2_ts : p.v_ts;
+    auto koff = [&](int piece) {
+      const int v = piece * 64 + lane, i = v / NVK, vc = v - i * NVK;
+      const int key = (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
+      return (unsigned)(key * kts * 2 + vc * 16);
+    };
+    auto voff = [&](int piece) {
+      const int v = piece * 64 + lane, d = v >> 3, sl = v & 7, c = sl ^ ((d >> 1) & 7);
+      return (unsigned)(d * vts * 2 + c * 16);
+    };
+    offK = koff(wid);
+    offV = voff(wid);
+    offX = wid == 0 ? koff(4) : voff(4);
+  };
+  seg_offsets(false);
+  const int npieces = wid < 2 ? 3 : 2;
+  auto issue_tile = [&](int it) {                      // the pieces of tile `it` into ring slot it % NSLOT (tiles strictly in order)
+    if (it == nt0) {                                   // the bank segment starts: its bases, strides and per-lane offsets
+      kseg = uni(kb1);
+      vseg = uni(vb1);
+      kts2 = __builtin_amdgcn_readfirstlane((int)p.k2_ts * 2);
+      seg_offsets(true);
+    }
+    const int kt = it >= nt0 ? it - nt0 : it;
+    char* slot = smem + (it & (NSLOT - 1)) * SLOT_BYTES;
+    const int sK = kt * KT * kts2, sV = kt * KT * 2;
+    const __amdgpu_buffer_rsrc_t rK = dma_rsrc(kseg), rV = dma_rsrc(vseg);
+    blds16(rK, offK, sK, slot + wid * 1024);
+    blds16(rV, offV, sV, slot + SLOT_K + wid * 1024);
+    if (wid == 0) blds16(rK, offX, sK, slot + 4 * 1024);
+    if (wid == 1) blds16(rV, offX, sV, slot + SLOT_K + 4 * 1024);
+  };
+
+  // ---- fragment read offsets inside a slot
+  int kofs[KSQ];                                        // K rows of half tile 0 (half tile 1: + 32 rows)
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) kofs[ks] = (ks == 2 && lh == 1) ? SLOT_CONST - 32 * HD * 2 * 0 : lr * (HD * 2) + ks * 32 + lh * 16;
+  // (the padding vector is addressed slot-relative like the rows; body() adds the half tile's row offset only to real rows)
+  const bool kpad = lh == 1;                            // lanes whose third K-step reads the constant vector
+  int vofs[2][2][DT];                                   // [half tile][s2][dt]
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int d = 32 * dt + lr, c = 4 * hf + 2 * s2 + lh;
+        vofs[hf][s2][dt] = d < HD ? SLOT_K + d * 128 + ((c ^ ((d >> 1) & 7)) << 4) : d == HD ? SLOT_CONST + 16 : SLOT_CONST + 32;
+      }
+
+  auto store_out = [&](T* base) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      constexpr int R = HD % 32, REG = (R & 3) + 4 * (R >> 3), LHS = (R >> 2) & 1;
+      const float mine = o[qb][HD / 32][REG], other = __shfl_xor(mine, 32);
+      const float inv = 1.f / (lh == LHS ? mine : other);
+      T* orow = base + (long)(q0 + 32 * qb + lr) * p.o_ts;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * lh;
+          if (d < HD) {
+            union { bf16_t e[4]; u32x2 u; } pk4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk4.e[e] = f32_to_bf16(o[qb][dt][4 * g + e] * inv);
+            *reinterpret_cast<u32x2*>(orow + d) = pk4.u;
+          }
+        }
+    }
+  };
+  T* ob_twin = p.o_twin ? reinterpret_cast<T*>(p.o_twin) + bo * p.o_bs0 + bi * p.o_bs1 + (long)head * HD : nullptr;
+
+  auto rescale = [&](f32x16 (&sn)[QB], const float (&mt)[QB], bool first) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float delta = first ? mt[qb] : fmaxf(mt[qb], 0.f);
+      const float m_new = m_run[qb] + delta;
+      const float hi = Elem<T>::cvt(m_new), lo = Elem<T>::cvt(m_new - hi);
+      delta = (hi + lo) - m_run[qb];
+      if (lh == 1) {
+        qf[qb][KSQ - 1].set(0, -hi);
+        qf[qb][KSQ - 1].set(1, -lo);
+      }
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+      m_run[qb] += delta;
+#pragma unroll
+      for (int i = 0; i < DT; ++i) o[qb][i] *= alpha;
+      sn[qb] -= delta;
+    }
+  };
+  auto tile_max = [&](const f32x16 (&sn)[QB], float (&mt)[QB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float m1 = fmaxf(fmaxf(sn[qb][0], sn[qb][1]), sn[qb][2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) m1 = fmaxf(fmaxf(m1, sn[qb][r]), sn[qb][r + 1]);
+      m1 = fmaxf(m1, sn[qb][15]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m1), __float_as_uint(m1), false, false);
+      mt[qb] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+  };
+  auto kfrag = [&](Frag<T>& f, const char* slot, int hf, int ks) __attribute__((always_inline)) {
+    const int off = (ks == 2 && kpad) ? SLOT_CONST : kofs[ks] + hf * 32 * HD * 2;
+    frag_load(f, reinterpret_cast<const T*>(slot + off));
+  };
+
+  // ---- prologue: tiles 0, 1, 2 on their way, tiles 0 and 1 landed; the scores of half tile 0 ----
+  issue_tile(0);
+  if (ntiles > 1) issue_tile(1);
+  if (ntiles > 2) issue_tile(2);
+  if (ntiles > 2) { if (npieces == 3) wait_vmcnt<3>(); else wait_vmcnt<2>(); } else wait_vmcnt<0>();
+  __syncthreads();
+  f32x16 sA[QB], sB[QB];
+  {
+    Frag<T> kf[KSQ];
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) kfrag(kf[ks], smem, 0, ks);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) sA[qb] = (f32x16)(0.f);
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks)
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) mma32(sA[qb], kf[ks], qf[qb][ks]);
+    float mt[QB];
+    tile_max(sA, mt);
+    rescale(sA, mt, true);
+  }
+
+  // Fragment registers are double-buffered across bodies: a body multiplies with the K / first-V^T fragments its predecessor read for it and
+  // reads its successor's behind its last score MFMA (the LDS round trip of five ds_read_b128 is off the wave's critical path; the
+  // ablation that removed the fragment reads altogether ran 15 % faster).
+  union VF { u32x4 u; Frag<T> f; };
+  auto body = [&](f32x16 (&sp)[QB], f32x16 (&sn)[QB], Frag<T> (&kf)[KSQ], VF (&vf0)[DT], Frag<T> (&kfn)[KSQ], VF (&vf0n)[DT], const char* vslot, int vhf,
+                  const char* kslot_n, int khf_n, const char* vslot_n, int vhf_n, bool decide, bool twin) __attribute__((always_inline)) {
+    VF vf1[DT];
+    float ex[2][16];
+    Frag<T> pf[2][QB];
+    auto exps = [&](int e0, int e1, int s2) __attribute__((always_inline)) {
+#pragma unroll
+      for (int e = e0; e < e1; ++e) PIN(sp[e >> 3][8 * s2 + (e & 7)]);
+#pragma unroll
+      for (int e = e0; e < e1; ++e) ex[e >> 3][8 * s2 + (e & 7)] = __builtin_amdgcn_exp2f(sp[e >> 3][8 * s2 + (e & 7)]);
+#pragma unroll
+      for (int e = e0; e < e1; ++e) {
+        const int eq = e >> 3;
+        if ((e & 7) == 7) {
+          float p8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) p8[j] = ex[eq][8 * s2 + j];
+          frag_set8(pf[s2][eq], p8);
+          PIN(pf[s2][eq].v);
+        } else {
+          PIN(ex[eq][8 * s2 + (e & 7)]);
+        }
+      }
+    };
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vf1[dt].u = *reinterpret_cast<const u32x4*>(vslot + vofs[vhf][1][dt]);
+    FENCE();
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const int ks = c >> 1, qb = c & 1;
+      if (qb == 0) PIN(kf[ks].v);
+      if (ks == 0) sn[qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0].v, qf[qb][0].v, (f32x16)(0.f), 0, 0, 0);
+      else mma32(sn[qb], kf[ks], qf[qb][ks]);
+      PIN(sn[qb]);
+      exps((16 * c + 3) / 6, (16 * (c + 1) + 3) / 6, 0);
+      FENCE();
+    }
+    // the successor's K fragments (this body's are consumed)
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) kfrag(kfn[ks], kslot_n, khf_n, ks);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int dt = c >> 1, qb = c & 1;
+      mma32(o[qb][dt], vf0[dt].f, pf[0][qb]);
+      PIN(o[qb][dt]);
+      exps(4 * c, 4 * c + 4, 1);
+      FENCE();
+    }
+    // ... and its first V^T fragments
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vf0n[dt].u = *reinterpret_cast<const u32x4*>(vslot_n + vofs[vhf_n][0][dt]);
+    float mt[QB];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int dt = c >> 1, qb = c & 1;
+      mma32(o[qb][dt], vf1[dt].f, pf[1][qb]);
+      PIN(o[qb][dt]);
+      if (c < 2) {
+        PIN(sn[c]);
+        float m1 = fmaxf(fmaxf(sn[c][0], sn[c][1]), sn[c][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) m1 = fmaxf(fmaxf(m1, sn[c][r]), sn[c][r + 1]);
+        m1 = fmaxf(m1, sn[c][15]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m1), __float_as_uint(m1), false, false);
+        mt[c] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        PIN(mt[c]);
+      }
+      FENCE();
+    }
+    if (twin) store_out(ob_twin);
+    if (decide && __any(fmaxf(mt[0], mt[1]) > RESCALE_LAG)) rescale(sn, mt, false);
+  };
+
+  Frag<T> kfA[KSQ], kfB[KSQ];
+  VF vfA[DT], vfB[DT];
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) kfrag(kfA[ks], smem, 1, ks);                                        // S(0, 1)
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) vfA[dt].u = *reinterpret_cast<const u32x4*>(smem + vofs[0][0][dt]);   // P.V(0, 0)
+  for (int it = 0; it < ntiles; ++it) {
+    if (it > 0) {
+      // tile it + 1 (issued two iterations ago) has landed -- this wave's pieces: only those of tile it + 2 may still be in flight --
+      // and, behind the barrier, everybody's; the barrier also frees slot (it + 3) % 4 = (it - 1) % 4, last read in iteration it - 1
+      // (the fragments read ahead at the end of iteration it - 1 come from tile it's slot)
+      if (it + 2 < ntiles) { if (npieces == 3) wait_vmcnt<3>(); else wait_vmcnt<2>(); } else wait_vmcnt<0>();
+      __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's fragment reads have returned
+      __builtin_amdgcn_s_barrier();
+    }
+    if (it + 3 < ntiles) issue_tile(it + 3);
+    const char* cur = smem + (it & (NSLOT - 1)) * SLOT_BYTES;
+    const char* nxt = smem + ((it + 1) & (NSLOT - 1)) * SLOT_BYTES;
+    // S(it, 1) || P.V(it, 0); reads ahead: K(it + 1, 0), V(it, 1)
+    body(sA, sB, kfA, vfA, kfB, vfB, cur, 0, nxt, 0, cur, 1, true, false);
+    // S(it + 1, 0) || P.V(it, 1); reads ahead: K(it + 1, 1), V(it + 1, 0)
+    body(sB, sA, kfB, vfB, kfA, vfA, cur, 1, nxt, 1, nxt, 0, it + 1 < ntiles, ob_twin && it == nt0 - 1);
+  }
+  store_out(ob);
+}
+#undef PIN
+#undef FENCE
+
 }  // namespace
 
 // attention.hip's dispatcher: bf16, head_dim 40, V transposed, nq % 256 == 0, nk % 64 == 0, nk2 % 64 == 0
+int g_attn64_ver = 3;       // mmgt_tune("attn64_ver", 1 / 2 / 3): 1 = attn64_kernel (phased), 2 = attn64p_kernel (pipelined over half tiles), 3 = attn64d_kernel (+ LDS-DMA staging)
+void mmgt_attn64_set_ver(int v) { g_attn64_ver = v; }
+int g_attn64_nw = 4;        // mmgt_tune("attn64_nw", 4 / 8): waves per workgroup of attn64p_kernel
+void mmgt_attn64_set_nw(int v) { g_attn64_nw = v; }
+int g_attn64_abl = 0;
+void mmgt_attn64_set_abl(int v) { g_attn64_abl = v; }
 int g_attn64_lds_pad = 0;   // mmgt_tune("attn64_pad", bytes): extra dynamic LDS per workgroup (experiment: 96 KiB forces one workgroup per CU)
 void mmgt_attn64_set_pad(int v) { g_attn64_lds_pad = v; }
 
@@ -350,6 +1023,41 @@ int mmgt_attn64_launch(const void* params, int batch, int heads, void* stream) {
 #if ATTN_TRACE
   hipLaunchKernelGGL(attn64_kernel, dim3((unsigned)((long)p.nqb * batch * heads)), dim3(NT), (size_t)g_attn64_lds_pad, (hipStream_t)stream, p, g_attn64_trace);
 #else
+  if (g_attn64_ver == 3) {
+    hipLaunchKernelGGL(attn64d_kernel, dim3((unsigned)((long)p.nqb * batch * heads)), dim3(NT), 0, (hipStream_t)stream, p);
+    MMGT_LAUNCH_CHECK();
+    return 0;
+  }
+  if (g_attn64_ver == 2) {
+    const dim3 grid((unsigned)((long)p.nqb * batch * heads));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t pad = (size_t)g_attn64_lds_pad;       // (experiment: dynamic LDS on top of the 48 KiB ring forces one workgroup per CU)
+#define ATTN64P(A) { if (pad) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn64p_kernel<A, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad); \
+                     hipLaunchKernelGGL((attn64p_kernel<A, 4>), grid, dim3(NT), pad, s, p); }
+    if (g_attn64_nw == 8 && p.nq % 512 == 0) {        // 8 waves per workgroup: 512 queries share a staged tile
+      p.nqb = p.nq / 512;
+      if (g_attn64_abl == 2) hipLaunchKernelGGL((attn64p_kernel<2, 8>), dim3((unsigned)((long)p.nqb * batch * heads)), dim3(512), 0, s, p);
+      else hipLaunchKernelGGL((attn64p_kernel<0, 8>), dim3((unsigned)((long)p.nqb * batch * heads)), dim3(512), 0, s, p);
+      MMGT_LAUNCH_CHECK();
+      return 0;
+    }
+    switch (g_attn64_abl) {
+      case 1: ATTN64P(1) break;
+      case 2: ATTN64P(2) break;
+      case 3: ATTN64P(3) break;
+      case 4: ATTN64P(4) break;
+      case 8: ATTN64P(8) break;
+      case 16: ATTN64P(16) break;
+      case 19: ATTN64P(19) break;
+      case 32: ATTN64P(32) break;
+      case 64: ATTN64P(64) break;
+      case 31: ATTN64P(31) break;
+      default: ATTN64P(0)
+    }
+#undef ATTN64P
+    MMGT_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(attn64_kernel, dim3((unsigned)((long)p.nqb * batch * heads)), dim3(NT), (size_t)g_attn64_lds_pad, (hipStream_t)stream, p);
 #endif
   MMGT_LAUNCH_CHECK();

@@ -907,6 +907,9 @@ void mmgt_ffn_set_dbg(int v);
 void mmgt_ffn_set_ver(int v);
 void mmgt_rowgemm_set_dbg(int v);
 void mmgt_attn64_set_pad(int v);
+void mmgt_attn64_set_ver(int v);
+void mmgt_attn64_set_abl(int v);
+void mmgt_attn64_set_nw(int v);
 // Switches of the HOST side of the operator (mmgt_amd/unet3d.py, pipeline.py, smga.py read them through mmgt_tune_get): they live here,
 // beside the kernel knobs, so that ONE state -- this table -- describes what a run executed (MMGT_TUNE="twin_attention=0,splitk=0").
 namespace {
@@ -945,6 +948,9 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "splitk")) { g_splitk = value; return 0; }
   if (key && !strcmp(key, "tailsplit")) { g_tailsplit = value; return 0; }
   if (key && !strcmp(key, "attn64_pad")) { mmgt_attn64_set_pad(value); return 0; }
+  if (key && !strcmp(key, "attn64_ver") && value >= 1 && value <= 3) { mmgt_attn64_set_ver(value); return 0; }
+  if (key && !strcmp(key, "attn64_abl")) { mmgt_attn64_set_abl(value); return 0; }
+  if (key && !strcmp(key, "attn64_nw") && (value == 4 || value == 8)) { mmgt_attn64_set_nw(value); return 0; }
   if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 4) { mmgt_ffn_set_dbg(value); return 0; }
   if (key && !strcmp(key, "rowgemm_dbg") && value >= 0 && value <= 5) { mmgt_rowgemm_set_dbg(value); return 0; }
   if (key && !strcmp(key, "ffn_ver") && (value == 3 || value == 4)) { mmgt_ffn_set_ver(value); return 0; }

@@ -456,9 +456,19 @@ def test_attention_spatial_with_bank(dt, hd, nq, nk2, vt):
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
 
-@pytest.mark.parametrize("hd,a64", [(40, 1), (40, 0), (80, 1)])
+def _set_attn64(a64):
+    """a64 = 0: the 32-queries-per-wave kernel of attention.hip; 1 / 2 / 3: attn64.hip's phased, pipelined and DMA-staged kernels; None: default."""
+    from mmgt_amd import hip
+    hip.tune("attn64", 1 if a64 is None else min(a64, 1))
+    hip.tune("attn64_ver", ATTN64_DEFAULT_VER if a64 is None else max(a64, 1))
+
+
+ATTN64_DEFAULT_VER = 3
+
+
+@pytest.mark.parametrize("hd,a64", [(40, 1), (40, 2), (40, 3), (40, 0), (80, 1)])
 def test_attention_online_softmax_rescale_branch_is_forced(hd, a64):
-    """(a64: the 64-queries-per-wave kernel of attn64.hip, the production path at head_dim 40, on / off.)
+    """(a64: the 64-queries-per-wave kernels of attn64.hip, the production path at head_dim 40 -- 1 phased, 2 pipelined, 3 DMA-staged -- or off.)
     The rare, data-dependent branch of the online softmax (guide rule 26): one key row per later tile is spiked against one query
     so that query's running maximum jumps mid-sequence (own keys and bank keys); full-tensor check against fp64, bf16, V transposed,
     whole 64-key tiles -- the production configuration of the spatial self-attention."""
@@ -487,17 +497,17 @@ def test_attention_online_softmax_rescale_branch_is_forced(hd, a64):
     vT, vbT = v.transpose(1, 2).contiguous(), vb.transpose(1, 2).contiguous()
     out = torch.empty_like(q)
     try:
-        hip.tune("attn64", a64)
+        _set_attn64(a64)
         hip.attention(q, k, vT, out, batch=B, heads=heads, hd=hd, nq=nq, nk=nq, scale=scale, q_str=(nq * inner, 0, inner),
                       k_str=(nq * inner, 0, inner), v_str=(vT.stride(0), 0, vT.stride(1)), o_str=(nq * inner, 0, inner),
                       v_transposed=True, k2=kb, v2=vbT, k2_str=(kb.stride(0), inner), v2_str=(vbT.stride(0), vbT.stride(1)),
                       k2_bdiv=2, nk2=nk2, seg2_first_batch=2)
     finally:
-        hip.tune("attn64", 1)
+        _set_attn64(None)
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
 
-@pytest.mark.parametrize("a64", [0, 1])
+@pytest.mark.parametrize("a64", [0, 1, 2, 3])
 def test_attention_run_to_run_deterministic(a64):
     """Identical launches give bitwise identical results (a data race between the staging writes and the fragment reads of the
     flash attention kernels would show as a result that changes from launch to launch): spatial shape with bank, head_dim 40,
@@ -517,7 +527,7 @@ def test_attention_run_to_run_deterministic(a64):
                       k2_str=(kb.stride(0), kb.stride(1)), v2_str=(vbt.stride(0), vbt.stride(1)), k2_bdiv=B // 2, nk2=n,
                       seg2_first_batch=B // 2)
     try:
-        hip.tune("attn64", a64)
+        _set_attn64(a64)
         run()
         first = o.clone()
         for _ in range(12):
@@ -525,7 +535,7 @@ def test_attention_run_to_run_deterministic(a64):
             run()
             assert torch.equal(o, first)
     finally:
-        hip.tune("attn64", 1)
+        _set_attn64(None)
 
 
 @pytest.mark.parametrize("dt", DT)
@@ -547,8 +557,9 @@ def test_attention_temporal_layout(dt, hd, frames, hw):
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
 
+@pytest.mark.parametrize("a64", [1, 2, 3])
 @pytest.mark.parametrize("nq,nk2,frames", [(256, 128, 2), (512, 256, 3)])
-def test_attention_twin_output_is_the_own_key_attention(nq, nk2, frames):
+def test_attention_twin_output_is_the_own_key_attention(nq, nk2, frames, a64):
     """mmgt_attention_twin: one pass over [own keys | bank] per frame writes the attention over both segments AND, as the state after the
     last own-key tile, the attention over the own keys alone -- bitwise what two separate launches compute (the CFG pair of the first
     reference-attention reader: mmgt_amd/unet3d.py _spatial_transformer_twin)."""
@@ -567,10 +578,14 @@ def test_attention_twin_output_is_the_own_key_attention(nq, nk2, frames):
                 seg2_first_batch=0)
     both = torch.empty((frames, nq, inner), device=dev(), dtype=dt)
     twin = torch.empty_like(both)
-    hip.attention(qk, qk[..., inner:], vt, both, twin_out=twin, **common, **seg2)
     ref_both, ref_own = torch.empty_like(both), torch.empty_like(both)
-    hip.attention(qk, qk[..., inner:], vt, ref_both, **common, **seg2)
-    hip.attention(qk, qk[..., inner:], vt, ref_own, **common)
+    try:
+        _set_attn64(a64)
+        hip.attention(qk, qk[..., inner:], vt, both, twin_out=twin, **common, **seg2)
+        hip.attention(qk, qk[..., inner:], vt, ref_both, **common, **seg2)
+        hip.attention(qk, qk[..., inner:], vt, ref_own, **common)
+    finally:
+        _set_attn64(None)
     assert torch.equal(both, ref_both) and torch.equal(twin, ref_own)
     sp = lambda t, n: t.double().reshape(frames, n, heads, hd).permute(0, 2, 1, 3)
     want = _ref_attn(sp(qk[..., :inner], nq), sp(qk[..., inner:], nq), sp(v, nq), hd ** -0.5).permute(0, 2, 1, 3).reshape(frames, nq, inner)
