@@ -274,10 +274,14 @@ int mmgt_window_stack(const float* x, float* out, int frames, long D, int half, 
  * (x / 2 + 0.5).clamp(0, 1) (pipeline_pose2vid_long.py:121-123) fused with save_videos_grid's (x * 255).astype(uint8)
  * (src/utils/util.py:148-160). */
 int mmgt_frames_to_u8(const void* x, unsigned char* out, long npix, int cpad, float scale, float shift, int dtype, void* stream);
-/* SYNTHETIC stand-in for the DWPose drawing (src/dwpose/util.py, out of scope): channel c of frame t = 255 within `radius` pixels of
- * a key point k in [lohi[2c], lohi[2c+1]) with score > 0.3; kp (frames, npoints, 3) = (x, y, score), x / y in [0, 1]. */
-int mmgt_splat_keypoints(const float* kp, unsigned char* out, int frames, int npoints, int H, int W, int channels, const int* lohi,
-                         float radius, void* stream);
+/* SMGA key points -> the four frame streams of Stage 2, drawn on the device: kp (frames, 134, 3) fp32 = SMGA's normalised
+ * (x, y, score) features.  Replaces data/extract_movment_mask_all.py:319-321 `pose_vid_generator` (denormalize :128-132, mask_leg :66-89,
+ * process_keypoints :98-119), src/dwpose/__init__.py:220-283 `DWposeDetector_movment_mask.__call__` with draw_pose / draw_pose_mask_head /
+ * _lips / _hand (:133-196) and src/dwpose/util.py:79-157,160-206,208-230,291-302,349-388 (cv2.ellipse2Poly, fillConvexPoly, line, circle
+ * restated), and the mp4 write / read round trip of scripts/audio2vid.py:386,426-430.  pose (frames, 512, 512, 3) u8; hands / lips / face
+ * masks (frames, 512, 512) u8 (face = face box + hand boxes with the reference's uint8 wrap-around).  H = W = 512 (the reference's canvas). */
+int mmgt_dwpose_draw(const float* kp, unsigned char* pose, unsigned char* hands_mask, unsigned char* lips_mask, unsigned char* face_mask,
+                     int frames, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,9 @@ run the same producers on the GPU through libmmgt_hip.so (csrc/conditioning.hip,
                             two-pass fixed-point resampling from the integer coefficient tables computed here exactly as
                             Pillow's Resample.c does -- bit-exact with PIL (tests/test_conditioning.py)
   * process_audio_emb_device
+  * pose_frames_device      data/extract_movment_mask_all.py:319-321 `pose_vid_generator` + src/dwpose: SMGA key points -> the pose
+                            frames PoseGuider reads and the face / lips / hands mask frames, drawn on the device (csrc/dwpose.hip) instead of
+                            four mp4 files written and read back (scripts/audio2vid.py:386,426-441)
 """
 import math
 from typing import List
@@ -117,3 +120,25 @@ def blur_mask_device(masks_u8: torch.Tensor, kernel_size: int) -> torch.Tensor:
 def process_audio_emb_device(audio_emb: torch.Tensor) -> torch.Tensor:
     from . import hip
     return hip.window_stack(audio_emb.to(torch.float32).contiguous(), 2)
+
+
+def pose_frames_device(kp_normalised: torch.Tensor, height: int = 512, width: int = 512):
+    """kp_normalised (L, 402) fp32 on the GPU: SMGA's output after the seam smoothing (scripts/audio2vid.py:351-376) ->
+    (pose (1, 3, L, height, width) fp32 in [0, 1] = ToTensor of the drawn frames after transforms.Resize((height, width)), :436-441;
+     face_u8, lips_u8, hands_u8 (L, 512, 512) uint8 mask frames for blur_mask_device).  The reference draws at 512 x 512; other square
+    sizes go through PIL's bilinear resampling per channel (what torchvision's Resize on a PIL image is), bit-exact with PIL."""
+    from . import hip
+    kp = kp_normalised.to(torch.float32).reshape(kp_normalised.shape[0], 134, 3).contiguous()
+    pose_u8, hands, lips, face = hip.dwpose_draw(kp)
+    if (height, width) == (512, 512):
+        pose = pose_u8.permute(3, 0, 1, 2)[None].to(torch.float32) / 255.0
+    else:
+        if height != width:
+            raise NotImplementedError("pose_frames_device: square frames only (the reference's configs are 512 x 512)")
+        key = (512, height, pose_u8.device)
+        if key not in _TABLES:
+            b, c = pil_bilinear_tables(512, height)
+            _TABLES[key] = (b.to(pose_u8.device), c.to(pose_u8.device))
+        chans = [hip.resample_u8(pose_u8[..., ch].contiguous(), height, *_TABLES[key]) for ch in range(3)]
+        pose = torch.stack(chans, 0)[None]
+    return pose.contiguous(), face, lips, hands

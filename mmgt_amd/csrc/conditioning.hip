@@ -13,9 +13,6 @@
 //  * mmgt_frames_to_u8      the output path, src/utils/util.py:148-160 `save_videos_grid`: (x * 255).astype(uint8) of the
 //                           decoded frames, fused with decode_latents' (x / 2 + 0.5).clamp(0, 1)
 //                           (pipeline_pose2vid_long.py:121-123) and the layout change to (frame, h, w, rgb).
-//  * mmgt_splat_keypoints   a SYNTHETIC stand-in for the DWPose drawing code (src/dwpose/util.py, cv2 polygons; out of
-//                           scope): discs at the key points, so that scripts/audio2vid.py --synthetic can chain SMGA's
-//                           key points into the Stage-2 sampler.  Not a parity surface.
 #include "common.h"
 #include "mmgt_hip.h"
 
@@ -144,26 +141,6 @@ __global__ void frames_to_u8_kernel(const T* __restrict__ x, unsigned char* __re
   }
 }
 
-// key points (T, K, 3) = (x, y, score) with x, y in [0, 1]; channel c of frame t gets 255 inside radius `rad` of any key point
-// k with lo[c] <= k < hi[c] and score > 0.3
-__global__ void splat_kernel(const float* __restrict__ kp, unsigned char* __restrict__ out, int T, int K, int H, int W, int C,
-                             const int* __restrict__ lohi, float rad) {
-  const long total = (long)T * H * W * C;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    long r = i / C;
-    const int x = (int)(r % W);
-    r /= W;
-    const int y = (int)(r % H), t = (int)(r / H);
-    bool hit = false;
-    for (int k = lohi[2 * c]; k < lohi[2 * c + 1] && !hit; ++k) {
-      const float* q = kp + ((long)t * K + k) * 3;
-      const float dx = q[0] * W - (x + 0.5f), dy = q[1] * H - (y + 0.5f);
-      hit = q[2] > 0.3f && dx * dx + dy * dy <= rad * rad;
-    }
-    out[i] = hit ? 255 : 0;
-  }
-}
 
 inline int grid_for(long n) {
   long g = (n + 255) / 256;
@@ -213,11 +190,3 @@ extern "C" int mmgt_frames_to_u8(const void* x, unsigned char* out, long npix, i
   return 0;
 }
 
-extern "C" int mmgt_splat_keypoints(const float* kp, unsigned char* out, int frames, int npoints, int H, int W, int channels,
-                                    const int* lohi, float radius, void* stream) {
-  MMGT_CHECK(kp && out && lohi && frames > 0 && npoints > 0 && H > 0 && W > 0 && channels > 0, "splat_keypoints: bad arguments");
-  hipLaunchKernelGGL(splat_kernel, dim3(grid_for((long)frames * H * W * channels)), dim3(256), 0, (hipStream_t)stream, kp, out,
-                     frames, npoints, H, W, channels, lohi, radius);
-  MMGT_LAUNCH_CHECK();
-  return 0;
-}

@@ -83,7 +83,7 @@ _SIGS = {
     "mmgt_resample_u8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "mmgt_window_stack": (c_int, [c_void_p, c_void_p, c_int, c_long, c_int, c_void_p]),
     "mmgt_frames_to_u8": (c_int, [c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_int, c_void_p]),
-    "mmgt_splat_keypoints": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p]),
+    "mmgt_dwpose_draw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mmgt_accumulate_window_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                             c_int, c_int, c_int, c_int, c_void_p]),
 }
@@ -692,11 +692,15 @@ def frames_to_u8(x, scale=0.5, shift=0.5):
     return out
 
 
-def splat_keypoints(kp, H, W, lohi, radius):
-    _dev(kp, lohi)
-    assert kp.dtype == torch.float32 and kp.dim() == 3 and kp.shape[2] == 3 and kp.is_contiguous() and lohi.dtype == torch.int32
-    C = lohi.shape[0]
-    out = torch.empty((kp.shape[0], H, W, C), device=kp.device, dtype=torch.uint8)
-    _check(lib().mmgt_splat_keypoints(_ptr(kp), _ptr(out), kp.shape[0], kp.shape[1], H, W, C, _ptr(lohi), radius, _stream()),
-           "mmgt_splat_keypoints")
-    return out
+
+def dwpose_draw(kp, H=512, W=512):
+    """SMGA's normalised key points (L, 402) or (L, 134, 3) fp32 -> (pose (L, H, W, 3), hands, lips, face (L, H, W)) uint8: the reference's
+    pose_vid_generator frames drawn on the device (see mmgt_dwpose_draw)."""
+    _dev(kp)
+    kp = kp.reshape(kp.shape[0], 134, 3)
+    assert kp.dtype == torch.float32 and kp.is_contiguous()
+    L = kp.shape[0]
+    pose = torch.empty((L, H, W, 3), device=kp.device, dtype=torch.uint8)
+    hands, lips, face = (torch.empty((L, H, W), device=kp.device, dtype=torch.uint8) for _ in range(3))
+    _check(lib().mmgt_dwpose_draw(_ptr(kp), _ptr(pose), _ptr(hands), _ptr(lips), _ptr(face), L, H, W, _stream()), "mmgt_dwpose_draw")
+    return pose, hands, lips, face

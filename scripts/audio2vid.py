@@ -9,8 +9,8 @@ The chain is the reference's (line numbers of its scripts/audio2vid.py):
      conditioned on frame 59 of the previous one (or on the reference image's pose), optional 5-candidate motion selection
      (`find_best_slice`, :79-108)                                  -> mmgt_amd.smga.SMGA.render_sample (HIP)
   2. seam smoothing by cubic splines around every 60th frame (:351-374)   -> host numpy / scipy, as in the reference
-  3. key points -> pose / face / lips frames (:386, cv2 drawing of src/dwpose, out of scope) -> a SYNTHETIC disc renderer on the
-     device (mmgt_splat_keypoints) stands in, so the masks below are produced from SMGA's own output
+  3. key points -> pose / face / lips / hands frames (:386 `pose_vid_generator`: cv2 drawing of src/dwpose into four mp4 files, read
+     back at :426-430) -> drawn on the device, byte for byte the reference's frames (mmgt_dwpose_draw, csrc/dwpose.hip), no files
   4. wav2vec2 features of the waveform (:420-426, src/dataset/audio_processor.py:76-131) -> mmgt_amd.wav2vec.Wav2VecModel (HIP);
      mask blur + 4-level pyramid (:453-476), audio window stack + AudioProjModel (:426,439-441) -> device kernels
   5. Pose2VideoPipeline (:484-498), frames converted to uint8 on the device, written as .npy / .gif.
@@ -150,16 +150,10 @@ def main():
     tps_origin = np.concatenate([init_feature.numpy().astype(np.float32), np.concatenate(tps, 0)[:-1]], 0)  # :351-359
     kps = smooth_seams(tps_origin)[:a.L]                                                                     # (L, 402)
 
-    # ---- 3. key points -> pose / face / lips frames (synthetic stand-in for the DWPose drawing)
+    # ---- 3. key points -> pose / face / lips frames: the reference's DWPose drawing (data/extract_movment_mask_all.py:319-321,
+    # src/dwpose) on the device -- no mp4 files written and read back (:386,426-441)
     t0 = time.time()
-    kp = torch.from_numpy(kps).float().reshape(a.L, 134, 3).clone()
-    kp[..., :2] = (kp[..., :2].clamp(-1, 1) + 1) / 2
-    kp[..., 2] = 1.0
-    kp = kp.to(dev).contiguous()
-    groups = lambda g: torch.tensor(g, dtype=torch.int32, device=dev)
-    pose_u8 = hip.splat_keypoints(kp, a.H, a.W, groups([[0, 24], [92, 134], [24, 92]]), 4.0)               # body | hands | face
-    face_u8 = hip.splat_keypoints(kp, a.H, a.W, groups([[24, 92]]), 12.0)[..., 0].contiguous()
-    lips_u8 = hip.splat_keypoints(kp, a.H, a.W, groups([[72, 92]]), 8.0)[..., 0].contiguous()
+    pose, face_u8, lips_u8, _hands_u8 = C.pose_frames_device(torch.from_numpy(kps).to(dev), a.H, a.W)
     # ---- 4. conditioning on the device (:426,439-441,453-476)
     face = C.mask_pyramid_device(C.blur_mask_device(face_u8, 31), a.H)
     lips = C.mask_pyramid_device(C.blur_mask_device(lips_u8, 21), a.H)
@@ -175,7 +169,6 @@ def main():
     wave = ((wave - wave.mean()) / (wave.var(unbiased=False) + 1e-7).sqrt()).to(dev)                        # Wav2Vec2FeatureExtractor's normalisation
     feats = w2v.audio_emb(wave, a.L)                                                                        # (frames, 12 layers, 768)
     audio_tensor = audioproj(C.process_audio_emb_device(feats)[None])                                       # (1, L, 32, 768)
-    pose = (pose_u8.permute(3, 0, 1, 2)[None].float() / 255.0).contiguous()                                 # ToTensor: (1, 3, L, H, W)
     torch.cuda.synchronize()
     timing["conditioning_s"] = round(time.time() - t0, 3)
 
