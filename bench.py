@@ -34,6 +34,27 @@ EXEC_TFLOP_PER_STEP = 71.6      # as executed by the reference's op graph (quote
 VAE_TFLOP_PER_FRAME = 2.51
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 FRAMES, LATENT = 24, 64
+FULL_CPU_STEP = "profiles/r3/bench_full_cpu_baseline_r3.json"   # one measured full CFG step of the oracle on the GPU box's host cores
+
+
+def executed_tflop(hip):
+    """TFLOP one step of THIS build executes: SURVEY 8d's 62.0 minus the exact skips of the CFG pair that are switched on (DESIGN section 4;
+    each is work the reference performs on provably zero or identical operands).  Derived from the shapes, per switch of the mmgt_tune table."""
+    f, n0 = FRAMES, LATENT * LATENT                       # frames per CFG row, tokens per frame at level 0
+    t = ALGO_TFLOP_PER_STEP * 1e12
+    if hip.tune_get("zero_audio_skip") and hip.tune_get("oz3"):
+        # the unconditional row's audio cross-attention (zero keys / values -> output exactly 0): per MM-HAA module its q projection, the
+        # 32-key attention of the three branches and the 3 x inner columns of the merged out-projection (inner, tokens per frame) per module
+        for inner, n in ((320, n0), (320, n0), (320, n0 // 4), (640, n0 // 4), (640, n0 // 16), (1280, n0 // 16)):
+            rows = f * n
+            t -= 2.0 * rows * inner * 3 * inner + 4.0 * rows * 3 * inner * 32 + 2.0 * rows * inner * 3 * inner
+    if hip.tune_get("shared_rows"):
+        # conv_in and the first ResnetBlock3D on the f frames once (both rows enter with the same latents / pose / timestep)
+        t -= 2.0 * f * n0 * 320 * 36 + 2 * (2.0 * f * n0 * 320 * 9 * 320)
+        if hip.tune_get("twin_attention"):
+            # the first reference reader: GroupNorm / proj_in / q | k | v once, ONE attention pass over the own keys for both rows
+            t -= 4 * (2.0 * f * n0 * 320 * 320) + 4.0 * 8 * 40 * n0 * n0 * f
+    return t / 1e12
 
 
 def parse_args():
@@ -110,6 +131,14 @@ def cpu_baseline(sd_cpu, frames_sample=2):
             f"{dt:.1f} s" + (f", scaled x{FRAMES // frames_sample} to 24 frames" if frames_sample != FRAMES else " (measured, not scaled)"))
     rec = {"value": 1.0 / (dt * FRAMES / frames_sample), "unit": "steps/s", "cores": cores, "kind": "port", "sample": what,
            "cpu": _cpu_name()}
+    full = os.path.join(ROOT, FULL_CPU_STEP)
+    if frames_sample != FRAMES and os.path.exists(full):
+        # 128 cores are not filled by 2 frames, so the cost is NOT linear in frames: the stated baseline is the MEASURED full
+        # step (same oracle, same host class, committed); today's bounded sample and its linear scaling are reported beside it
+        m = json.load(open(full))["cpu_baseline"]
+        rec = {"value": m["value"], "unit": "steps/s", "cores": m["cores"], "kind": f"port, measured {FULL_CPU_STEP}",
+               "sample": m["sample"], "cpu": m["cpu"],
+               "todays_sample": {"value_scaled_linearly": 1.0 / (dt * FRAMES / frames_sample), "cores": cores, "cpu": _cpu_name(), "sample": what}}
     return rec, inp, out
 
 
@@ -128,6 +157,16 @@ def pmc_traffic():
         return None, None
     d = json.load(open(files[-1]))
     return d["total_GB_per_step"] * 1e9, os.path.relpath(files[-1], ROOT)
+
+
+def pmc_mfma_busy():
+    """Matrix-pipe busy fraction of the whole step from the committed PMC pass of this same command (profiles/r*/pmc_step_mfma*.json:
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE, tools/profile_bench.sh)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_step_mfma*.json")), key=os.path.getmtime)
+    if not files:
+        return None, None
+    return json.load(open(files[-1]))["mfma_busy"], os.path.relpath(files[-1], ROOT)
 
 
 def _cpu_name():
@@ -403,6 +442,10 @@ def main():
         per_gpu = a.steps / elapsed
         ach = ALGO_TFLOP_PER_STEP * a.steps / (dev_ms / 1e3)
         traffic, traffic_src = pmc_traffic()
+        from mmgt_amd import hip
+        exe = executed_tflop(hip) if a.dtype == "bf16" else ALGO_TFLOP_PER_STEP
+        ach_exe = exe * a.steps / (dev_ms / 1e3)
+        busy, busy_src = pmc_mfma_busy()
         res = {
             "metric": "UNet3D denoise-steps/sec at 512x512x24 bf16", "value": world * per_gpu, "unit": "steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
@@ -413,9 +456,12 @@ def main():
                        "device_ms_per_step_rank0": dev_ms / a.steps},
             "roofline": {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                         "executed_tflop": exe, "frac_executed": ach_exe / PEAK_BF16_TFLOPS, "mfma_busy": busy,
                          "note": f"whole denoise step on one GPU: {ALGO_TFLOP_PER_STEP} TFLOP algorithmic per step "
-                                 f"(SURVEY 8d; {EXEC_TFLOP_PER_STEP} as executed by the reference) / HIP-event time; "
-                                 f"traffic = bytes per step from {traffic_src}"},
+                                 f"(SURVEY 8d; {EXEC_TFLOP_PER_STEP} as executed by the reference) / HIP-event time; executed_tflop = "
+                                 f"what this build runs per step after the exact skips of the CFG pair that are switched on; "
+                                 f"traffic = bytes per step from {traffic_src}; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
+                                 f"kernel cycles) over the step's kernels from {busy_src}"},
         }
         if world == 1 and not a.no_extras:
             res["roofline_kernels"] = kernel_rooflines(unet, dev)

@@ -486,3 +486,84 @@ def test_two_gib_split_keeps_a_single_bias2_row_for_every_run(monkeypatch):
     t1 = torch.zeros((1, 16))
     hip.conv3x3(x, wp, None, bias2=t1, bias2_rows=max(6 * 64, 256))
     assert [c[1][4] for c in rec.calls] == [2, 2, 2] and all(c[1][11] == t1.data_ptr() and c[1][12] >= 128 for c in rec.calls)
+
+
+def _worker8(rank, world, port, q):
+    import torch.distributed as dist
+    from mmgt_amd import parallel as P
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # weights across bucket boundaries: 7 tensors of odd sizes, buckets of 256 bytes (= 64 floats): tensors of 60 + 3 (one bucket, slots
+        # rounded to 16 bytes), 70 (alone: larger than a bucket), 1, 2, 50 (a bucket), 61 (the next)
+        spec = {"w0": (60,), "w1": (3,), "w2": (7, 10), "w3": (1,), "w4": (2,), "w5": (5, 10), "w6": (61,)}
+        mk = lambda i, s: torch.arange(int(np.prod(s)), dtype=torch.float32).reshape(s) * (i + 1) + 0.5 * i
+        sd = {k: mk(i, s) for i, (k, s) in enumerate(spec.items())} if rank == 3 else None
+        got = P.broadcast_state_dict(sd, spec, src=3, bucket_bytes=256)
+        ok = all(torch.equal(got[k], mk(i, s)) and got[k].data_ptr() % 16 == 0 for i, (k, s) in enumerate(spec.items()))
+        # clips of UNEQUAL shape per rank (different frame counts and sizes), uint8 as the output path produces them
+        shape = (1 + rank % 3, 2 + rank, 3 + (rank % 2), 3)
+        frames = (torch.arange(int(np.prod(shape)), dtype=torch.int64) * (rank + 1) % 251).to(torch.uint8).reshape(shape)
+        gathered = P.gather_frames(frames, dst=0)
+        if rank == 0:
+            for r, g in enumerate(gathered):
+                shp = (1 + r % 3, 2 + r, 3 + (r % 2), 3)
+                want = (torch.arange(int(np.prod(shp)), dtype=torch.int64) * (r + 1) % 251).to(torch.uint8).reshape(shp)
+                ok &= g.shape == shp and torch.equal(g, want)
+        else:
+            ok &= gathered is None
+        q.put((rank, bool(ok), P.shard_units(11, rank, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_clip_parallel_plumbing_world_size_8():
+    """Config 4's plumbing at its real rank count (gloo): weight broadcast across bucket boundaries from a non-zero source, frame gather of
+    clips whose shapes differ per rank, every unit owned exactly once."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+    assert sorted(u for r in res for u in r[2]) == list(range(11))
+
+
+def test_bench_self_launch_builds_the_torchrun_child_before_torch_is_imported():
+    """`bench.py --gpus 8` outside a launcher: a plain child process `python -m torch.distributed.run --nnodes=1 --nproc-per-node=8
+    --master-addr 127.0.0.1 ... bench.py <same flags>`, started before this process has imported torch (nothing has touched the GPU, so the
+    child is not an exec from a GPU-initialised process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import json, os, subprocess, sys
+sys.argv = ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"]
+seen = {}
+def fake_call(cmd, env=None):
+    seen["cmd"], seen["torch_loaded"], seen["ipc"] = cmd, "torch" in sys.modules, (env or {}).get("HSA_ENABLE_IPC_MODE_LEGACY")
+    return 7
+subprocess.call = fake_call
+os.environ.pop("RANK", None)
+import bench
+try:
+    bench.main()
+except SystemExit as e:
+    seen["rc"] = e.code
+print(json.dumps(seen))
+"""
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    seen = __import__("json").loads(out.stdout.strip().splitlines()[-1])
+    cmd = seen["cmd"]
+    assert seen["rc"] == 7 and seen["torch_loaded"] is False and seen["ipc"] == "0"
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1].isdigit()
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]

@@ -188,7 +188,7 @@ def test_long_video_config5_at_full_size_512x512x96(weights):
     pipe = _build(sds, torch.bfloat16)
     kw = dict(motion_scale=[1.0, 1.0, 2.0], context_frames=24, context_overlap=8, latents=inp["latents"],
               clip_image_embeds=inp["clip"], ref_image_latents=inp["ref_lat"], decode=False)
-    run = lambda **k: pipe(None, inp["pose"], inp["audio"], inp["full"], inp["face"], inp["lips"], 512, 512, L, 2, 3.5, **kw, **k).videos
+    run = lambda steps=2, g=3.5, **k: pipe(None, inp["pose"], inp["audio"], inp["full"], inp["face"], inp["lips"], 512, 512, L, steps, g, **kw, **k).videos
     a = run()
     torch.cuda.synchronize()
     t0 = time.time()
@@ -202,8 +202,18 @@ def test_long_video_config5_at_full_size_512x512x96(weights):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
         par = run(window_group=True, cfg_split=True)
+        # The tight gate: ONE step at guidance 1 (+ 2^-20: the reference loop insists on > 1) -- no amplification of the
+        # per-forward rounding, so the 12 (window, CFG row) units must reproduce the batched forwards of the serial loop at the
+        # single-row operator test's tolerance in EVERY frame of every window: a wrong window weight, a frame off by one in one of the six
+        # windows or a swapped CFG row is an O(0.1 .. 1) difference on latents of this size.
+        one_serial = run(1, 1.0 + 2.0 ** -20)
+        one_split = run(1, 1.0 + 2.0 ** -20, window_group=True, cfg_split=True)
     finally:
         dist.destroy_process_group()
+    d1 = (one_split.float() - one_serial.float()).abs()
+    print(f"one step at guidance 1, cfg_split units vs serial: max|d| {d1.max().item():.3e} mean {d1.mean().item():.3e}; worst frame "
+          f"{int(d1.amax(dim=(0, 1, 3, 4)).argmax())}")
+    torch.testing.assert_close(one_split.float(), one_serial.float(), rtol=1.6e-2, atol=2e-3)
     d = (par.float() - a.float()).abs()
     print(f"cfg_split path vs serial at 512x512x96: max|d| {d.max().item():.3e} mean {d.mean().item():.3e} on mean|x| {a.abs().mean().item():.3f}")
     # measured: mean 2.4 % of mean|x|, max 3.5 % of the range after 2 guided steps (guidance 3.5 amplifies the per-forward bf16

@@ -47,3 +47,111 @@ def test_ops_match_torch_math_fp32():
     want = F.conv2d(xi.permute(0, 3, 1, 2), wc, None, stride=2, padding=1).permute(0, 2, 3, 1)
     got = torch.ops.mmgt_hip.conv3x3_nhwc(xi, pack_conv3x3(wc).to(dev), None, None, 2, False)
     torch.testing.assert_close(got, want, rtol=1e-3, atol=1e-4)
+
+
+def test_fake_kernels_of_the_fused_ops_give_shapes():
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        e = lambda *s, dt=torch.bfloat16: torch.empty(*s, device="cuda", dtype=dt)
+        outs = torch.ops.mmgt_hip.attn_bank_fwd(e(4, 256, 640), e(4, 320, 256), e(2, 64, 320), e(2, 320, 64), 8, 40 ** -0.5, 2, 0, True)
+        assert [o.shape for o in outs] == [(4, 256, 320)] * 2
+        assert torch.ops.mmgt_hip.temporal_attn(e(16, 9, 960), 8, 8).shape == (16, 9, 320)
+        assert torch.ops.mmgt_hip.mmhaa_cross(e(2, 64, 960), e(2, 32, 1920), e(3, 128, dt=torch.float32), 8).shape == (2, 64, 960)
+        x = e(256, 320)
+        assert torch.ops.mmgt_hip.ff_fused(x, e(320, dt=torch.float32), e(320, dt=torch.float32), e(10, dt=torch.uint8),
+                                           e(320, dt=torch.float32), 1280, None, None, None).shape == (256, 320)
+        assert torch.ops.mmgt_hip.rowgemm320(x, e(10, dt=torch.uint8), 960, None, None, None, None).shape == (256, 960)
+        assert torch.ops.mmgt_hip.vae_decode(e(2, 4, 8, 8), [e(3)]).shape == (2, 3, 64, 64)
+
+
+@pytest.mark.gpu
+def test_attention_family_ops_match_torch_math():
+    """attn_bank_fwd (read-mode reference attention, + its twin), temporal_attn, mmhaa_cross against SDPA restatements of the reference's
+    call sites (mutual_self_attention.py:149-188, motion_module.py:351-388, attention.py:700-760)."""
+    dev = "cuda:0"
+    r = lambda n, s, sc=1.0: hash_uniform("to." + n, s, sc).to(dev)
+    heads, hd, frames = 8, 40, 2
+    inner = heads * hd
+    sp = lambda t: t.reshape(t.shape[0], t.shape[1], heads, -1).transpose(1, 2)
+    # ---- bank attention, fp32: images 2, 3 (the conditional row) also read the bank of row 1
+    B, n, nb = 4, 64, 32
+    qk, v = r("qk", (B, n, 2 * inner)), r("v", (B, n, inner))
+    kb, vb = r("kb", (2, nb, inner)), r("vb", (2, nb, inner))
+    out = torch.ops.mmgt_hip.attn_bank_fwd(qk, v.transpose(1, 2).contiguous(), kb, vb.transpose(1, 2).contiguous(), heads, hd ** -0.5, frames, 2, False)[0]
+    for b in range(B):
+        k, vv = qk[b:b + 1, :, inner:], v[b:b + 1]
+        if b >= 2:
+            k, vv = torch.cat([k, kb[b // frames][None]], 1), torch.cat([vv, vb[b // frames][None]], 1)
+        want = F.scaled_dot_product_attention(sp(qk[b:b + 1, :, :inner]), sp(k), sp(vv)).transpose(1, 2).reshape(1, n, inner)
+        torch.testing.assert_close(out[b:b + 1], want, rtol=1e-3, atol=1e-4)
+    # ---- twin, bf16 (the production kernel): ONE pass gives [own + bank] and [own]
+    n2 = 256
+    qk16, v16 = r("qk16", (2, n2, 2 * inner)).bfloat16(), r("v16", (2, n2, inner)).bfloat16()
+    kb16, vb16 = r("kb16", (1, 64, inner)).bfloat16(), r("vb16", (1, 64, inner)).bfloat16()
+    both, own = torch.ops.mmgt_hip.attn_bank_fwd(qk16, v16.transpose(1, 2).contiguous(), kb16, vb16.transpose(1, 2).contiguous(), heads, hd ** -0.5,
+                                                 2, 0, True)
+    f64 = lambda t: t.double()
+    k_all, v_all = torch.cat([qk16[..., inner:], kb16.expand(2, -1, -1)], 1), torch.cat([v16, vb16.expand(2, -1, -1)], 1)
+    want_both = F.scaled_dot_product_attention(sp(f64(qk16[..., :inner])), sp(f64(k_all)), sp(f64(v_all))).transpose(1, 2).reshape(2, n2, inner)
+    want_own = F.scaled_dot_product_attention(sp(f64(qk16[..., :inner])), sp(f64(qk16[..., inner:])), sp(f64(v16))).transpose(1, 2).reshape(2, n2, inner)
+    torch.testing.assert_close(both.double(), want_both, rtol=0, atol=2e-2)
+    torch.testing.assert_close(own.double(), want_own, rtol=0, atol=2e-2)
+    # ---- temporal attention over the frame axis of ((b f), hw, 3C)
+    b, f, hw = 2, 8, 9
+    qkv = r("qkv", (b * f, hw, 3 * inner))
+    seq = lambda t: t.reshape(b, f, hw, heads, hd).permute(0, 2, 3, 1, 4).reshape(b * hw, heads, f, hd)
+    want = F.scaled_dot_product_attention(seq(qkv[..., :inner]), seq(qkv[..., inner:2 * inner]), seq(qkv[..., 2 * inner:]))
+    want = want.reshape(b, hw, heads, f, hd).permute(0, 3, 1, 2, 4).reshape(b * f, hw, inner)
+    torch.testing.assert_close(torch.ops.mmgt_hip.temporal_attn(qkv, f, heads), want, rtol=1e-3, atol=1e-4)
+    # ---- the three masked audio cross-attentions
+    B, n, la = 2, 64, 32
+    q3, kv3 = r("q3", (B, n, 3 * inner)), r("kv3", (B, la, 6 * inner))
+    ms = (r("ms", (3, B * n)).abs() * torch.tensor([1.0, 1.0, 2.0], device=dev)[:, None]).contiguous()
+    got = torch.ops.mmgt_hip.mmhaa_cross(q3, kv3, ms, heads)
+    for i in range(3):
+        sl = slice(i * inner, (i + 1) * inner)
+        a = F.scaled_dot_product_attention(sp(q3[..., sl]), sp(kv3[..., sl]), sp(kv3[..., 3 * inner:][..., sl])).transpose(1, 2).reshape(B, n, inner)
+        torch.testing.assert_close(got[..., sl], a * ms[i].view(B, n, 1), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_fused_projection_ops_match_torch_math_bf16():
+    """ff_fused (+ proj_out), rowgemm320: bf16-only kernels against fp64 of the same bf16 operands (one output ulp + accumulation noise)."""
+    from mmgt_amd.packing import pack_ff_fused, pack_ff_proj_out, pack_rowgemm
+    dev = "cuda:0"
+    r = lambda n, s, sc=1.0: hash_uniform("tf." + n, s, sc).to(dev)
+    M, C, inner = 512, 320, 1280
+    x = r("x", (M, C), 1.5).bfloat16()
+    g, be = 1 + 0.2 * r("g", (C,)), 0.1 * r("be", (C,))
+    w1, b1 = (r("w1", (2 * inner, C)) * C ** -0.5).bfloat16(), 0.1 * r("b1", (2 * inner,))
+    w2, b2 = (r("w2", (C, inner)) * inner ** -0.5).bfloat16(), 0.1 * r("b2", (C,))
+    ln = F.layer_norm(x.double(), (C,), g.double(), be.double(), 1e-5).bfloat16().double()
+    hcat = ln @ w1.double().t() + b1.double()
+    hid = (hcat[:, :inner] * F.gelu(hcat[:, inner:])).bfloat16().double()
+    want = x.double() + hid @ w2.double().t() + b2.double()
+    got = torch.ops.mmgt_hip.ff_fused(x, g, be, pack_ff_fused(w1, b1, w2), b2, inner, None, None, None)
+    torch.testing.assert_close(got.double(), want, rtol=2 ** -7, atol=2e-2)
+    wpo, bpo, res2 = (r("wpo", (C, C)) * C ** -0.5).bfloat16(), 0.1 * r("bpo", (C,)), r("res2", (M, C)).bfloat16()
+    want_po = res2.double() + want.bfloat16().double() @ wpo.double().t() + bpo.double()
+    got_po = torch.ops.mmgt_hip.ff_fused(x, g, be, pack_ff_fused(w1, b1, w2), b2, inner, pack_ff_proj_out(wpo), bpo, res2)
+    torch.testing.assert_close(got_po.double(), want_po, rtol=2 ** -7, atol=3e-2)
+    wq, bq = (r("wq", (960, C)) * C ** -0.5).bfloat16(), 0.1 * r("bq", (960,))
+    want_q = ln @ wq.double().t() + bq.double()
+    got_q = torch.ops.mmgt_hip.rowgemm320(x, pack_rowgemm(wq), 960, bq, g, be, None)
+    torch.testing.assert_close(got_q.double(), want_q, rtol=2 ** -7, atol=2e-2)
+
+
+@pytest.mark.gpu
+def test_vae_decode_op_matches_oracle():
+    from mmgt_amd.synthetic import synth_state_dict
+    from mmgt_amd.vae import vae_decoder_spec
+    from oracle import vae_ref
+    sd = synth_state_dict(vae_decoder_spec(), prefix="vae.", device="cpu")
+    lat = hash_uniform("vae.lat", (1, 4, 2, 8, 8), 1.0)
+    with torch.no_grad():
+        ref = vae_ref.decode_latents(sd, lat)                                         # (1, 3, 2, 64, 64) in [0, 1]
+    weights = [sd[k].cuda() for k in vae_decoder_spec()]
+    z = (lat[0] / 0.18215).permute(1, 0, 2, 3).contiguous().cuda()
+    out = torch.ops.mmgt_hip.vae_decode(z, weights)
+    torch.testing.assert_close((out / 2 + 0.5).clamp(0, 1).cpu(), ref[0].permute(1, 0, 2, 3), rtol=1e-3, atol=1e-4)
+    assert torch.equal(torch.ops.mmgt_hip.vae_decode(z, weights), out)                # the cached packing

@@ -3,6 +3,7 @@
   <out>/bench_steps3_kernel_stats_<tag>.csv   rocprofv3's own per-kernel stats (copied)
   <out>/bench_steps3_summary_<tag>.md         per-kernel launches / ms per step
   <out>/pmc_traffic_<tag>.json                HBM-side read / write bytes per step and per kernel
+  <out>/pmc_step_mfma_<tag>.json              matrix-pipe busy fraction of the step and of every kernel (SQ_VALU_MFMA_BUSY_CYCLES)
 usage: python3 tools/profile_summarize.py <dir with prof_<tag>_{trace,fetch,write}> <tag> <out dir>"""
 import collections
 import csv
@@ -44,7 +45,7 @@ if os.path.exists(log):
         if line.startswith('{"metric"'):
             bench_line = line.strip()
 with open(os.path.join(out, f"bench_steps3_summary_{tag}.md"), "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline  (build {tag})\n\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras  (build {tag})\n\n")
     f.write(f"{steps_total} denoise steps (1 warm-up + 3 timed) at 512x512x24 bf16 on one MI355X; per-step = total / {steps_total}. "
             f"Raw stats: bench_steps3_kernel_stats_{tag}.csv; HBM-side traffic from PMC: pmc_traffic_{tag}.json.\n\n")
     f.write("| kernel | launches/step | ms/step | avg us |\n|---|---|---|---|\n")
@@ -91,5 +92,35 @@ json.dump({
     "note": "counts L2 -> fabric requests, i.e. Infinity-Cache hits are included (not pure HBM)",
     "read_GB_per_step": rd, "write_GB_per_step": wr, "per_kernel_GB_per_step": perk, "total_GB_per_step": rd + wr},
     open(os.path.join(out, f"pmc_traffic_{tag}.json"), "w"), indent=1)
+# ---- matrix-pipe busy: SQ_VALU_MFMA_BUSY_CYCLES counts busy cycles summed over the chip's 1024 SIMDs; a kernel's cycles = GRBM_GUI_ACTIVE / 8
+# (rocprofv3 sums the 8 XCDs: MI355X_MICROARCH.md, DVFS give-back)
+mdir = os.path.join(src, f"prof_{tag}_mfma", "p_counter_collection.csv")
+if os.path.exists(mdir):
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    with open(mdir) as f:
+        for r in csv.DictReader(f):
+            k = short(r["Kernel_Name"])
+            if not is_own(k):
+                continue
+            per[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                cnt[k] += 1
+    NSIMD = 1024
+    rowsm = {}
+    for k, c in per.items():
+        cyc = c["GRBM_GUI_ACTIVE"] / 8
+        rowsm[k] = {"mfma_busy": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (NSIMD * cyc) if cyc else 0.0, "kernel_cycles_per_step": cyc / steps_pmc,
+                    "launches_per_step": cnt[k] / steps_pmc}
+    tot_busy = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"] for c in per.values())
+    tot_cyc = sum(c["GRBM_GUI_ACTIVE"] / 8 for c in per.values())
+    rowsm = dict(sorted(rowsm.items(), key=lambda kv: -kv[1]["kernel_cycles_per_step"]))
+    json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 "
+                          "--warmup 1 --no-cpu-baseline --no-extras",
+               "steps_profiled": steps_pmc, "mfma_busy": tot_busy / (NSIMD * tot_cyc),
+               "definition": "sum over the step's own kernels of SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x sum of kernel cycles), kernel cycles = "
+                             "GRBM_GUI_ACTIVE / 8; a profiled pass holds a lower clock than an un-profiled run, cycles are what is compared",
+               "per_kernel": rowsm}, open(os.path.join(out, f"pmc_step_mfma_{tag}.json"), "w"), indent=1)
+    print("matrix pipe busy over the step:", round(tot_busy / (NSIMD * tot_cyc), 4))
 print(open(os.path.join(out, f"bench_steps3_summary_{tag}.md")).read()[-900:])
 print("traffic GB/step: read", round(rd, 1), "write", round(wr, 1))
