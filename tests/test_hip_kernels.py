@@ -154,9 +154,11 @@ def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
 
+@pytest.mark.parametrize("ver", [1, 2])
 @pytest.mark.parametrize("cfg", [16, 17])
-def test_gemm16_persistent_workgroups_exact(cfg):
-    """Several tiles per persistent workgroup (more tiles than CUs): the tile-boundary machinery of gemm16 -- bias vectors
+def test_gemm16_persistent_workgroups_exact(cfg, ver):
+    """(ver: mmgt_tune("g16_ver") -- 1 = gemm16_kernel, the default; 2 = the staggered gemm16s_kernel wherever it applies: K >= 192, no residual, no row scale.)
+    Several tiles per persistent workgroup (more tiles than CUs): the tile-boundary machinery of gemm16 -- bias vectors
     fetched one tile ahead into LDS, the next W chunk issued in front of the epilogue stores with a counted wait that leaves
     those stores in flight, group 1's deferred barrier, residual prefetch -- on exact small-integer problems (sparse -1/0/1
     operands, integer bias / per-batch bias / residual): any stale stage, late bias copy or mixed-up tile shows as a wrong
@@ -174,6 +176,7 @@ def test_gemm16_persistent_workgroups_exact(cfg):
         return torch.randint(-3, 4, shape, generator=g).to(dev()).to(dtype)
     try:
         hip.tune("gemm_cfg", cfg)
+        hip.tune("g16_ver", ver)
         for M, N, K, use_b2 in [(66000, 1280, 320, False), (140100, 320, 64, False), (70000, 640, 128, True), (66000, 960, 320, False)]:
             a, w = sparse(M, K), sparse(N, K)
             bias = ints(N) if N != 960 else None
@@ -210,10 +213,12 @@ def test_gemm16_persistent_workgroups_exact(cfg):
         assert torch.equal(out.float(), ref), (cfg, "conv", int((out.float() != ref).sum()))
     finally:
         hip.tune("gemm_cfg", 0)
+        hip.tune("g16_ver", 1)
 
 
+@pytest.mark.parametrize("ver", [1, 2])
 @pytest.mark.parametrize("cfg", [16, 17])
-def test_gemm16_core_exact_integers_and_geglu(cfg):
+def test_gemm16_core_exact_integers_and_geglu(cfg, ver):
     """The 16x16x32 ping-pong core (cfg 16: 256 x 256 tile, cfg 17: 256 x 320; bf16 only; GEGLU runs on cfg 16 only): (a) exact small-integer operands with an ASYMMETRIC weight matrix --
     any row/column or k-order mix-up in the fragment maps, the permlane16 epilogue or the swizzle shows as a wrong integer;
     (b) GEGLU with packed weights, (c) ragged M / N edges and several tiles per persistent workgroup, (d) bias2 + residual."""
@@ -222,6 +227,7 @@ def test_gemm16_core_exact_integers_and_geglu(cfg):
     dt = torch.bfloat16
     try:
         hip.tune("gemm_cfg", cfg)
+        hip.tune("g16_ver", ver)
         for M, N, K in [(256, 256, 64), (300, 264, 128), (2000, 1288, 320), (1000, 320, 192), (520, 640, 64)]:
             a = torch.randint(-1, 2, (M, K), device=dev()).to(dt)
             w = torch.randint(-1, 2, (N, K), device=dev()).to(dt)
@@ -249,6 +255,7 @@ def test_gemm16_core_exact_integers_and_geglu(cfg):
         torch.testing.assert_close(out.double(), ref, **tol(dt))
     finally:
         hip.tune("gemm_cfg", 0)
+        hip.tune("g16_ver", 1)
 
 
 @pytest.mark.parametrize("dt", DT)

@@ -202,18 +202,24 @@ def test_long_video_config5_at_full_size_512x512x96(weights):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
         par = run(window_group=True, cfg_split=True)
-        # The tight gate: ONE step at guidance 1 (+ 2^-20: the reference loop insists on > 1) -- no amplification of the
-        # per-forward rounding, so the 12 (window, CFG row) units must reproduce the batched forwards of the serial loop at the
-        # single-row operator test's tolerance in EVERY frame of every window: a wrong window weight, a frame off by one in one of the six
-        # windows or a swapped CFG row is an O(0.1 .. 1) difference on latents of this size.
+        # The tight gate: ONE step at guidance 1 (+ 2^-20: the reference loop insists on > 1) from t = 999, where the DDIM update
+        # returns x0 = -v: the latents ARE the (negated) predictions, no amplification.  The 12 (window, CFG row) units run single-row
+        # forwards (other GEMM tiles, no shared-row / twin paths), so against the batched forwards of the serial loop they are a second
+        # bf16 evaluation of the same function: the two must agree within the measured bf16 noise floor of this operator at this shape
+        # (tests/golden/unet3d_full_cfg2_bf16floor.npz: max 2.2e-2, mean 3.5e-3 against fp32) in EVERY frame of every window -- a wrong
+        # window weight, a frame off by one in one of the six windows or a swapped CFG row is an O(0.1 .. 1) difference.
         one_serial = run(1, 1.0 + 2.0 ** -20)
         one_split = run(1, 1.0 + 2.0 ** -20, window_group=True, cfg_split=True)
     finally:
         dist.destroy_process_group()
+    import numpy as np
+    fl = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "unet3d_full_cfg2_bf16floor.npz"))
+    fmax, fmean = float(fl["max_abs"]), float(fl["mean_abs"])
     d1 = (one_split.float() - one_serial.float()).abs()
-    print(f"one step at guidance 1, cfg_split units vs serial: max|d| {d1.max().item():.3e} mean {d1.mean().item():.3e}; worst frame "
-          f"{int(d1.amax(dim=(0, 1, 3, 4)).argmax())}")
-    torch.testing.assert_close(one_split.float(), one_serial.float(), rtol=1.6e-2, atol=2e-3)
+    per_frame = d1.mean(dim=(0, 1, 3, 4))
+    print(f"one step at guidance 1, cfg_split units vs serial: max|d| {d1.max().item():.3e} mean {d1.mean().item():.3e} (bf16 floor {fmax:.3e} / "
+          f"{fmean:.3e}); per-frame mean {per_frame.min().item():.3e} .. {per_frame.max().item():.3e}")
+    assert d1.max() <= 1.5 * fmax and d1.mean() <= 1.5 * fmean and per_frame.max() <= 2.0 * fmean
     d = (par.float() - a.float()).abs()
     print(f"cfg_split path vs serial at 512x512x96: max|d| {d.max().item():.3e} mean {d.mean().item():.3e} on mean|x| {a.abs().mean().item():.3f}")
     # measured: mean 2.4 % of mean|x|, max 3.5 % of the range after 2 guided steps (guidance 3.5 amplifies the per-forward bf16

@@ -87,6 +87,8 @@ SETS = {
     "vae": lambda: [conv_case(8, 512, 128, 128), conv_case(8, 512, 256, 128), conv_case(8, 512, 128, 64), conv_case(8, 256, 256, 256),
                     conv_case(8, 256, 512, 256), conv_case(8, 128, 512, 512), conv_case(8, 64, 512, 512), conv_case(8, 256, 256, 256, up=True),
                     gemm_case(2097152, 128, 256), gemm_case(524288, 256, 512)],
+    "g16s": lambda: [gemm_case(49152, 5120, 640, act=1), gemm_case(196608, 960, 320, bias=False), gemm_case(12288, 3840, 1280, bias=False),
+                     conv_case(48, 64, 320, 320)],
     "big": lambda: [gemm_case(8192, 8192, 8192, bias=False), gemm_case(4096, 4096, 4096, bias=False)],
     "step": lambda: [
         gemm_case(196608, 2560, 320, act=1), gemm_case(49152, 5120, 640, act=1), gemm_case(12288, 10240, 1280, act=1),
@@ -124,4 +126,4 @@ if __name__ == "__main__":
             mn, md = min(times[c]), statistics.median(times[c])
             cells.append(f"c{c}: {mn:7.1f}/{md:7.1f}us {flops / mn / 1e6:5.0f}TF d={d:.1e}")
         print(f"{name:44s} | " + " | ".join(cells), flush=True)
-    hip.tune(key, 0 if key == "gemm_cfg" else -1)
+    hip.tune(key, {"gemm_cfg": 0, "g16_ver": 1}.get(key, -1))
