@@ -89,6 +89,10 @@ SETS = {
                     gemm_case(2097152, 128, 256), gemm_case(524288, 256, 512)],
     "g16s": lambda: [gemm_case(49152, 5120, 640, act=1), gemm_case(196608, 960, 320, bias=False), gemm_case(12288, 3840, 1280, bias=False),
                      conv_case(48, 64, 320, 320)],
+    # shapes whose 256 x 320 tiling leaves a quarter of the CUs idle (192 tiles) or runs 1.5 rounds (384 tiles)
+    "quant": lambda: [gemm_case(12288, 1280, 1280, res=True), gemm_case(12288, 1280, 5120, res=True), gemm_case(12288, 1280, 1280),
+                      gemm_case(49152, 640, 640, res=True), gemm_case(49152, 640, 2560, res=True), gemm_case(49152, 640, 640),
+                      gemm_case(12288, 2560, 1280), gemm_case(49152, 1280, 640)],
     "big": lambda: [gemm_case(8192, 8192, 8192, bias=False), gemm_case(4096, 4096, 4096, bias=False)],
     "step": lambda: [
         gemm_case(196608, 2560, 320, act=1), gemm_case(49152, 5120, 640, act=1), gemm_case(12288, 10240, 1280, act=1),
