@@ -163,7 +163,12 @@ def pmc_mfma_busy():
     """Matrix-pipe busy fraction of the whole step from the committed PMC pass of this same command (profiles/r*/pmc_step_mfma*.json:
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE, tools/profile_bench.sh)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_step_mfma*.json")), key=os.path.getmtime)
+    cur = os.path.join(ROOT, "profiles", "CURRENT_TRAFFIC")      # the matrix-pipe pass of the same profile run sits beside the traffic passes
+    if os.path.exists(cur):
+        sib = os.path.join(ROOT, open(cur).read().split()[0].replace("pmc_traffic_", "pmc_step_mfma_"))
+        if os.path.exists(sib):
+            return json.load(open(sib))["mfma_busy"], os.path.relpath(sib, ROOT)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_step_mfma*.json")))   # (by name: file times do not survive a checkout)
     if not files:
         return None, None
     return json.load(open(files[-1]))["mfma_busy"], os.path.relpath(files[-1], ROOT)
