@@ -942,7 +942,7 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "attn64")) { mmgt_attn_set64(value); return 0; }
   if (key && !strcmp(key, "attn_heads_inner")) { mmgt_attn_set_heads_inner(value); return 0; }
   if (key && !strcmp(key, "g16_pb")) { mmgt_gemm16_set_pb(value); return 0; }
-  if (key && !strcmp(key, "g16_ver") && value >= 1 && value <= 2) { mmgt_gemm16_set_ver(value); return 0; }
+  if (key && !strcmp(key, "g16_ver") && value >= 1 && value <= 3) { mmgt_gemm16_set_ver(value); return 0; }
   if (key && !strcmp(key, "gn_rows")) { mmgt_gn_set_rows(value); return 0; }
   if (key && !strcmp(key, "gn_interleave")) { mmgt_gn_set_interleave(value); return 0; }
   if (key && !strcmp(key, "gn_narrow")) { mmgt_gn_set_narrow(value); return 0; }

@@ -523,8 +523,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
 }
 
 unsigned long long* g_trace = nullptr;
-int g_ver = 1;  // mmgt_tune("g16_ver", 1 / 2): 1 = gemm16_kernel (wave groups one barrier apart), 2 = gemm16s_kernel (one chunk apart: gemm16s.hip,
-                // slower as measured in round 4: kept for A/B) wherever it applies (K >= 192, no residual / row scale / post-scale bias)
+int g_ver = 1;  // mmgt_tune("g16_ver", 1 / 2 / 3): 1 = gemm16_kernel (wave groups one barrier apart), 2 = gemm16s_kernel (one chunk apart: gemm16s.hip,
+                // slower as measured in round 4: kept for A/B) wherever it applies (K >= 192, no residual / row scale / post-scale bias),
+                // 3 = gemm16v_kernel (gemm16v.hip: one wave per SIMD, 128 x 128 wave tiles) for the 256-column tile
 int g_pb = -1;   // mmgt_tune("g16_pb", v): row panels per column-major group of the tile order (-1 = by shape, 1 = row-major)
 
 template <int MODE, int BN>
@@ -567,6 +568,7 @@ void mmgt_gemm16_set_pb(int v) { g_pb = v; }
 void mmgt_gemm16_set_ver(int v) { g_ver = v; }
 int mmgt_gemm16s_launch(int mode, int bn, const void* ad, const void* W, long bsw, const void* ep, int M, int N, int K, int batch, void* stream,
                         int pb_tune);
+int mmgt_gemm16v_launch(int mode, const void* ad, const void* W, long bsw, const void* ep, int M, int N, int K, int batch, void* stream, int pb_tune);
 
 namespace {
 
@@ -659,7 +661,8 @@ int mmgt_gemm16_splitk(int mode, int bn, const void* adp, const void* W, const v
   pe.fast = 1;
   const int ks = K / S;
   int rc;
-  if (g_ver >= 2 && !g_trace && ks >= 192) rc = mmgt_gemm16s_launch(mode, bn, &ad, W, 0, &pe, M, N, ks, S, s, g_pb);
+  if (g_ver == 3 && !g_trace && bn == 256) rc = mmgt_gemm16v_launch(mode, &ad, W, 0, &pe, M, N, ks, S, s, g_pb);
+  else if (g_ver == 2 && !g_trace && ks >= 192) rc = mmgt_gemm16s_launch(mode, bn, &ad, W, 0, &pe, M, N, ks, S, s, g_pb);
   else if (bn == 320) rc = mode == 0 ? launch16<0, 320>(ad, W, 0, pe, M, N, ks, S, s) : launch16<1, 320>(ad, W, 0, pe, M, N, ks, S, s);
   else rc = mode == 0 ? launch16<0, 256>(ad, W, 0, pe, M, N, ks, S, s) : launch16<1, 256>(ad, W, 0, pe, M, N, ks, S, s);
   if (rc) return rc;
@@ -701,8 +704,9 @@ int mmgt_gemm16_launch(int mode, int bn, const void* adp, const void* W, long bs
   const Epi& ep = *reinterpret_cast<const Epi*>(epp);
   hipStream_t s = (hipStream_t)stream;
   const bool post = ep.row_scale != nullptr || ep.alpha != 1.f || ep.bias_post != nullptr;
+  if (g_ver == 3 && !g_trace && bn == 256) return mmgt_gemm16v_launch(mode, adp, W, bsw, epp, M, N, K, batch, stream, g_pb);   // gemm16v.hip: one wave per SIMD
   // gemm16s: K >= 192 (its streams run at most one tile ahead)
-  if (g_ver >= 2 && !g_trace && !post && K >= 192 && !ep.residual) return mmgt_gemm16s_launch(mode, bn, adp, W, bsw, epp, M, N, K, batch, stream, g_pb);
+  if (g_ver == 2 && !g_trace && !post && K >= 192 && !ep.residual) return mmgt_gemm16s_launch(mode, bn, adp, W, bsw, epp, M, N, K, batch, stream, g_pb);
   if (bn == 320) return mode == 0 ? launch16<0, 320>(ad, W, bsw, ep, M, N, K, batch, s) : launch16<1, 320>(ad, W, bsw, ep, M, N, K, batch, s);
   return mode == 0 ? launch16<0, 256>(ad, W, bsw, ep, M, N, K, batch, s) : launch16<1, 256>(ad, W, bsw, ep, M, N, K, batch, s);
 }

@@ -154,10 +154,10 @@ def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize("ver", [1, 2])
+@pytest.mark.parametrize("ver", [1, 2, 3])
 @pytest.mark.parametrize("cfg", [16, 17])
 def test_gemm16_persistent_workgroups_exact(cfg, ver):
-    """(ver: mmgt_tune("g16_ver") -- 1 = gemm16_kernel, the default; 2 = the staggered gemm16s_kernel wherever it applies: K >= 192, no residual, no row scale.)
+    """(ver: mmgt_tune("g16_ver") -- 1 = gemm16_kernel, the default; 2 = the staggered gemm16s_kernel wherever it applies: K >= 192, no residual, no row scale; 3 = gemm16v_kernel, one wave per SIMD, for the 256-column tile: cfg 16.)
     Several tiles per persistent workgroup (more tiles than CUs): the tile-boundary machinery of gemm16 -- bias vectors
     fetched one tile ahead into LDS, the next W chunk issued in front of the epilogue stores with a counted wait that leaves
     those stores in flight, group 1's deferred barrier, residual prefetch -- on exact small-integer problems (sparse -1/0/1
@@ -216,7 +216,7 @@ def test_gemm16_persistent_workgroups_exact(cfg, ver):
         hip.tune("g16_ver", 1)
 
 
-@pytest.mark.parametrize("ver", [1, 2])
+@pytest.mark.parametrize("ver", [1, 2, 3])
 @pytest.mark.parametrize("cfg", [16, 17])
 def test_gemm16_core_exact_integers_and_geglu(cfg, ver):
     """The 16x16x32 ping-pong core (cfg 16: 256 x 256 tile, cfg 17: 256 x 320; bf16 only; GEGLU runs on cfg 16 only): (a) exact small-integer operands with an ASYMMETRIC weight matrix --

@@ -93,6 +93,12 @@ SETS = {
     "quant": lambda: [gemm_case(12288, 1280, 1280, res=True), gemm_case(12288, 1280, 5120, res=True), gemm_case(12288, 1280, 1280),
                       gemm_case(49152, 640, 640, res=True), gemm_case(49152, 640, 2560, res=True), gemm_case(49152, 640, 640),
                       gemm_case(12288, 2560, 1280), gemm_case(49152, 1280, 640)],
+    # the 256-column family (gemm16v candidates): GEGLU, q|k|v, long-K + residual at N = 1280, convs to 1280 / 640, 8192^3
+    "v256": lambda: [gemm_case(49152, 5120, 640, act=1), gemm_case(12288, 10240, 1280, act=1), gemm_case(196608, 2560, 320, act=1),
+                     gemm_case(12288, 3840, 1280, bias=False), gemm_case(49152, 1920, 640, bias=False), gemm_case(12288, 1280, 5120, res=True),
+                     gemm_case(12288, 1280, 1280, res=True), gemm_case(49152, 1280, 640), gemm_case(8192, 8192, 8192, bias=False),
+                     conv_case(48, 16, 1280, 1280), conv_case(48, 16, 2560, 1280), conv_case(48, 32, 640, 640), conv_case(48, 16, 1280, 1280, up=True)],
+    "v3": lambda: [gemm_case(49152, 5120, 640, act=1), gemm_case(12288, 3840, 1280, bias=False), gemm_case(8192, 8192, 8192, bias=False), conv_case(48, 16, 1280, 1280)],
     "big": lambda: [gemm_case(8192, 8192, 8192, bias=False), gemm_case(4096, 4096, 4096, bias=False)],
     "step": lambda: [
         gemm_case(196608, 2560, 320, act=1), gemm_case(49152, 5120, 640, act=1), gemm_case(12288, 10240, 1280, act=1),

@@ -5,6 +5,9 @@
 //
 //   hipcc --offload-arch=gfx950 -O3 tools/micro/lonewave.hip -o /tmp/lonewave && /tmp/lonewave > profiles/r4/lonewave_r4.txt
 #include <hip/hip_runtime.h>
+#ifndef LW_ASM
+#define LW_ASM 1
+#endif
 
 #include <algorithm>
 #include <cstdio>
@@ -39,7 +42,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k(unsigned long long* out, cons
       for (int i = 0; i < 8; ++i) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+#if LW_ASM
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[8 * i + j]) : "v"(fa[i]), "v"(fb[j]));   // tied AGPR operand: the tile stays in place
+#else
           acc[8 * i + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[8 * i + j], 0, 0, 0);
+#endif
           if ((MODE & 1) && (j & 3) == 3) {
             const int q = 2 * i + (j >> 2);
             const s16x8 v = *reinterpret_cast<const s16x8*>(rd + ((it * 2 + s) & 1) * 8192 + q * 512);
