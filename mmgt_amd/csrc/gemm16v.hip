@@ -33,7 +33,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) float acc4;
 #ifndef G16V_ABL
-#define G16V_ABL 0   // timing ablations (make ablv; results wrong): 1 no LDS-DMA in the loop, 2 no vmcnt wait, 4 no barrier, 8 no per-row lgkmcnt waits, 16 every DMA piece with the poison offset (issued, reads zeros, moves no memory)
+#define G16V_ABL 0   // timing ablations (make ablv; results wrong): 1 no LDS-DMA in the loop, 2 no vmcnt wait, 4 no barrier, 8 no per-row lgkmcnt waits, 16 every DMA piece with the poison offset (issued, reads zeros, moves no memory), 32 / 64 the A / the W pieces only
 #endif
 
 // D += Wfrag x Afrag with the accumulator tile tied to ONE accumulation-register quad for the whole kernel (see the header)
@@ -175,10 +175,10 @@ __global__ __launch_bounds__(256, 1) void gemm16v_kernel(ADesc ad, const char* _
     constexpr int P = decltype(Pc)::value, I = P < GA ? P : P - GA, k = I & 3;
     char* base = smem + stage * STAGE_BYTES + (P < GA ? 0 : A_BYTES) + (wid * GA + (I & ~3)) * 1024;
     if constexpr (P < GA) {
-      if (MODE == 1 && a_second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, (__attribute__((address_space(3))) void*)base, 16, (int)((G16V_ABL & 16) ? DMA_POISON : aoff[I]), soffA + (RSRC_BACK - 1024 * k), 1024 * k, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, (__attribute__((address_space(3))) void*)base, 16, (int)((G16V_ABL & 16) ? DMA_POISON : aoff[I]), soffA + (RSRC_BACK - 1024 * k), 1024 * k, 0);
+      if (MODE == 1 && a_second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, (__attribute__((address_space(3))) void*)base, 16, (int)((G16V_ABL & (16 | 32)) ? DMA_POISON : aoff[I]), soffA + (RSRC_BACK - 1024 * k), 1024 * k, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, (__attribute__((address_space(3))) void*)base, 16, (int)((G16V_ABL & (16 | 32)) ? DMA_POISON : aoff[I]), soffA + (RSRC_BACK - 1024 * k), 1024 * k, 0);
     } else {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)base, 16, (int)((G16V_ABL & 16) ? DMA_POISON : woff[I]), soffW + (RSRC_BACK - 1024 * k), 1024 * k, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void*)base, 16, (int)((G16V_ABL & (16 | 64)) ? DMA_POISON : woff[I]), soffW + (RSRC_BACK - 1024 * k), 1024 * k, 0);
     }
   };
   // Bias.  The accumulators of a tile START from bias[n] + bias2[batch row of m][n] instead of zero, read from an LDS copy of the
