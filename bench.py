@@ -64,7 +64,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-cpu-baseline", action="store_true",
-                    help="time one FULL 24-frame CFG forward of the oracle on the host (minutes) instead of the 2-frame sample")
+                    help="time one FULL 24-frame CFG forward of the oracle on the host (minutes); the default on hosts with >= 64 cores")
+    ap.add_argument("--sample-cpu-baseline", action="store_true",
+                    help="time the 2-of-24-frame sample of the oracle only (the default on hosts with < 64 cores)")
     ap.add_argument("--no-extras", action="store_true", help="skip the VAE / prologue / per-kernel legs")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--master-port", type=int, default=0)
@@ -197,6 +199,26 @@ def _time_ms(fn, reps=20, warm=3):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
+
+
+def box_calib(dev, dtype):
+    """What THIS box does on two fixed loads, so that lines from different boxes (+-4 % on identical binaries) can be read against each other:
+    the in-kernel clock / rate of a bare 16x16x32 bf16 MFMA loop after 2 s of back-to-back launches (csrc/calib.hip) and the time of one
+    fixed gemm16 launch, 8192^3 bf16 on random operands."""
+    import torch
+    from mmgt_amd import hip
+    from mmgt_amd.synthetic import hash_uniform
+    mhz, tf = hip.box_calib(2.0)
+    rec = {"mfma_loop_mhz": mhz, "mfma_loop_tflops": tf, "what": "bare v_mfma_f32_16x16x32_bf16 loop, random operands, one wave per SIMD, "
+           "in-kernel clock (s_memtime / s_memrealtime) after 2 s of back-to-back launches"}
+    if dtype == torch.bfloat16:
+        a = hash_uniform("calib.a", (8192, 8192), 1.0, dev).to(dtype)
+        w = hash_uniform("calib.w", (8192, 8192), 1.0, dev).to(dtype)
+        o = torch.empty((8192, 8192), device=dev, dtype=dtype)
+        ms = _time_ms(lambda: hip.gemm(a, w, out=o), reps=20, warm=5)
+        rec["gemm16_8192_us"] = ms * 1e3
+        rec["gemm16_8192_tflops"] = 2.0 * 8192 ** 3 / ms / 1e9
+    return rec
 
 
 def kernel_rooflines(unet, dev):
@@ -468,11 +490,14 @@ def main():
                                  f"traffic = bytes per step from {traffic_src}; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
                                  f"kernel cycles) over the step's kernels from {busy_src}"},
         }
+        res["box_calib"] = box_calib(dev, dtype)
         if world == 1 and not a.no_extras:
             res["roofline_kernels"] = kernel_rooflines(unet, dev)
             res.update(extras(pipe, unet, dev, dtype))
         if sd_cpu is not None:
-            rec, cinp, cout = cpu_baseline(sd_cpu, FRAMES if a.full_cpu_baseline else 2)
+            # a measured full step (about 160 s on the GPU box's 128 host cores) is what the default line carries; small hosts keep the sample
+            full_cpu = a.full_cpu_baseline or (not a.sample_cpu_baseline and (os.cpu_count() or 1) >= 64)
+            rec, cinp, cout = cpu_baseline(sd_cpu, FRAMES if full_cpu else 2)
             res["cpu_baseline"] = rec
             del sd_cpu
             # the same sample through the bf16 HIP operator: the metric's "max|delta| vs CPU ref" 

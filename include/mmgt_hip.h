@@ -43,15 +43,21 @@ const char* mmgt_last_error(void);
  *   "attn64"   = 1 (default) / 0: the 64-queries-per-wave spatial attention kernel at head_dim 40;
  *   "gn_rows"  = 0 (default: measured choice) or the GroupNorm rows per workgroup;
  *   "splitk"   = 1 (default) / 0: split-K of long reductions on grids of at most half a tile per CU (the 8x8-level convs);
- *   "ffn_dbg"  = 0 (default) .. 4: ablation builds of mmgt_ff_fused (timing only, results are garbage for v > 0).
+ *   "ffn_dbg"  = 0 (default) .. 2: ablation builds of mmgt_ff_fused (timing only, results are garbage for v > 0).
  *   "tailsplit" = 1 (default) / 0: convs whose tile count leaves the last round of the persistent grid half empty run that round's rows
  *               as a second launch with the reduction split in two (A/B switch).
- *   "ffn_ver"  = 4 (default): single-role kernel of mmgt_ff_fused, 3: the producer / consumer kernel (A/B measurements). */
+ * One kernel per family ships: the measured-slower variants of earlier rounds (gemm16s / gemm16v, the phased and register-staged
+ * head_dim-40 attention kernels, the producer / consumer FeedForward) are records under tools/micro/. */
 int mmgt_tune(const char* key, int value);
 /* Host-side switches kept in the same table (what mmgt_amd/unet3d.py, pipeline.py and smga.py consult; all default 1, 0 = the
  * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "zero_audio_skip",
- * "window_state", "smga_graph", "gn_fused_stats".  mmgt_tune sets them, mmgt_tune_get reads them: one state describes a run. */
+ * "window_state", "smga_graph".  mmgt_tune sets them, mmgt_tune_get reads them: one state describes a run. */
 int mmgt_tune_get(const char* key, int* value);
+/* Box calibration for bench.py's `box_calib` (csrc/calib.hip): a bare v_mfma_f32_16x16x32_bf16 loop on random operands, one wave per SIMD,
+ * launched back to back for `warm_seconds` (0 .. 10); *mfma_mhz = the in-kernel clock of the last launch (delta s_memtime / delta
+ * s_memrealtime, median over the workgroups), *mfma_tflops = the rate of the last batch of launches.  Measures the BOX (boxes differ by
+ * several per cent in the clock they hold under load), not the product.  Host pointers; synchronises the stream. */
+int mmgt_box_calib(float warm_seconds, float* mfma_mhz, float* mfma_tflops, void* stream);
 /* Debug only (tools/trace_gemm16.py): p = device buffer of u64 [grid][32 tiles][2 wave groups][4] that gemm16's workgroups fill
  * with 100-MHz stamps at their tile phases; NULL (the default) switches the stamps off. */
 void mmgt_gemm16_set_trace(void* p);

@@ -900,17 +900,11 @@ void mmgt_attn_set64(int v);
 void mmgt_gn_set_rows(int v);
 void mmgt_attn_set_heads_inner(int v);
 void mmgt_gemm16_set_pb(int v);
-void mmgt_gemm16_set_ver(int v);
 void mmgt_gn_set_interleave(int v);
 void mmgt_gn_set_lpr0(int v);
 void mmgt_gn_set_narrow(int v);
 void mmgt_ffn_set_dbg(int v);
-void mmgt_ffn_set_ver(int v);
 void mmgt_rowgemm_set_dbg(int v);
-void mmgt_attn64_set_pad(int v);
-void mmgt_attn64_set_ver(int v);
-void mmgt_attn64_set_abl(int v);
-void mmgt_attn64_set_nw(int v);
 // Switches of the HOST side of the operator (mmgt_amd/unet3d.py, pipeline.py, smga.py read them through mmgt_tune_get): they live here,
 // beside the kernel knobs, so that ONE state -- this table -- describes what a run executed (MMGT_TUNE="twin_attention=0,splitk=0").
 namespace {
@@ -924,7 +918,6 @@ HostSwitch g_host[] = {
     {"zero_audio_skip", 1},  // skip the audio cross-attention of an all-zero (unconditional) audio row
     {"window_state", 1},     // keep what a window's audio / masks determine across the steps of a clip
     {"smga_graph", 1},       // replay the SMGA sampler loop as a HIP graph
-    {"gn_fused_stats", 1},   // GroupNorm statistics from the producing conv's epilogue
 };
 }  // namespace
 extern "C" int mmgt_tune_get(const char* key, int* value) {
@@ -942,20 +935,14 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "attn64")) { mmgt_attn_set64(value); return 0; }
   if (key && !strcmp(key, "attn_heads_inner")) { mmgt_attn_set_heads_inner(value); return 0; }
   if (key && !strcmp(key, "g16_pb")) { mmgt_gemm16_set_pb(value); return 0; }
-  if (key && !strcmp(key, "g16_ver") && value >= 1 && value <= 3) { mmgt_gemm16_set_ver(value); return 0; }
   if (key && !strcmp(key, "gn_rows")) { mmgt_gn_set_rows(value); return 0; }
   if (key && !strcmp(key, "gn_interleave")) { mmgt_gn_set_interleave(value); return 0; }
   if (key && !strcmp(key, "gn_narrow")) { mmgt_gn_set_narrow(value); return 0; }
   if (key && !strcmp(key, "gn_lpr0")) { if (value != 4 && value != 8 && value != 16) return -1; mmgt_gn_set_lpr0(value); return 0; }
   if (key && !strcmp(key, "splitk")) { g_splitk = value; return 0; }
   if (key && !strcmp(key, "tailsplit")) { g_tailsplit = value; return 0; }
-  if (key && !strcmp(key, "attn64_pad")) { mmgt_attn64_set_pad(value); return 0; }
-  if (key && !strcmp(key, "attn64_ver") && value >= 1 && value <= 3) { mmgt_attn64_set_ver(value); return 0; }
-  if (key && !strcmp(key, "attn64_abl")) { mmgt_attn64_set_abl(value); return 0; }
-  if (key && !strcmp(key, "attn64_nw") && (value == 4 || value == 8)) { mmgt_attn64_set_nw(value); return 0; }
-  if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 4) { mmgt_ffn_set_dbg(value); return 0; }
+  if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 2) { mmgt_ffn_set_dbg(value); return 0; }
   if (key && !strcmp(key, "rowgemm_dbg") && value >= 0 && value <= 5) { mmgt_rowgemm_set_dbg(value); return 0; }
-  if (key && !strcmp(key, "ffn_ver") && (value == 3 || value == 4)) { mmgt_ffn_set_ver(value); return 0; }
   mmgt_set_error("tune: unknown key");
   return 1;
 }

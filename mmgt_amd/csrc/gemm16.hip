@@ -523,9 +523,6 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
 }
 
 unsigned long long* g_trace = nullptr;
-int g_ver = 1;  // mmgt_tune("g16_ver", 1 / 2 / 3): 1 = gemm16_kernel (wave groups one barrier apart), 2 = gemm16s_kernel (one chunk apart: gemm16s.hip,
-                // slower as measured in round 4: kept for A/B) wherever it applies (K >= 192, no residual / row scale / post-scale bias),
-                // 3 = gemm16v_kernel (gemm16v.hip: one wave per SIMD, 128 x 128 wave tiles) for the 256-column tile
 int g_pb = -1;   // mmgt_tune("g16_pb", v): row panels per column-major group of the tile order (-1 = by shape, 1 = row-major)
 
 template <int MODE, int BN>
@@ -565,10 +562,6 @@ int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int
 // Debug (tools/trace_gemm16.py): a device buffer of [grid][32 tiles][2 groups][4 stamps] u64 receives 100-MHz time stamps.
 extern "C" void mmgt_gemm16_set_trace(void* p) { g_trace = reinterpret_cast<unsigned long long*>(p); }
 void mmgt_gemm16_set_pb(int v) { g_pb = v; }
-void mmgt_gemm16_set_ver(int v) { g_ver = v; }
-int mmgt_gemm16s_launch(int mode, int bn, const void* ad, const void* W, long bsw, const void* ep, int M, int N, int K, int batch, void* stream,
-                        int pb_tune);
-int mmgt_gemm16v_launch(int mode, const void* ad, const void* W, long bsw, const void* ep, int M, int N, int K, int batch, void* stream, int pb_tune);
 
 namespace {
 
@@ -606,9 +599,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // Partial-sum workspace of the split-K / tail-split launches: one buffer per device, owned by the library.  It grows only OUTSIDE a
 // stream capture (hipMalloc / hipFree inside one would invalidate the capture), and a buffer that a capture has recorded is never
-// freed: a graph replays with the pointer it captured, so a later growth retires that buffer instead of releasing it.
-constexpr int MAX_DEV = 16;
-struct SplitkWs { float* p = nullptr; size_t bytes = 0; bool captured = false; };
+// freed: a graph replays with the pointer it captured, so a later growth retires that buffer instead of releasing it.  Growth is
+// geometric and the retired list is bounded (every growth after a capture used to leak a slab without limit).
+constexpr int MAX_DEV = 16, MAX_RETIRED = 8;
+struct SplitkWs {
+  float* p = nullptr; size_t bytes = 0; bool captured = false;
+  float* retired[MAX_RETIRED] = {};          // buffers a graph captured before the workspace grew: kept alive for its replays, and
+  size_t retired_bytes[MAX_RETIRED] = {};    // taken back into service when a later request fits one of them
+  int nretired = 0;
+};
 SplitkWs g_splitk_ws[MAX_DEV];
 
 float* splitk_workspace(size_t need, hipStream_t s) {
@@ -626,14 +625,29 @@ float* splitk_workspace(size_t need, hipStream_t s) {
                      "shape once outside the capture (warm-up) first", need);
       return nullptr;
     }
-    if (w.p && !w.captured) (void)hipFree(w.p);       // (synchronises the device: nothing is reading the old buffer afterwards)
-    w = SplitkWs{};
-    if (hipMalloc(reinterpret_cast<void**>(&w.p), need) != hipSuccess) {
-      w = SplitkWs{};
-      mmgt_set_error("gemm16 split-K: cannot allocate %zu bytes of partial sums", need);
-      return nullptr;
+    // Grow geometrically (at most log2 growths over a process) so that a sequence of slowly growing shapes cannot retire a slab each.
+    size_t want = need;
+    if (w.bytes && want < 2 * w.bytes) want = 2 * w.bytes;
+    if (w.p && !w.captured) {
+      (void)hipFree(w.p);                             // (synchronises the device: nothing is reading the old buffer afterwards)
+    } else if (w.p) {
+      if (w.nretired == MAX_RETIRED) {
+        mmgt_set_error("gemm16 split-K: %d captured workspaces already retired; destroy the graphs that hold them and restart", MAX_RETIRED);
+        return nullptr;
+      }
+      w.retired[w.nretired] = w.p;
+      w.retired_bytes[w.nretired++] = w.bytes;
     }
-    w.bytes = need;
+    w.p = nullptr; w.bytes = 0; w.captured = false;
+    if (hipMalloc(reinterpret_cast<void**>(&w.p), want) != hipSuccess) {
+      if (want == need || hipMalloc(reinterpret_cast<void**>(&w.p), need) != hipSuccess) {
+        w.p = nullptr;
+        mmgt_set_error("gemm16 split-K: cannot allocate %zu bytes of partial sums", need);
+        return nullptr;
+      }
+      want = need;
+    }
+    w.bytes = want;
   }
   if (capturing) w.captured = true;
   return w.p;
@@ -661,9 +675,7 @@ int mmgt_gemm16_splitk(int mode, int bn, const void* adp, const void* W, const v
   pe.fast = 1;
   const int ks = K / S;
   int rc;
-  if (g_ver == 3 && !g_trace && bn == 256) rc = mmgt_gemm16v_launch(mode, &ad, W, 0, &pe, M, N, ks, S, s, g_pb);
-  else if (g_ver == 2 && !g_trace && ks >= 192) rc = mmgt_gemm16s_launch(mode, bn, &ad, W, 0, &pe, M, N, ks, S, s, g_pb);
-  else if (bn == 320) rc = mode == 0 ? launch16<0, 320>(ad, W, 0, pe, M, N, ks, S, s) : launch16<1, 320>(ad, W, 0, pe, M, N, ks, S, s);
+  if (bn == 320) rc = mode == 0 ? launch16<0, 320>(ad, W, 0, pe, M, N, ks, S, s) : launch16<1, 320>(ad, W, 0, pe, M, N, ks, S, s);
   else rc = mode == 0 ? launch16<0, 256>(ad, W, 0, pe, M, N, ks, S, s) : launch16<1, 256>(ad, W, 0, pe, M, N, ks, S, s);
   if (rc) return rc;
   const long nthr = (long)M * (N / 8);
@@ -703,10 +715,6 @@ int mmgt_gemm16_launch(int mode, int bn, const void* adp, const void* W, long bs
   const ADesc& ad = *reinterpret_cast<const ADesc*>(adp);
   const Epi& ep = *reinterpret_cast<const Epi*>(epp);
   hipStream_t s = (hipStream_t)stream;
-  const bool post = ep.row_scale != nullptr || ep.alpha != 1.f || ep.bias_post != nullptr;
-  if (g_ver == 3 && !g_trace && bn == 256) return mmgt_gemm16v_launch(mode, adp, W, bsw, epp, M, N, K, batch, stream, g_pb);   // gemm16v.hip: one wave per SIMD
-  // gemm16s: K >= 192 (its streams run at most one tile ahead)
-  if (g_ver == 2 && !g_trace && !post && K >= 192 && !ep.residual) return mmgt_gemm16s_launch(mode, bn, adp, W, bsw, epp, M, N, K, batch, stream, g_pb);
   if (bn == 320) return mode == 0 ? launch16<0, 320>(ad, W, bsw, ep, M, N, K, batch, s) : launch16<1, 320>(ad, W, bsw, ep, M, N, K, batch, s);
   return mode == 0 ? launch16<0, 256>(ad, W, bsw, ep, M, N, K, batch, s) : launch16<1, 256>(ad, W, bsw, ep, M, N, K, batch, s);
 }

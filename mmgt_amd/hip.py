@@ -23,6 +23,7 @@ _SIGS = {
     "mmgt_last_error": (ctypes.c_char_p, []),
     "mmgt_tune": (c_int, [ctypes.c_char_p, c_int]),
     "mmgt_tune_get": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_int)]),
+    "mmgt_box_calib": (c_int, [c_float, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
     "mmgt_gemm16_set_trace": (None, [c_void_p]),
     "mmgt_ffn_set_trace": (None, [c_void_p]),
     "mmgt_gemm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_long,
@@ -125,6 +126,14 @@ def tune_get(key):
     v = c_int(0)
     _check(lib().mmgt_tune_get(key.encode(), ctypes.byref(v)), "mmgt_tune_get")
     return v.value
+
+
+def box_calib(warm_seconds=2.0):
+    """(in-kernel MHz, TFLOP/s) of a bare 16x16x32 bf16 MFMA loop on random operands after `warm_seconds` of back-to-back launches: a
+    measure of the BOX, quoted beside a step time so that lines from different boxes can be compared (include/mmgt_hip.h: mmgt_box_calib)."""
+    mhz, tf = c_float(0), c_float(0)
+    _check(lib().mmgt_box_calib(float(warm_seconds), ctypes.byref(mhz), ctypes.byref(tf), _stream()), "mmgt_box_calib")
+    return mhz.value, tf.value
 
 
 def dtype_code(dt):

@@ -120,7 +120,6 @@ class UNet3DConditionModel:
         self._share_rows = bool(hip.tune_get("shared_rows"))      # conv_in + first resnet once for both CFG rows
         self._fuse_oz = bool(hip.tune_get("oz3"))                 # 0: the three masked audio out-projections as separate launches
         self._fuse_ln = bool(hip.tune_get("rowgemm"))             # 0: LayerNorm and q / k / v GEMMs as separate launches
-        self._gn_fused = bool(hip.tune_get("gn_fused_stats"))     # GroupNorm statistics from the producing conv's epilogue
         self.spec = unet3d_spec(boc, cfg["cross_attention_dim"], cfg["audio_attention_dim"], self.in_channels,
                                 self.out_channels, cfg["layers_per_block"],
                                 cfg["motion_module_kwargs"].get("temporal_position_encoding_max_len", 32))

@@ -154,11 +154,9 @@ def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize("ver", [1, 2, 3])
 @pytest.mark.parametrize("cfg", [16, 17])
-def test_gemm16_persistent_workgroups_exact(cfg, ver):
-    """(ver: mmgt_tune("g16_ver") -- 1 = gemm16_kernel, the default; 2 = the staggered gemm16s_kernel wherever it applies: K >= 192, no residual, no row scale; 3 = gemm16v_kernel, one wave per SIMD, for the 256-column tile: cfg 16.)
-    Several tiles per persistent workgroup (more tiles than CUs): the tile-boundary machinery of gemm16 -- bias vectors
+def test_gemm16_persistent_workgroups_exact(cfg):
+    """Several tiles per persistent workgroup (more tiles than CUs): the tile-boundary machinery of gemm16 -- bias vectors
     fetched one tile ahead into LDS, the next W chunk issued in front of the epilogue stores with a counted wait that leaves
     those stores in flight, group 1's deferred barrier, residual prefetch -- on exact small-integer problems (sparse -1/0/1
     operands, integer bias / per-batch bias / residual): any stale stage, late bias copy or mixed-up tile shows as a wrong
@@ -176,7 +174,6 @@ def test_gemm16_persistent_workgroups_exact(cfg, ver):
         return torch.randint(-3, 4, shape, generator=g).to(dev()).to(dtype)
     try:
         hip.tune("gemm_cfg", cfg)
-        hip.tune("g16_ver", ver)
         for M, N, K, use_b2 in [(66000, 1280, 320, False), (140100, 320, 64, False), (70000, 640, 128, True), (66000, 960, 320, False)]:
             a, w = sparse(M, K), sparse(N, K)
             bias = ints(N) if N != 960 else None
@@ -213,12 +210,10 @@ def test_gemm16_persistent_workgroups_exact(cfg, ver):
         assert torch.equal(out.float(), ref), (cfg, "conv", int((out.float() != ref).sum()))
     finally:
         hip.tune("gemm_cfg", 0)
-        hip.tune("g16_ver", 1)
 
 
-@pytest.mark.parametrize("ver", [1, 2, 3])
 @pytest.mark.parametrize("cfg", [16, 17])
-def test_gemm16_core_exact_integers_and_geglu(cfg, ver):
+def test_gemm16_core_exact_integers_and_geglu(cfg):
     """The 16x16x32 ping-pong core (cfg 16: 256 x 256 tile, cfg 17: 256 x 320; bf16 only; GEGLU runs on cfg 16 only): (a) exact small-integer operands with an ASYMMETRIC weight matrix --
     any row/column or k-order mix-up in the fragment maps, the permlane16 epilogue or the swizzle shows as a wrong integer;
     (b) GEGLU with packed weights, (c) ragged M / N edges and several tiles per persistent workgroup, (d) bias2 + residual."""
@@ -227,7 +222,6 @@ def test_gemm16_core_exact_integers_and_geglu(cfg, ver):
     dt = torch.bfloat16
     try:
         hip.tune("gemm_cfg", cfg)
-        hip.tune("g16_ver", ver)
         for M, N, K in [(256, 256, 64), (300, 264, 128), (2000, 1288, 320), (1000, 320, 192), (520, 640, 64)]:
             a = torch.randint(-1, 2, (M, K), device=dev()).to(dt)
             w = torch.randint(-1, 2, (N, K), device=dev()).to(dt)
@@ -255,7 +249,6 @@ def test_gemm16_core_exact_integers_and_geglu(cfg, ver):
         torch.testing.assert_close(out.double(), ref, **tol(dt))
     finally:
         hip.tune("gemm_cfg", 0)
-        hip.tune("g16_ver", 1)
 
 
 @pytest.mark.parametrize("dt", DT)
@@ -464,18 +457,14 @@ def test_attention_spatial_with_bank(dt, hd, nq, nk2, vt):
 
 
 def _set_attn64(a64):
-    """a64 = 0: the 32-queries-per-wave kernel of attention.hip; 1 / 2 / 3: attn64.hip's phased, pipelined and DMA-staged kernels; None: default."""
+    """a64 = 0: the 32-queries-per-wave kernel of attention.hip; 1: attn64.hip's 64-queries-per-wave kernel (attn64d_kernel); None: default (1)."""
     from mmgt_amd import hip
-    hip.tune("attn64", 1 if a64 is None else min(a64, 1))
-    hip.tune("attn64_ver", ATTN64_DEFAULT_VER if a64 is None else max(a64, 1))
+    hip.tune("attn64", 1 if a64 is None else a64)
 
 
-ATTN64_DEFAULT_VER = 3
-
-
-@pytest.mark.parametrize("hd,a64", [(40, 1), (40, 2), (40, 3), (40, 0), (80, 1)])
+@pytest.mark.parametrize("hd,a64", [(40, 1), (40, 0), (80, 1)])
 def test_attention_online_softmax_rescale_branch_is_forced(hd, a64):
-    """(a64: the 64-queries-per-wave kernels of attn64.hip, the production path at head_dim 40 -- 1 phased, 2 pipelined, 3 DMA-staged -- or off.)
+    """(a64: the 64-queries-per-wave kernel of attn64.hip, the production path at head_dim 40, or off.)
     The rare, data-dependent branch of the online softmax (guide rule 26): one key row per later tile is spiked against one query
     so that query's running maximum jumps mid-sequence (own keys and bank keys); full-tensor check against fp64, bf16, V transposed,
     whole 64-key tiles -- the production configuration of the spatial self-attention."""
@@ -514,7 +503,7 @@ def test_attention_online_softmax_rescale_branch_is_forced(hd, a64):
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
 
-@pytest.mark.parametrize("a64", [0, 1, 2, 3])
+@pytest.mark.parametrize("a64", [0, 1])
 def test_attention_run_to_run_deterministic(a64):
     """Identical launches give bitwise identical results (a data race between the staging writes and the fragment reads of the
     flash attention kernels would show as a result that changes from launch to launch): spatial shape with bank, head_dim 40,
@@ -564,9 +553,8 @@ def test_attention_temporal_layout(dt, hd, frames, hw):
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
 
-@pytest.mark.parametrize("a64", [1, 2, 3])
 @pytest.mark.parametrize("nq,nk2,frames", [(256, 128, 2), (512, 256, 3)])
-def test_attention_twin_output_is_the_own_key_attention(nq, nk2, frames, a64):
+def test_attention_twin_output_is_the_own_key_attention(nq, nk2, frames, a64=1):
     """mmgt_attention_twin: one pass over [own keys | bank] per frame writes the attention over both segments AND, as the state after the
     last own-key tile, the attention over the own keys alone -- bitwise what two separate launches compute (the CFG pair of the first
     reference-attention reader: mmgt_amd/unet3d.py _spatial_transformer_twin)."""

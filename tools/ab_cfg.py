@@ -136,4 +136,4 @@ if __name__ == "__main__":
             mn, md = min(times[c]), statistics.median(times[c])
             cells.append(f"c{c}: {mn:7.1f}/{md:7.1f}us {flops / mn / 1e6:5.0f}TF d={d:.1e}")
         print(f"{name:44s} | " + " | ".join(cells), flush=True)
-    hip.tune(key, {"gemm_cfg": 0, "g16_ver": 1}.get(key, -1))
+    hip.tune(key, {"gemm_cfg": 0}.get(key, -1))

@@ -44,13 +44,11 @@ def t_us(fn, reps=3):
 if __name__ == "__main__":
     for name, run, fl, o in [case(4096, 320, 4096), case(4096, 320, 0), case(1024, 640, 1024), case(1024, 640, 0), case(256, 1280, 256)]:
         outs = {}
-        for a64 in (0, 1, 2, 3):                        # 0: 32 queries per wave; 1: 64 per wave, phased (attn64_kernel); 2: pipelined over half tiles; 3: + LDS-DMA staging
-            hip.tune("attn64", min(a64, 1))
-            hip.tune("attn64_ver", max(a64, 1))
+        for a64 in (0, 1):                              # 0: 32 queries per wave (attention.hip); 1: 64 per wave, LDS-DMA staged (attn64d_kernel)
+            hip.tune("attn64", a64)
             t_us(run)
             ts = [t_us(run) for _ in range(5)]
             outs[a64] = o.float().clone()
             print(f"{name:32s} attn64={a64} | {min(ts):8.1f}/{statistics.median(ts):8.1f} us {fl / min(ts) / 1e6:5.0f} TF", flush=True)
-        print(f"    max|attn64 - base| = {(outs[1] - outs[0]).abs().max().item():.3e}   max|pipelined - base| = {(outs[2] - outs[0]).abs().max().item():.3e}   max|dma - pipelined| = {(outs[3] - outs[2]).abs().max().item():.3e}", flush=True)
+        print(f"    max|attn64 - base| = {(outs[1] - outs[0]).abs().max().item():.3e}", flush=True)
     hip.tune("attn64", 1)
-    hip.tune("attn64_ver", 3)

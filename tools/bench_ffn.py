@@ -49,24 +49,13 @@ def main():
     out2 = torch.empty_like(x)
     two = lambda: hip.gemm(hip.ff_fused(x, g, b, img, b2, x, INNER, out=out), wpo, bpo, residual=res2, out=out2)
     po = lambda: hip.ff_fused_po(x, g, b, img, b2, x, INNER, imgpo, bpo, res2, out=out2)
-    hip.lib().mmgt_tune(b"ffn_ver", 4)
     for rnd in range(3):
         t2, tp = t_ms(two), t_ms(po)
         print(f"round {rnd}: ff_fused + proj_out GEMM (+res) {t2 * 1e3:7.1f} us | ff_fused_po {tp * 1e3:7.1f} us", flush=True)
-    def ver(v):
-        hip.lib().mmgt_tune(b"ffn_ver", v)
-        return t_ms(fused)
     for rnd in range(3):
-        t3v, t4v, t3 = ver(3), ver(4), t_ms(three)
-        print(f"round {rnd}: fused two-role {t3v * 1e3:7.1f} us = {fl / t3v / 1e9:6.0f} TFLOP/s | single-role {t4v * 1e3:7.1f} us = "
-              f"{fl / t4v / 1e9:6.0f} TFLOP/s | LN + ff1 + ff2 {t3 * 1e3:7.1f} us = {fl / t3 / 1e9:6.0f} TFLOP/s", flush=True)
-    for v in (3, 4):
-        hip.lib().mmgt_tune(b"ffn_ver", v)
-        for dbg, what in ((1, "compute stream alone (no weight fetch)"), (2, "weight stream alone (no MFMA / GELU)")):
-            hip.lib().mmgt_tune(b"ffn_dbg", dbg)
-            print(f"ver {v} ffn_dbg {dbg}: {t_ms(fused) * 1e3:7.1f} us   {what}", flush=True)
-        hip.lib().mmgt_tune(b"ffn_dbg", 0)
-
-
-if __name__ == "__main__":
-    main()
+        t4v, t3 = t_ms(fused), t_ms(three)
+        print(f"round {rnd}: fused {t4v * 1e3:7.1f} us = {fl / t4v / 1e9:6.0f} TFLOP/s | LN + ff1 + ff2 {t3 * 1e3:7.1f} us = {fl / t3 / 1e9:6.0f} TFLOP/s", flush=True)
+    for dbg, what in ((1, "compute stream alone (no weight fetch)"), (2, "weight stream alone (no MFMA / GELU)")):
+        hip.lib().mmgt_tune(b"ffn_dbg", dbg)
+        print(f"ffn_dbg {dbg}: {t_ms(fused) * 1e3:7.1f} us   {what}", flush=True)
+    hip.lib().mmgt_tune(b"ffn_dbg", 0)

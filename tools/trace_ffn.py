@@ -25,8 +25,7 @@ def main():
     out = torch.empty_like(x)
     if len(sys.argv) > 1:
         hip.lib().mmgt_tune(b"ffn_dbg", int(sys.argv[1]))
-    ver = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    hip.lib().mmgt_tune(b"ffn_ver", ver)
+    ver = 4
     for _ in range(3):
         hip.ff_fused(x, g, b, img, b2, x, INNER, out=out)
     nwg = M // 128
