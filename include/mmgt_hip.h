@@ -44,13 +44,14 @@ const char* mmgt_last_error(void);
  *   "gn_rows"  = 0 (default: measured choice) or the GroupNorm rows per workgroup;
  *   "splitk"   = 1 (default) / 0: split-K of long reductions on grids of at most half a tile per CU (the 8x8-level convs);
  *   "ffn_dbg"  = 0 (default) .. 2: ablation builds of mmgt_ff_fused (timing only, results are garbage for v > 0).
+ *   "tleg_abl" = 0 (default) or a bit of csrc/tleg.hip's ABL list: timing ablations of mmgt_temporal_leg320 at 24 frames (results are garbage).
  *   "tailsplit" = 1 (default) / 0: convs whose tile count leaves the last round of the persistent grid half empty run that round's rows
  *               as a second launch with the reduction split in two (A/B switch).
  * One kernel per family ships: the measured-slower variants of earlier rounds (gemm16s / gemm16v, the phased and register-staged
  * head_dim-40 attention kernels, the producer / consumer FeedForward) are records under tools/micro/. */
 int mmgt_tune(const char* key, int value);
 /* Host-side switches kept in the same table (what mmgt_amd/unet3d.py, pipeline.py and smga.py consult; all default 1, 0 = the
- * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "zero_audio_skip",
+ * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "tleg", "zero_audio_skip",
  * "window_state", "smga_graph".  mmgt_tune sets them, mmgt_tune_get reads them: one state describes a run. */
 int mmgt_tune_get(const char* key, int* value);
 /* Box calibration for bench.py's `box_calib` (csrc/calib.hip): a bare v_mfma_f32_16x16x32_bf16 loop on random operands, one wave per SIMD,
@@ -264,6 +265,16 @@ int mmgt_activation(const void* x, void* out, long n, int act, int dtype, void* 
 int mmgt_smga_ddim_step(const void* pred_uncond, const void* pred_cond, const float* x, const float* noise, float* out, long n,
                         float guidance, float sqrt_recip_acp, float sqrt_recipm1_acp, float sqrt_acp_next, float c, float sigma,
                         int last, int dtype, void* stream);
+
+/* One launch per temporal-attention leg of a level-0 motion module (csrc/tleg.hip; src/models/motion_module.py:236-259,351-388):
+ *   out = x + to_out(softmax_f(q k^T * scale) v),  q | k | v = (LayerNorm(x; ln_gamma, eps) + beta_pe[f]) . W^T   per pixel over its `frames` rows.
+ * x / out (batch * frames * n_pix, 320) bf16, rows ordered (batch, frame, pixel), contiguous; out may alias x.  beta_pe (pe_rows >= frames, 320)
+ * fp32 = LayerNorm bias + positional encoding of frame f.  wimg = packing.pack_tleg(Wq, Wk, Wv, Wo) (mmgt_temporal_leg320_image_bytes() bytes),
+ * bias_o (320) fp32.  frames = 24 or 12 (48 rows per wave), n_pix a multiple of 4 * 48 / frames.  bf16 only: the fp32-I/O mode and every
+ * other shape run rowgemm / LayerNorm + GEMM -> mmgt_attention -> GEMM + residual. */
+long mmgt_temporal_leg320_image_bytes(void);
+int mmgt_temporal_leg320(const void* x, void* out, const float* ln_gamma, const float* beta_pe, int pe_rows, const void* wimg, const float* bias_o,
+                         int batch, int frames, int n_pix, float scale, float eps, int dtype, void* stream);
 
 /* ---- conditioning producers and the output path on the device; uint8 image buffers are device pointers.
  * blur_mask: (frames, H, W) u8 -> (frames, 64, 64) u8 = cv2.resize(64x64, bilinear) -> cv2.GaussianBlur(ksize, sigma from ksize,

@@ -55,6 +55,15 @@ extern "C" int mmgt_box_calib(float warm_seconds, float* mfma_mhz, float* mfma_t
   hipDeviceProp_t prop;
   MMGT_CHECK(hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess, "box_calib: device query failed");
   const int nwg = prop.multiProcessorCount, iters = 20000;      // 320 000 MFMAs per wave: ~2.3 ms per launch at 2.2 GHz
+  // 96 KiB of (unused) dynamic LDS per workgroup: at most ONE workgroup per CU, so the nwg workgroups load every CU with one wave per SIMD
+  // (without it the dispatcher doubles workgroups up on some CUs and leaves others idle: 1.46 PFLOP/s at 2.39 GHz on a round-5 box)
+  constexpr int CALIB_LDS = 96 * 1024;
+  static bool attr = false;
+  if (!attr) {
+    MMGT_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(calib_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CALIB_LDS) == hipSuccess,
+               "box_calib: cannot reserve LDS");
+    attr = true;
+  }
   unsigned long long* d_st = nullptr;
   float* d_sink = nullptr;
   MMGT_CHECK(hipMalloc(reinterpret_cast<void**>(&d_st), sizeof(unsigned long long) * 2 * nwg) == hipSuccess &&
@@ -67,7 +76,7 @@ extern "C" int mmgt_box_calib(float warm_seconds, float* mfma_mhz, float* mfma_t
   unsigned seed = 1;
   do {                                                            // back-to-back launches until the chip has settled under the load
     (void)hipEventRecord(e0, s);
-    for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(calib_mfma_kernel, dim3(nwg), dim3(256), 0, s, d_st, d_sink, iters, seed++);
+    for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(calib_mfma_kernel, dim3(nwg), dim3(256), CALIB_LDS, s, d_st, d_sink, iters, seed++);
     (void)hipEventRecord(e1, s);
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&last_ms, e0, e1);

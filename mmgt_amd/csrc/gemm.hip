@@ -905,6 +905,7 @@ void mmgt_gn_set_lpr0(int v);
 void mmgt_gn_set_narrow(int v);
 void mmgt_ffn_set_dbg(int v);
 void mmgt_rowgemm_set_dbg(int v);
+void mmgt_tleg_set_abl(int v);
 // Switches of the HOST side of the operator (mmgt_amd/unet3d.py, pipeline.py, smga.py read them through mmgt_tune_get): they live here,
 // beside the kernel knobs, so that ONE state -- this table -- describes what a run executed (MMGT_TUNE="twin_attention=0,splitk=0").
 namespace {
@@ -915,6 +916,7 @@ HostSwitch g_host[] = {
     {"shared_rows", 1},      // conv_in + first resnet once when the CFG rows share their input
     {"oz3", 1},              // the three masked audio out-projections as one GEMM
     {"rowgemm", 1},          // row-stationary LayerNorm / GroupNorm -> projection launches
+    {"tleg", 1},             // a level-0 temporal-attention leg as one launch (csrc/tleg.hip)
     {"zero_audio_skip", 1},  // skip the audio cross-attention of an all-zero (unconditional) audio row
     {"window_state", 1},     // keep what a window's audio / masks determine across the steps of a clip
     {"smga_graph", 1},       // replay the SMGA sampler loop as a HIP graph
@@ -942,6 +944,7 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "splitk")) { g_splitk = value; return 0; }
   if (key && !strcmp(key, "tailsplit")) { g_tailsplit = value; return 0; }
   if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 2) { mmgt_ffn_set_dbg(value); return 0; }
+  if (key && !strcmp(key, "tleg_abl") && value >= 0 && value < 128) { mmgt_tleg_set_abl(value); return 0; }
   if (key && !strcmp(key, "rowgemm_dbg") && value >= 0 && value <= 5) { mmgt_rowgemm_set_dbg(value); return 0; }
   mmgt_set_error("tune: unknown key");
   return 1;

@@ -67,6 +67,9 @@ _SIGS = {
                                       c_void_p]),
     "mmgt_rowgemm320": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                 c_long, c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_temporal_leg320_image_bytes": (c_long, []),
+    "mmgt_temporal_leg320": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int,
+                                     c_void_p]),
     "mmgt_channel_norm_gelu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
     "mmgt_lerp_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_silu": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p]),
@@ -450,6 +453,26 @@ def rowgemm320(x, wimg, N, bias=None, *, ln_gamma=None, ln_beta=None, pe_div=0, 
                                  0 if residual is None else residual.stride(0), _ptr(out), 0 if out is None else out.stride(0), n1,
                                  _ptr(out_t), n_tok, npad, M, N, dtype_code(x.dtype), _stream()), "mmgt_rowgemm320")
     return out, out_t
+
+
+def temporal_leg320_supported(dtype, C, heads, frames, n_pix):
+    return dtype == torch.bfloat16 and C == 320 and heads == 8 and frames in (12, 24) and n_pix % (4 * 48 // frames) == 0
+
+
+def temporal_leg320(x, ln_gamma, beta_pe, wimg, bias_o, batch, frames, n_pix, scale, eps=1e-5, out=None):
+    """x + to_out(temporal attention(LayerNorm(x) + pe)) of a level-0 motion-module attention block in ONE launch (csrc/tleg.hip).  x (batch *
+    frames * n_pix, 320) bf16 rows (batch, frame, pixel); beta_pe (>= frames, 320) fp32 = LayerNorm bias + pe rows; wimg = packing.pack_tleg."""
+    _dev(x, ln_gamma, beta_pe, wimg, bias_o, out)
+    assert x.dim() == 2 and x.shape == (batch * frames * n_pix, 320) and x.is_contiguous() and x.dtype == torch.bfloat16
+    assert wimg.dtype == torch.uint8 and wimg.is_contiguous() and wimg.numel() == lib().mmgt_temporal_leg320_image_bytes()
+    assert beta_pe.dim() == 2 and beta_pe.shape[1] == 320 and beta_pe.shape[0] >= frames
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.shape == x.shape and out.is_contiguous() and out.dtype == x.dtype
+    _check(lib().mmgt_temporal_leg320(_ptr(x), _ptr(out), _ptr(_f32(ln_gamma, "ln_gamma")), _ptr(_f32(beta_pe, "beta_pe")), beta_pe.shape[0],
+                                      _ptr(wimg), _ptr(_f32(bias_o, "bias_o")), batch, frames, n_pix, scale, eps, dtype_code(x.dtype), _stream()),
+           "mmgt_temporal_leg320")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------ attention

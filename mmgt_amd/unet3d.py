@@ -19,7 +19,7 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from . import hip
-from .packing import pack_conv3x3, pack_ff_fused, pack_ff_proj_out, pack_geglu, pack_rowgemm, pad_cols, pad_rows, round_up
+from .packing import pack_conv3x3, pack_ff_fused, pack_ff_proj_out, pack_geglu, pack_rowgemm, pack_tleg, pad_cols, pad_rows, round_up
 from .unet3d_spec import unet3d_spec
 
 SD15_CONFIG = dict(  # SD-1.5 unet/config.json + unet_3d.py:649-662 + config/prompts/animation.yaml:47-75
@@ -120,6 +120,7 @@ class UNet3DConditionModel:
         self._share_rows = bool(hip.tune_get("shared_rows"))      # conv_in + first resnet once for both CFG rows
         self._fuse_oz = bool(hip.tune_get("oz3"))                 # 0: the three masked audio out-projections as separate launches
         self._fuse_ln = bool(hip.tune_get("rowgemm"))             # 0: LayerNorm and q / k / v GEMMs as separate launches
+        self._fuse_tleg = bool(hip.tune_get("tleg"))              # 0: a level-0 temporal-attention leg as three launches
         self.spec = unet3d_spec(boc, cfg["cross_attention_dim"], cfg["audio_attention_dim"], self.in_channels,
                                 self.out_channels, cfg["layers_per_block"],
                                 cfg["motion_module_kwargs"].get("temporal_position_encoding_max_len", 32))
@@ -404,6 +405,11 @@ class UNet3DConditionModel:
                     w[a + ".qkv.w"] = self._t(torch.cat([sd[a + ".to_q.weight"], sd[a + ".to_k.weight"],
                                                          sd[a + ".to_v.weight"]], 0))
                     rowimg(a + ".qkv_img", [sd[a + ".to_q.weight"], sd[a + ".to_k.weight"], sd[a + ".to_v.weight"]])
+                    if self._fuse_tleg and has(a + ".to_out.0.weight") and has(a + ".to_out.0.bias") and \
+                            hip.temporal_leg320_supported(self._dtype, sd[a + ".to_q.weight"].shape[1], self.heads, 24, 4096):
+                        # the whole leg (LayerNorm + pe -> q | k | v -> attention over the frames -> to_out + residual) as one launch (csrc/tleg.hip)
+                        w[a + ".tleg_img"] = pack_tleg(*(sd[a + k].to(self._device) for k in (".to_q.weight", ".to_k.weight", ".to_v.weight",
+                                                                                               ".to_out.0.weight")))
                 lin(a + ".to_out.0", a + ".o")
                 if has(a + ".pos_encoder.pe"):
                     w[a + ".pe"] = self._f(sd[a + ".pos_encoder.pe"][0])
@@ -764,6 +770,10 @@ class UNet3DConditionModel:
         hid = self._norm_proj_in(q, x)
         for i in range(2):
             a = f"{t}.attention_blocks.{i}"
+            if (a + ".tleg_img") in self.w and (f"{t}.norms.{i}.bpe") in self.w and hip.temporal_leg320_supported(self._dtype, c, self.heads, frames, n):
+                hid = hip.temporal_leg320(hid, self.w[f"{t}.norms.{i}.g"], self.w[f"{t}.norms.{i}.bpe"], self.w[a + ".tleg_img"], self.w[a + ".o.bias"],
+                                          b, frames, n, hd ** -0.5)
+                continue
             if (a + ".qkv_img") in self.w and n % 128 == 0:
                 qkv, _ = hip.rowgemm320(hid, self.w[a + ".qkv_img"], 3 * c, ln_gamma=self.w[f"{t}.norms.{i}.g"],
                                         ln_beta=self.w[f"{t}.norms.{i}.bpe"], pe_div=n, pe_mod=frames)
