@@ -68,6 +68,7 @@ def parse_args():
     ap.add_argument("--sample-cpu-baseline", action="store_true",
                     help="time the 2-of-24-frame sample of the oracle only (the default on hosts with < 64 cores)")
     ap.add_argument("--no-extras", action="store_true", help="skip the VAE / prologue / per-kernel legs")
+    ap.add_argument("--no-calib", action="store_true", help="skip box_calib (profiled runs: its kernels are not part of the step)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--master-port", type=int, default=0)
     return ap.parse_args()
@@ -488,9 +489,11 @@ def main():
                                  f"(SURVEY 8d; {EXEC_TFLOP_PER_STEP} as executed by the reference) / HIP-event time; executed_tflop = "
                                  f"what this build runs per step after the exact skips of the CFG pair that are switched on; "
                                  f"traffic = bytes per step from {traffic_src}; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
-                                 f"kernel cycles) over the step's kernels from {busy_src}"},
+                                 f"kernel cycles) over the step's kernels from {busy_src} -- both are committed rocprofv3 PMC passes of this "
+                                 f"command at --steps 3 --warmup 1 (per-step = total / 4), not measurements of this {a.steps}-step run"},
         }
-        res["box_calib"] = box_calib(dev, dtype)
+        if not a.no_calib:
+            res["box_calib"] = box_calib(dev, dtype)
         if world == 1 and not a.no_extras:
             res["roofline_kernels"] = kernel_rooflines(unet, dev)
             res.update(extras(pipe, unet, dev, dtype))

@@ -32,7 +32,9 @@ __global__ __launch_bounds__(256) void calib_mfma_kernel(unsigned long long* __r
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[4 * i + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[4 * i + j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j)   // (tied accumulation-register operand: through the builtin hipcc copies the tiles between AGPR ranges and pads
+                                    //  with s_nops -- 27 cycles per MFMA instead of 16, and the loop no longer loads the chip: tools/micro/lonewave.hip)
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[4 * i + j]) : "v"(a[i]), "v"(b[j]));
   }
   asm volatile("s_nop 15\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
   float sum = 0.f;

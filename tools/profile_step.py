@@ -62,6 +62,10 @@ def key_of(name, args, kw):
     if name == "groupnorm_affine":
         x = args[0]
         return f"groupnorm_affine nb={x.shape[0]} hw={x.shape[1]} c={x.shape[2]} (statistics only)", 0
+    if name == "temporal_leg320":
+        x, B, F, n = args[0], args[5], args[6], args[7]
+        return (f"temporal_leg320 B={B} F={F} n={n} (LN + pe -> q|k|v -> attention over the frames -> to_out + res)",
+                2 * x.shape[0] * 320 * 4 * 320 + 4 * x.shape[0] * 320 * F)
     if name == "ff_fused_po":
         x = args[0]
         inner = args[6]
@@ -93,10 +97,10 @@ def main():
     if len(sys.argv) > 2:                                       # window length (the reference ships context_frames = 12)
         bench.FRAMES = int(sys.argv[2])
         bench.build_inputs.__defaults__ = (bench.FRAMES,) + bench.build_inputs.__defaults__[1:]
-    for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "ff_fused", "ff_fused_po", "rowgemm320", "groupnorm_affine", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
+    for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "ff_fused", "ff_fused_po", "temporal_leg320", "rowgemm320", "groupnorm_affine", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
               "ncfhw_to_nhwc", "nhwc_to_ncfhw", "timestep_features", "silu", "cfg_ddim_step", "accumulate_window"]:
         wrap(n)
-    sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-extras"]
+    sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-calib"]
     import io
     import contextlib
     # run bench.main() (its own warmup is recorded too: drop those records afterwards)

@@ -45,7 +45,7 @@ if os.path.exists(log):
         if line.startswith('{"metric"'):
             bench_line = line.strip()
 with open(os.path.join(out, f"bench_steps3_summary_{tag}.md"), "w") as f:
-    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras  (build {tag})\n\n")
+    f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-calib  (build {tag})\n\n")
     f.write(f"{steps_total} denoise steps (1 warm-up + 3 timed) at 512x512x24 bf16 on one MI355X; per-step = total / {steps_total}. "
             f"Raw stats: bench_steps3_kernel_stats_{tag}.csv; HBM-side traffic from PMC: pmc_traffic_{tag}.json.\n\n")
     f.write("| kernel | launches/step | ms/step | avg us |\n|---|---|---|---|\n")
@@ -74,7 +74,7 @@ def pmc(kind, counter):
     return per
 
 
-steps_pmc = 3                                      # 1 warm-up + 2 timed
+steps_pmc = 4                                      # 1 warm-up + 3 timed: the same command as the kernel-trace pass
 fetch, write = pmc("fetch", "FETCH_SIZE"), pmc("write", "WRITE_SIZE")
 perk = {}
 for k in set(fetch) | set(write):
@@ -85,7 +85,7 @@ for k in set(fetch) | set(write):
 perk = dict(sorted(perk.items(), key=lambda kv: -(kv[1]["read"] + kv[1]["write"])))
 rd, wr = sum(v["read"] for v in perk.values()), sum(v["write"] for v in perk.values())
 json.dump({
-    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (two separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (two separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-calib",
     "steps_profiled": steps_pmc,
     "correction": "gfx950: FETCH_SIZE reports exactly 1/2 of wide coalesced reads (MI355X_MICROARCH.md, HBM section) -> read bytes = "
                   "2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 is exact for 16-byte stores.",
@@ -115,8 +115,8 @@ if os.path.exists(mdir):
     tot_busy = sum(c["SQ_VALU_MFMA_BUSY_CYCLES"] for c in per.values())
     tot_cyc = sum(c["GRBM_GUI_ACTIVE"] / 8 for c in per.values())
     rowsm = dict(sorted(rowsm.items(), key=lambda kv: -kv[1]["kernel_cycles_per_step"]))
-    json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 2 "
-                          "--warmup 1 --no-cpu-baseline --no-extras",
+    json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 3 "
+                          "--warmup 1 --no-cpu-baseline --no-extras --no-calib",
                "steps_profiled": steps_pmc, "mfma_busy": tot_busy / (NSIMD * tot_cyc),
                "definition": "sum over the step's own kernels of SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x sum of kernel cycles), kernel cycles = "
                              "GRBM_GUI_ACTIVE / 8; a profiled pass holds a lower clock than an un-profiled run, cycles are what is compared",
