@@ -39,7 +39,8 @@ extern "C" {
 int mmgt_abi_version(void);
 const char* mmgt_last_error(void);
 /* Benchmark-only knobs (A/B measurements and tests; the defaults are the product):
- *   "gemm_cfg" = 0 (heuristic tile choice) or 1, 3, 6, 9, 12, 16, 17 (force a GEMM / conv tile configuration);
+ *   "gemm_cfg" = 0 (heuristic tile choice) or 1, 3, 6, 9, 12, 16, 17, 19 (force a GEMM / conv tile configuration; 19 = gemm16's 192 x 320 tile);
+ *   "bm192"    = 1 (default) / 0: the 192-row gemm16 tile for shapes whose 256-row tile count leaves the last round of the grid half empty;
  *   "attn64"   = 1 (default) / 0: the 64-queries-per-wave spatial attention kernel at head_dim 40;
  *   "gn_rows"  = 0 (default: measured choice) or the GroupNorm rows per workgroup;
  *   "splitk"   = 1 (default) / 0: split-K of long reductions on grids of at most half a tile per CU (the 8x8-level convs);

@@ -738,7 +738,8 @@ int launch_cfg(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, i
 
 int g_splitk = 1;     // mmgt_tune("splitk", 0 / 1): A/B switch of the split-K path
 int g_tailsplit = 1;  // mmgt_tune("tailsplit", 0 / 1): A/B switch of the tail split (below)
-int g_gemm_cfg = 0;   // 0 = heuristic; 1, 3, 6, 9, 12, 16 force a tile configuration (mmgt_tune("gemm_cfg", v), benchmarking only)
+int g_gemm_cfg = 0;   // 0 = heuristic; 1, 3, 6, 9, 12, 16, 17, 19 force a tile configuration (mmgt_tune("gemm_cfg", v), benchmarking only)
+int g_bm192 = 1;      // mmgt_tune("bm192", 0 / 1): A/B switch of the 192-row gemm16 tile
 
 }  // namespace
 // gemm16.hip: the bf16 256x256 8-phase core on 16x16x32 MFMAs (cfg 16)
@@ -802,30 +803,46 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
                                                                                                          //  to 64 -- VAE 8 x 512^2 x 128 -> 64: 651 -> 503 us on the 128x64 tile)
     } else if (b16 && !geglu && N % 320 == 0 && N <= 960 && M >= 131072) cfg = 17;
     else if (b16 && !geglu && N % 320 == 0 && N <= 1280 && M >= 49152 && (K >= 1280 || ep.residual || N == 1280)) cfg = 17;   // 32x32 level
+    else if (b16 && !geglu && N == 640 && M >= 24576 && K >= 2560 && g_bm192) cfg = 17;   // (12-frame windows: ff2 of the 32x32 level on the 192-row tile, 90.4 -> 82.3 us)
     else if (sq_ok) cfg = b16 ? 16 : 9;
     else if (geglu || K >= 1280) cfg = tiles256 >= 256 ? 6 : (!geglu && tiles128 <= 256) ? 3 : 1;   // (<= one 128x128 tile per CU: 128x64 tiles, -5..-7 % at M = 3072)
     else if (M >= 131072 && N >= 640) cfg = 6;
     else cfg = 1;
   }
   if (geglu && (cfg == 3 || cfg == 12)) cfg = 1;   // GEGLU pairs need 64-column wave tiles
+  // cfg 19 = gemm16's 192 x 320 tile (round 5): taken where 256-row tiles leave the last round of the persistent grid half empty.  With T
+  // tiles on 256 CUs a launch runs ceil(T / 256) rounds of one tile time; a 192-row tile takes ~0.88 of a 256-row tile's time (three MFMA row
+  // tiles per four W fragment reads instead of four).  Measured (tools/ab_cfg.py SET=bm192, profiles/r5/ab_cfg_bm192_r5.txt): 49 152 x 640
+  // (384 tiles = 2 rounds against 512 = 2 x 0.88): K = 640 + residual 66.1 -> 62.5 us, K = 2560 + residual 184.8 -> 170.6, K = 1280 89.9 ->
+  // 83.2; conv 32 x 32, 320 -> 640 185 -> 174; 12-frame windows: 98 304 x 320 + residual 50.3 -> 46.2, 24 576 x 640 x 2560 88.4 -> 82.3, convs
+  // 175 -> 167 and 190 -> 178.  It loses where the round count does not drop (196 608 rows, N = 1280) and against the tail split of the
+  // long-reduction convs (48 x 32 x 32, 640 -> 640: 305 us against 322), which therefore keeps its shapes.
+  bool bm192 = cfg == 19;
+  if (cfg == 19) cfg = 17;
+  if (cfg == 17 && !bm192 && g_gemm_cfg == 0 && g_bm192 && std::is_same<T, bf16_t>::value && batch == 1 && N % 320 == 0) {
+    const long tn = N / 320;
+    const long r256 = (((long)(M + 255) / 256) * tn + 255) / 256, r192 = (((long)(M + 191) / 192) * tn + 255) / 256;
+    bm192 = (double)r192 * 0.88 < (double)r256 * 0.97;
+  }
   if (cfg == 16 || cfg == 17) {   // gemm16.hip, 256 / 320 columns: bf16, plain vectorised epilogue only (GEGLU: 256); else fall back
     const bool post = ep.row_scale || ep.alpha != 1.f || ep.bias_post;   // row scale / alpha / post-scale bias: without GEGLU only
     if (std::is_same<T, bf16_t>::value && ep.fast && ep.act <= (cfg == 16 && !post ? 1 : 0) &&
         (((uintptr_t)ep.bias | (uintptr_t)ep.bias2 | (uintptr_t)ep.bias_post) & 15) == 0 && N % 4 == 0) {   // (bias vectors travel by 16-byte DMA)
-      const int bn = cfg == 16 ? 256 : 320;
+      const int bn = cfg == 16 ? 256 : bm192 ? 192320 : 320;   // (192320: the 192 x 320 tile)
       // Tail split.  A persistent grid of T tiles runs ceil(T / 256) rounds of one tile per CU; with a long reduction and T = 256 q + r,
       // r <= 128 (the 32x32 level: 49 152 rows x 640 columns = 384 tiles), the last round keeps half the chip idle for a whole tile.  The
       // rows of the r tail tiles run as a second launch with the reduction split in two (2 r <= 256 half-tiles: one round of half the
       // length) + the fixed-order reduce.  Convs only (reductions of 2880 .. 17 280: 32x32 convs 640 -> 640 338 -> 310 us, 1280 -> 640
       // 631 -> 556, 1920 -> 640 923 -> 791): the fp32 partial slabs and the reduce cost ~25 us, which a dense K = 2560 tile does not repay.
-      const long tiles_n = (N + bn - 1) / bn, tiles_m = (M + 255) / 256, ntile = tiles_m * tiles_n;
+      const int bnc = cfg == 16 ? 256 : 320;
+      const long tiles_n = (N + bnc - 1) / bnc, tiles_m = (M + 255) / 256, ntile = tiles_m * tiles_n;
       const int nch = K / 64;
-      if (g_tailsplit && MODE == 1 && batch == 1 && !ad.ksplit && ep.act == 0 && !post && N % bn == 0 && N % 8 == 0 && K >= 2560 && nch % 2 == 0 && ntile > 256) {
+      if (g_tailsplit && (!bm192 || g_gemm_cfg == 0) && MODE == 1 && batch == 1 && !ad.ksplit && ep.act == 0 && !post && N % bnc == 0 && N % 8 == 0 && K >= 2560 && nch % 2 == 0 && ntile > 256) {
         const long rows_a = (256 * (ntile / 256) / tiles_n) * 256;                  // whole row tiles that fill ntile / 256 full rounds
         const long tail = (tiles_m - rows_a / 256) * tiles_n;
         const long img = MODE == 1 ? (long)ad.OH * ad.OW : 1;
         if (rows_a > 0 && rows_a < M && tail > 0 && 2 * tail <= 256 && 4 * tail >= 256 && rows_a % img == 0) {
-          int rc = mmgt_gemm16_launch(MODE, bn, &ad, W, bsw, &ep, (int)rows_a, N, K, 1, s);
+          int rc = mmgt_gemm16_launch(MODE, bnc, &ad, W, bsw, &ep, (int)rows_a, N, K, 1, s);
           if (rc) return rc;
           ADesc adb = ad;
           Epi epb = ep;
@@ -839,7 +856,7 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
           }
           if (ep.residual) epb.residual = ep.residual + rows_a * ep.ldr * esz;
           epb.out = ep.out + rows_a * ep.ldo * esz;
-          return mmgt_gemm16_splitk(MODE, bn, &adb, W, &epb, (int)(M - rows_a), N, K, 2, s, (int)rows_a);
+          return mmgt_gemm16_splitk(MODE, bnc, &adb, W, &epb, (int)(M - rows_a), N, K, 2, s, (int)rows_a);
         }
       }
       return mmgt_gemm16_launch(MODE, bn, &ad, W, bsw, &ep, M, N, K, batch, s);
@@ -942,6 +959,7 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "gn_narrow")) { mmgt_gn_set_narrow(value); return 0; }
   if (key && !strcmp(key, "gn_lpr0")) { if (value != 4 && value != 8 && value != 16) return -1; mmgt_gn_set_lpr0(value); return 0; }
   if (key && !strcmp(key, "splitk")) { g_splitk = value; return 0; }
+  if (key && !strcmp(key, "bm192")) { g_bm192 = value; return 0; }
   if (key && !strcmp(key, "tailsplit")) { g_tailsplit = value; return 0; }
   if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 2) { mmgt_ffn_set_dbg(value); return 0; }
   if (key && !strcmp(key, "tleg_abl") && value >= 0 && value < 128) { mmgt_tleg_set_abl(value); return 0; }

@@ -48,13 +48,18 @@ __device__ __forceinline__ acc4 mma16(s16x8 a, s16x8 b, acc4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int MODE, int BN>
+// BM = 192 (48 rows per wave = three 16-row tiles instead of four): the same core for shapes whose 256-row tile count leaves the last round of
+// the persistent grid half empty -- 49 152 x 640 is 384 tiles of 256 x 320 = 1.5 rounds of 256 CUs, but 512 tiles of 192 x 320 = two rounds of
+// 3/4 the length; 12 288 x 1280 is 192 tiles (a quarter of the chip idle throughout), but exactly 256 tiles of 192 x 320.
+template <int MODE, int BN, int BM = 256>
 __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __restrict__ W, long bsw, Epi ep, int M, int N,
                                                         int K, int tiles_m, int tiles_n, int pb, unsigned long long* trace) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   typedef bf16_t T;
   static_assert(BN == 256 || BN == 320, "BN");
-  constexpr int ESZ = 2, BM = 256, ROWB = 128, BK = 64, NW = 8;
+  static_assert(BM == 256 || BM == 192, "BM");
+  constexpr int ESZ = 2, ROWB = 128, BK = 64, NW = 8;
+  constexpr int WROWS = BM / 4, RT = WROWS / 16;   // rows and 16-row tiles per wave
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int CPR = 8, RPD = 8;               // 16-byte chunks per row; rows per 1-KiB DMA piece
   constexpr int GA = BM / RPD / NW, GB = BN / RPD / NW;   // pieces per wave and chunk: 4 x A + 4 or 5 x W
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
   // of a row depends on lm only ((16 t + lm) >> 1 & 7 == lm >> 1 & 7), so two per-lane offsets (ks = 0, 1) serve every tile
   const int sw = (lm >> 1) & 7;
   const int roff0 = lm * ROWB + ((lq ^ sw) << 4), roff1 = lm * ROWB + (((4 + lq) ^ sw) << 4);
-  const int a_base = wm * 64 * ROWB;                       // this wave's 64 A rows
+  const int a_base = wm * WROWS * ROWB;                    // this wave's A rows
   const int b_base = A_BYTES + wn * (BN / 2) * ROWB;       // this wave's BN / 2 W rows
 
   const int nchunks = K / BK;
@@ -288,15 +293,15 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
   for (int vt = blockIdx.x; vt < nwg; vt += G) {
     int tm, tn;
     decode(vt, tm, tn);
-    const int row0 = tm * BM + wm * 64, col0 = tn * BN + wn * (BN / 2);
+    const int row0 = tm * BM + wm * WROWS, col0 = tn * BN + wn * (BN / 2);
 
-    acc4 acc[4][NT];
+    acc4 acc[RT][NT];
     if (has_bias) {
       const acc4* lb = reinterpret_cast<const acc4*>(smem + BIAS_OFF) + wn * (BN / 8) + lq;   // this lane's columns 16 j + 4 lq + r
       const int b2r0 = (tm * BM) / b2div;
-      bool second[4];                      // row 16 i + lm of the wave belongs to the tile's second bias2 row
+      bool second[RT];                     // row 16 i + lm of the wave belongs to the tile's second bias2 row
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < RT; ++i) {
         int m = row0 + 16 * i + lm;
         if (m >= M) m = M - 1;
         second[i] = ep.bias2 && m / b2div != b2r0;
@@ -307,21 +312,21 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
         if (ep.bias2) {
           const acc4 r0v = lb[BIAS_ARR / 16 + 4 * j], r1v = lb[2 * BIAS_ARR / 16 + 4 * j];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i][j] = b + (second[i] ? r1v : r0v);
+          for (int i = 0; i < RT; ++i) acc[i][j] = b + (second[i] ? r1v : r0v);
         } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i][j] = b;
+          for (int i = 0; i < RT; ++i) acc[i][j] = b;
         }
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (acc4)(0.f);
     }
 
     stamp(0);
-    s16x8 fa[4][2], fb[2][2];   // [tile][ks]
+    s16x8 fa[RT][2], fb[2][2];   // [tile][ks]
     for (int ch = 0; ch < nchunks; ++ch) {
       if (trace && (wid & 3) == 0 && lane == 0 && trace_n < 8 && ch < 16)   // debug: chunk start stamps behind the tile stamps
         trace[65536 + (((long)blockIdx.x * 8 + trace_n) * 2 + wr) * 16 + ch] = wall_clock64();
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
         }
         if (P == 0) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
+          for (int t = 0; t < RT; ++t) {
             const char* pa = st + a_base + 16 * t * ROWB;
             fa[t][0] = *reinterpret_cast<const s16x8*>(pa + roff0);
             fa[t][1] = *reinterpret_cast<const s16x8*>(pa + roff1);
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
         if (P == NPH - 1) {
           // chunk c + 1 must have landed before the barrier that precedes its first read; the GA A pieces of chunk c + 2
           // issued during this chunk are the only younger LDS-DMA (epilogue loads / stores of a tile end are older)
-          constexpr int NST = 4 * (NT / 2);                  // 16-byte stores of a full tile's epilogue per wave (GEGLU: half)
+          constexpr int NST = RT * (NT / 2);                 // 16-byte stores of a full tile's epilogue per wave (GEGLU: half)
           if (skipW && w_relax) {
             if (ep.act == 1) { if (moreA) wait_vmcnt<GA + NST / 2>(); else wait_vmcnt<NST / 2>(); }
             else { if (moreA) wait_vmcnt<GA + NST>(); else wait_vmcnt<NST>(); }
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
+          for (int t = 0; t < RT; ++t)
 #pragma unroll
             for (int u = 0; u < 2; ++u) acc[t][2 * P + u] = mma16(fb[u][ks], fa[t][ks], acc[t][2 * P + u]);
         __builtin_amdgcn_s_setprio(0);
@@ -429,21 +434,21 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
         for (int jp = 0; jp < NPAIR; ++jp) dst[jp] = *reinterpret_cast<const u32x4*>(rrow + (32 * jp < ncol ? 32 * jp : ncol - 8));   // (beyond N: column N - 8)
       };
       if (RES && NBUF == 2) load_res(0, rv[0]);
-      float rsv[POST ? 4 : 1];
+      float rsv[POST ? RT : 1];
       const acc4* lpost = reinterpret_cast<const acc4*>(smem + BIAS_OFF + 3 * BIAS_ARR) + ((wn * (BN / 2) + cofs) >> 2);
       if (POST) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < RT; ++i) {
           const int m = row0 + 16 * i + lme;
           rsv[i] = (ep.row_scale ? ep.row_scale[m < M ? m : M - 1] : 1.f) * ep.alpha;
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < RT; ++i) {
         const int m = row0 + 16 * i + lme;
         T* orow = obase + (long)m * ep.ldo;
         if (RES) {
-          if (NBUF == 2 ? i < 3 : true) load_res(NBUF == 2 ? i + 1 : i, rv[NBUF == 2 ? (i + 1) & 1 : 0]);
+          if (NBUF == 2 ? i < RT - 1 : true) load_res(NBUF == 2 ? i + 1 : i, rv[NBUF == 2 ? (i + 1) & 1 : 0]);
         }
 #pragma unroll
         for (int jp = 0; jp < NPAIR; ++jp) {
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
       // = one 16-byte store); mmgt_splitk_reduce sums the slabs in slice order and applies the epilogue
       float* pb = reinterpret_cast<float*>(ep.out) + (long)bz * ep.bso + col0 + 4 * lqe;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < RT; ++i) {
         const int m = row0 + 16 * i + lme;
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -525,12 +530,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
 unsigned long long* g_trace = nullptr;
 int g_pb = -1;   // mmgt_tune("g16_pb", v): row panels per column-major group of the tile order (-1 = by shape, 1 = row-major)
 
-template <int MODE, int BN>
+template <int MODE, int BN, int BM = 256>
 int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N, int K, int batch, hipStream_t s) {
-  constexpr int BM = 256;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   const size_t lds = (size_t)2 * (BM + BN) * 128 + 4 * 2048;   // stages + the four bias vectors
-  auto kern = gemm16_kernel<MODE, BN>;
+  auto kern = gemm16_kernel<MODE, BN, BM>;
   static int resident = 0;
   if (!resident) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -715,6 +719,7 @@ int mmgt_gemm16_launch(int mode, int bn, const void* adp, const void* W, long bs
   const ADesc& ad = *reinterpret_cast<const ADesc*>(adp);
   const Epi& ep = *reinterpret_cast<const Epi*>(epp);
   hipStream_t s = (hipStream_t)stream;
+  if (bn == 192320) return mode == 0 ? launch16<0, 320, 192>(ad, W, bsw, ep, M, N, K, batch, s) : launch16<1, 320, 192>(ad, W, bsw, ep, M, N, K, batch, s);   // 192 x 320 tile
   if (bn == 320) return mode == 0 ? launch16<0, 320>(ad, W, bsw, ep, M, N, K, batch, s) : launch16<1, 320>(ad, W, bsw, ep, M, N, K, batch, s);
   return mode == 0 ? launch16<0, 256>(ad, W, bsw, ep, M, N, K, batch, s) : launch16<1, 256>(ad, W, bsw, ep, M, N, K, batch, s);
 }

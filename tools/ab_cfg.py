@@ -93,6 +93,14 @@ SETS = {
     "quant": lambda: [gemm_case(12288, 1280, 1280, res=True), gemm_case(12288, 1280, 5120, res=True), gemm_case(12288, 1280, 1280),
                       gemm_case(49152, 640, 640, res=True), gemm_case(49152, 640, 2560, res=True), gemm_case(49152, 640, 640),
                       gemm_case(12288, 2560, 1280), gemm_case(49152, 1280, 640)],
+    # round 5: candidates of the 192 x 320 tile (cfg 19) at 24 and 12 frames
+    "bm192": lambda: [gemm_case(49152, 640, 640, res=True), gemm_case(49152, 640, 2560, res=True), gemm_case(49152, 640, 640), gemm_case(49152, 640, 1280),
+                      gemm_case(49152, 640, 320, res=True), gemm_case(12288, 1280, 1280, res=True), gemm_case(12288, 1280, 5120, res=True),
+                      gemm_case(49152, 1280, 640), gemm_case(196608, 320, 320, res=True), gemm_case(196608, 960, 320, bias=False),
+                      conv_case(48, 32, 640, 640), conv_case(48, 32, 1280, 640), conv_case(48, 32, 1920, 640), conv_case(48, 32, 320, 640),
+                      conv_case(48, 64, 320, 320), conv_case(48, 64, 640, 320),
+                      gemm_case(98304, 320, 320, res=True), gemm_case(24576, 640, 640, res=True), gemm_case(24576, 640, 2560, res=True),
+                      conv_case(24, 32, 640, 640), conv_case(24, 64, 320, 320)],
     # the 256-column family (gemm16v candidates): GEGLU, q|k|v, long-K + residual at N = 1280, convs to 1280 / 640, 8192^3
     "v256": lambda: [gemm_case(49152, 5120, 640, act=1), gemm_case(12288, 10240, 1280, act=1), gemm_case(196608, 2560, 320, act=1),
                      gemm_case(12288, 3840, 1280, bias=False), gemm_case(49152, 1920, 640, bias=False), gemm_case(12288, 1280, 5120, res=True),
