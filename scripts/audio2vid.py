@@ -10,7 +10,8 @@ The chain is the reference's (line numbers of its scripts/audio2vid.py):
      (`find_best_slice`, :79-108)                                  -> mmgt_amd.smga.SMGA.render_sample (HIP)
   2. seam smoothing by cubic splines around every 60th frame (:351-374)   -> host numpy / scipy, as in the reference
   3. key points -> pose / face / lips / hands frames (:386 `pose_vid_generator`: cv2 drawing of src/dwpose into four mp4 files, read
-     back at :426-430) -> drawn on the device, byte for byte the reference's frames (mmgt_dwpose_draw, csrc/dwpose.hip), no files
+     back at :426-430) -> drawn on the device (mmgt_dwpose_draw, csrc/dwpose.hip: bit-exact on uint8 with oracle/dwpose_ref.py, the restatement of the
+     reference drawers and of the OpenCV primitives under them; cv2 itself is not in this image, so that restatement is parity-unpinned), no files
   4. wav2vec2 features of the waveform (:420-426, src/dataset/audio_processor.py:76-131) -> mmgt_amd.wav2vec.Wav2VecModel (HIP);
      mask blur + 4-level pyramid (:453-476), audio window stack + AudioProjModel (:426,439-441) -> device kernels
   5. Pose2VideoPipeline (:484-498), frames converted to uint8 on the device, written as .npy / .gif.

@@ -48,7 +48,9 @@ def _normalised(fn):
         if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef, ast.Module)) and body and \
                 isinstance(body[0], ast.Expr) and isinstance(body[0].value, ast.Constant) and isinstance(body[0].value.value, str):
             node.body = body[1:] or [ast.Pass()]
-    return ast.dump(tree, annotate_fields=False, include_attributes=False)
+    # (ast.unparse, not ast.dump: the dump's text changed in Python 3.13 -- defaulted fields are omitted -- which would silently invalidate every
+    # committed entry on an interpreter bump; unparse prints source in one canonical layout -- ADVICE r4)
+    return ast.unparse(tree)
 
 
 def _deps_digest(deps):
