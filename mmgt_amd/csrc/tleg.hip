@@ -272,8 +272,7 @@ void tleg320_kernel(const TlegArgs a) {
 #pragma unroll
     for (int rt = 0; rt < TL_NRT; ++rt) c2prev[rt] = (u32x2){0u, 0u};
 
-    // One chunk = ten k-steps of NF weight fragments (fragment ks NF + f of the slot): per k-step the next one's fragments are requested, ONE
-    // counted wait, the MFMAs, then one DMA piece of the next chunk.  The last k-step carries the hand-over described at the top.
+    // One chunk = ten k-steps of NF weight fragments (fragment ks NF + f of the slot).  The last k-step carries the hand-over described at the top.
     auto run_chunk = [&](auto NFc, auto&& mfmas) {
       constexpr int NF = decltype(NFc)::value;
       const char* base = smem + TL_L_RING + cur_slot * TL_SLOT + wbase;
@@ -281,11 +280,7 @@ void tleg320_kernel(const TlegArgs a) {
       const bool live = dma_g < total;
       for_range(TL_IC(0), TL_IC(TL_NKS), [&](auto kc) {
         constexpr int ks = decltype(kc)::value;
-        if constexpr (ks + 1 < TL_NKS) {
-#pragma unroll
-          for (int f = 0; f < NF; ++f) wf[(ks + 1) & 1][f] = *reinterpret_cast<const s16x8*>(base + ((ks + 1) * NF + f) * 1024);
-          __builtin_amdgcn_s_waitcnt(0xC07F | (NF << 8));          // lgkmcnt(NF): this k-step's fragments have returned
-        } else {
+        if constexpr (ks == TL_NKS - 1) {
           if constexpr (!(ABL & 32)) {
             // this wave's pieces of the next chunk have landed: everything but the pieces of the chunk after next, the wave's youngest 8 or
             // 5 operations (the stores and residual loads of the out-projection phase are older than those)
@@ -298,9 +293,17 @@ void tleg320_kernel(const TlegArgs a) {
 #pragma unroll
           for (int f = 0; f < TL_NCT; ++f) wf[0][f] = *reinterpret_cast<const s16x8*>(nbase + f * 1024);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(ABL & 16)) mfmas(kc);
-        __builtin_amdgcn_sched_barrier(0);
+        // fragment group f: its MFMAs, then the request for the next k-step's fragment f -- the read goes out under the group's MFMAs instead
+        // of in a block in front of the k-step (the matrix pipe drained for ~20 cycles there).  In front of every group NF reads are in
+        // flight and the oldest is the one it needs: lgkmcnt(NF - 1)
+        for_range(TL_IC(0), NFc, [&](auto fc) {
+          constexpr int f = decltype(fc)::value;
+          if constexpr (ks + 1 < TL_NKS) __builtin_amdgcn_s_waitcnt(0xC07F | ((NF - 1) << 8));
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!(ABL & 16)) mfmas(kc, fc);
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (ks + 1 < TL_NKS) wf[(ks + 1) & 1][f] = *reinterpret_cast<const s16x8*>(base + ((ks + 1) * NF + f) * 1024);
+        });
         if constexpr (ks == 0 && !(ABL & 4)) {
           if (live) issue_chunk(dma_c, dma_slot);
         }
@@ -310,10 +313,8 @@ void tleg320_kernel(const TlegArgs a) {
     // a projection pass: acc[i][j] += W tile x row tile.  SW = false: D[ch][row] (acc[ct][rt]); SW = true: D[row][ch] (acc[rt][ct])
     auto project = [&](auto SWc, acc4 (&acc)[3][3]) {
       constexpr bool SW = decltype(SWc)::value;
-      run_chunk(TL_IC(TL_NCT), [&](auto kc) {
-        constexpr int ks = decltype(kc)::value;
-#pragma unroll
-        for (int ct = 0; ct < TL_NCT; ++ct)
+      run_chunk(TL_IC(TL_NCT), [&](auto kc, auto fc) {
+        constexpr int ks = decltype(kc)::value, ct = decltype(fc)::value;
 #pragma unroll
           for (int rt = 0; rt < TL_NRT; ++rt) {
             // (the first k-step takes C = 0 as an inline constant: no accumulator initialisation pass)
@@ -447,10 +448,8 @@ void tleg320_kernel(const TlegArgs a) {
 #pragma unroll
         for (int rt = 0; rt < TL_NRT; ++rt) { acc[0][rt] = b0; acc[1][rt] = b1; }
       }
-      run_chunk(TL_IC(2), [&](auto kc) {
-        constexpr int ks = decltype(kc)::value;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+      run_chunk(TL_IC(2), [&](auto kc, auto fc) {
+        constexpr int ks = decltype(kc)::value, nt = decltype(fc)::value;
 #pragma unroll
           for (int rt = 0; rt < TL_NRT; ++rt) {
             union { u32x4 u; s16x8 s; } ob;
