@@ -192,6 +192,21 @@ def _(x, wimg, n, bias, ln_gamma, ln_beta, residual):
     return x.new_empty((x.shape[0], n))
 
 
+@_lib.custom_op("mmgt_hip::temporal_leg", mutates_args=(), device_types="cuda")
+def temporal_leg(x: torch.Tensor, ln_gamma: torch.Tensor, beta_pe: torch.Tensor, wimg: torch.Tensor, bias_o: torch.Tensor, batch: int,
+                 frames: int, heads: int) -> torch.Tensor:
+    """x + to_out(attention over the frames of each pixel(LayerNorm(x) + pe)) of a level-0 motion-module attention block in ONE launch
+    (motion_module.py:236-259,351-388): x (batch * frames * n_pix, 320) bf16 rows (batch, frame, pixel), beta_pe (>= frames, 320) fp32 =
+    LayerNorm bias + positional-encoding rows, wimg = packing.pack_tleg(Wq, Wk, Wv, Wo).  frames = 24 or 12."""
+    n_pix = x.shape[0] // (batch * frames)
+    return hip.temporal_leg320(x, ln_gamma, beta_pe, wimg, bias_o, batch, frames, n_pix, (x.shape[1] // heads) ** -0.5)
+
+
+@temporal_leg.register_fake
+def _(x, ln_gamma, beta_pe, wimg, bias_o, batch, frames, heads):
+    return torch.empty_like(x)
+
+
 _VAES = {}
 
 
@@ -217,4 +232,4 @@ def _(z, weights):
 
 
 OPS = ("gemm", "conv3x3_nhwc", "attention", "groupnorm_silu", "layernorm", "cfg_ddim_step", "attn_bank_fwd", "temporal_attn", "mmhaa_cross",
-       "ff_fused", "rowgemm320", "vae_decode")
+       "ff_fused", "rowgemm320", "temporal_leg", "vae_decode")

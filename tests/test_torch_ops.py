@@ -62,6 +62,8 @@ def test_fake_kernels_of_the_fused_ops_give_shapes():
                                            e(320, dt=torch.float32), 1280, None, None, None).shape == (256, 320)
         assert torch.ops.mmgt_hip.rowgemm320(x, e(10, dt=torch.uint8), 960, None, None, None, None).shape == (256, 960)
         assert torch.ops.mmgt_hip.vae_decode(e(2, 4, 8, 8), [e(3)]).shape == (2, 3, 64, 64)
+        assert torch.ops.mmgt_hip.temporal_leg(e(2 * 24 * 8, 320), e(320, dt=torch.float32), e(32, 320, dt=torch.float32), e(10, dt=torch.uint8),
+                                               e(320, dt=torch.float32), 2, 24, 8).shape == (384, 320)
 
 
 @pytest.mark.gpu
@@ -139,6 +141,15 @@ def test_fused_projection_ops_match_torch_math_bf16():
     want_q = ln @ wq.double().t() + bq.double()
     got_q = torch.ops.mmgt_hip.rowgemm320(x, pack_rowgemm(wq), 960, bq, g, be, None)
     torch.testing.assert_close(got_q.double(), want_q, rtol=2 ** -7, atol=2e-2)
+    # temporal_leg: the op against the same fp64 restatement tests/test_tleg_gpu.py uses
+    from mmgt_amd.packing import pack_tleg
+    from tests import test_tleg_gpu as TT
+    B, Fr, n = 2, 12, 16
+    w = TT._weights("op", scale=2.0)
+    xt = r("xt", (B * Fr * n, C), 1.5).bfloat16()
+    got_t = torch.ops.mmgt_hip.temporal_leg(xt, w["g"], w["bpe"], pack_tleg(w["q"], w["k"], w["v"], w["o"]), w["bo"], B, Fr, 8)
+    want_t = TT._ref(xt, w, B, Fr, n, 40 ** -0.5)
+    assert ((got_t.double() - want_t).abs() <= 2.0 ** -8 * want_t.abs() + 8e-3).all()
 
 
 @pytest.mark.gpu
