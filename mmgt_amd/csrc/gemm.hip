@@ -962,7 +962,7 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "bm192")) { g_bm192 = value; return 0; }
   if (key && !strcmp(key, "tailsplit")) { g_tailsplit = value; return 0; }
   if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 2) { mmgt_ffn_set_dbg(value); return 0; }
-  if (key && !strcmp(key, "tleg_abl") && value >= 0 && value < 128) { mmgt_tleg_set_abl(value); return 0; }
+  if (key && !strcmp(key, "tleg_abl") && value >= 0 && value <= 128) { mmgt_tleg_set_abl(value); return 0; }
   if (key && !strcmp(key, "rowgemm_dbg") && value >= 0 && value <= 5) { mmgt_rowgemm_set_dbg(value); return 0; }
   mmgt_set_error("tune: unknown key");
   return 1;

@@ -86,10 +86,12 @@ __device__ __forceinline__ float quad_max(float v) {
 
 // do score tiles (key tile kt, query tile qt) hold any (key, query) pair of the same pixel?  rows 16 t .. 16 t + 15, pixel = row / F
 template <int F> constexpr bool tl_pair(int kt, int qt) { return (16 * kt) / F <= (16 * qt + 15) / F && (16 * qt) / F <= (16 * kt + 15) / F; }
+// ... and is every pair of them in the same pixel (no mask needed)?
+template <int F> constexpr bool tl_all(int kt, int qt) { return (16 * kt) / F == (16 * kt + 15) / F && (16 * qt) / F == (16 * qt + 15) / F && (16 * kt) / F == (16 * qt) / F; }
 
 // ABL (mmgt_tune("tleg_abl", bits), 24-frame kernel, timing only -- results are garbage): 1 no LayerNorm arithmetic, 2 no attention arithmetic,
 // 4 no weight DMA after the first chunk, 8 no epilogue (residual loads, stores), 16 no projection MFMAs, 32 no hand-over wait / barrier, 64 no row loads
-// after the first task
+// after the first task, 128 the counted waits of the hand-over but no barrier
 template <int F, int ABL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void tleg320_kernel(const TlegArgs a) {
@@ -139,18 +141,15 @@ void tleg320_kernel(const TlegArgs a) {
     ++dma_g;
     dma_c = dma_c == TL_NCH - 1 ? 0 : dma_c + 1;
   };
-  // ---- lane constants of the score mask: bit (4 kt + e) of vmask[qt] <=> key row 16 kt + 4 lq + e and query row 16 qt + lm share a pixel
-  unsigned vmask[TL_NRT];
+  // ---- lane constant of the score mask: bit (3 qt + kt) <=> the lane's keys of tile kt (rows 16 kt + 4 lq .. + 3) and its query of tile qt
+  // (row 16 qt + lm) belong to the same pixel.  One bit per tile pair: F is a multiple of 4, so a lane's four keys never straddle a pixel.
+  static_assert(F % 4 == 0, "a lane's four key rows must belong to one pixel");
+  unsigned tmask = 0;
 #pragma unroll
-  for (int qt = 0; qt < TL_NRT; ++qt) {
-    unsigned m = 0;
+  for (int qt = 0; qt < TL_NRT; ++qt)
 #pragma unroll
     for (int kt = 0; kt < TL_NRT; ++kt)
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if ((16 * kt + 4 * lq + e) / F == (16 * qt + lm) / F) m |= 1u << (4 * kt + e);
-    vmask[qt] = m;
-  }
+      if ((16 * kt + 4 * lq) / F == (16 * qt + lm) / F) tmask |= 1u << (3 * qt + kt);
   // ---- prologue: the first weight chunk on its way, the tables into LDS
   issue_chunk(0, 0);
   if (total > 1) issue_chunk(1, 1);
@@ -288,7 +287,7 @@ void tleg320_kernel(const TlegArgs a) {
             else if (dma_c < TL_NQKV) wait_vmcnt<TL_QKV_CHUNK / 4096>();
             else wait_vmcnt<TL_OUT_CHUNK / 4096>();
             __builtin_amdgcn_s_waitcnt(0xC07F);                      // ... and its reads of this chunk have returned
-            __builtin_amdgcn_s_barrier();
+            if constexpr (!(ABL & 128)) __builtin_amdgcn_s_barrier();
           }
 #pragma unroll
           for (int f = 0; f < TL_NCT; ++f) wf[0][f] = *reinterpret_cast<const s16x8*>(nbase + f * 1024);
@@ -304,8 +303,10 @@ void tleg320_kernel(const TlegArgs a) {
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (ks + 1 < TL_NKS) wf[(ks + 1) & 1][f] = *reinterpret_cast<const s16x8*>(base + ((ks + 1) * NF + f) * 1024);
         });
-        if constexpr (ks == 0 && !(ABL & 4)) {
-          if (live) issue_chunk(dma_c, dma_slot);
+        // wave w issues its pieces behind k-step 2 w: issued by all four waves at once the pieces queue in the CU's one address path and the
+        // last wave leaves its issue ~1000 cycles late -- the workgroup then waits for it at the hand-over barrier (22 us of a 227-us leg)
+        if constexpr (ks % 2 == 0 && ks < 8 && !(ABL & 4)) {
+          if (live && wid == ks / 2) issue_chunk(dma_c, dma_slot);
         }
       });
       chunk_next();
@@ -368,15 +369,18 @@ void tleg320_kernel(const TlegArgs a) {
           if constexpr (tl_pair<F>(kt, qt)) {
             acc4 t = mma16(frag2(kp[kt][0], kp[kt][1]), frag2(qp[qt][0], qp[qt][1]), (acc4)(0.f));
             t = mma16(frag2(kp[kt][2], z2), frag2(qp[qt][2], z2), t);
+            if constexpr (!tl_all<F>(kt, qt)) {              // one lane condition per tile pair
+              const bool ok = (tmask >> (3 * qt + kt)) & 1u;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              t[e] = (vmask[qt] >> (4 * kt + e)) & 1u ? t[e] * a.scale_log2e : -1e30f;
-              mx = fmaxf(mx, t[e]);
+              for (int e = 0; e < 4; ++e) t[e] = ok ? t[e] : -1e30f;
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) mx = fmaxf(mx, t[e]);
             s[kt] = t;
           }
         });
-        mx = quad_max(mx);
+        mx = quad_max(mx);                                   // (of the raw scores: the scale is positive and rides in the exponent's FMA)
+        const float nm = -mx * a.scale_log2e;
         float ls = 0.f;
         u32x2 pp[TL_NRT];
         for_range(TL_IC(0), TL_IC(TL_NRT), [&](auto kc) {
@@ -384,9 +388,11 @@ void tleg320_kernel(const TlegArgs a) {
           if constexpr (tl_pair<F>(kt, qt)) {
             acc4 e4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) e4[e] = __builtin_amdgcn_exp2f(s[kt][e] - mx);
+            for (int e = 0; e < 4; ++e) {
+              e4[e] = __builtin_amdgcn_exp2f(fmaf(s[kt][e], a.scale_log2e, nm));
+              ls += e4[e];
+            }
             pp[kt] = pack4(e4);
-            ls += (bf_lo(pp[kt][0]) + bf_hi(pp[kt][0])) + (bf_lo(pp[kt][1]) + bf_hi(pp[kt][1]));     // the denominator sums what P.V multiplies
           } else {
             pp[kt] = z2;
           }
@@ -524,7 +530,7 @@ extern "C" int mmgt_temporal_leg320(const void* x, void* out, const float* ln_ga
     MMGT_LAUNCH_CHECK();
     return 0;
   };
-  static bool attr[16][12] = {};
+  static bool attr[16][13] = {};
   if (frames == 24) {
     switch (g_tleg_abl) {
       case 1: return go(tleg320_kernel<24, 1>, attr[dev][4]);
@@ -535,6 +541,7 @@ extern "C" int mmgt_temporal_leg320(const void* x, void* out, const float* ln_ga
       case 32: return go(tleg320_kernel<24, 32>, attr[dev][9]);
       case 64: return go(tleg320_kernel<24, 64>, attr[dev][10]);
       case 36: return go(tleg320_kernel<24, 36>, attr[dev][11]);
+      case 128: return go(tleg320_kernel<24, 128>, attr[dev][12]);
       default: return go(tleg320_kernel<24, 0>, attr[dev][0]);
     }
   }

@@ -47,7 +47,7 @@ def _ref(x, w, B, F, n, scale, eps=1e-5):
     s = (sp(q) @ sp(k).transpose(-1, -2)) * scale
     e = torch.exp(s - s.max(-1, keepdim=True).values)
     pb = _bf(e.float()).double()
-    o = (pb @ sp(v)) / pb.sum(-1, keepdim=True)
+    o = (pb @ sp(v)) / e.sum(-1, keepdim=True)                                 # (the denominator sums the unrounded exponentials, as tattn_kernel does)
     o = _bf(o.permute(0, 3, 1, 2, 4).reshape(M, C).float()).double()
     return o @ w["o"].double().t() + w["bo"].double() + xd
 

@@ -59,7 +59,7 @@ if __name__ == "__main__":
         print("timing ablations (mmgt_tune tleg_abl; results are garbage):")
         base = min(t_us(fused) for _ in range(3))
         for bit, what in ((1, "no LayerNorm arithmetic"), (2, "no attention arithmetic"), (4, "no weight DMA"), (8, "no epilogue loads / stores"),
-                          (16, "no projection MFMAs"), (32, "no hand-over wait / barrier"), (36, "no weight DMA, no wait / barrier"), (64, "no row loads after the first task")):
+                          (16, "no projection MFMAs"), (32, "no hand-over wait / barrier"), (128, "hand-over waits but no barrier"), (36, "no weight DMA, no wait / barrier"), (64, "no row loads after the first task")):
             hip.tune("tleg_abl", bit)
             t = min(t_us(fused) for _ in range(3))
             print(f"  abl {bit:3d} {what:36s} {t:7.1f} us  ({t - base:+6.1f})", flush=True)
