@@ -18,14 +18,14 @@
 //      (one-pass statistics with v_dot2c_f32_bf16, ln_frag.h's bound), gamma and the beta + pe[f] table from LDS -> xn (120 registers), which
 //      serves as the A and as the B operand (the two fragment layouts coincide).
 //   2. per head: K^T = Wk xn^T and Q^T (D[ch][row]: the lane holds 4 channels of a row = half a fragment of the score product over channels),
-//      V = xn Wv^T (D[row][ch]: the lane holds 4 frames of a channel = half a fragment of P.V over the keys); heads are padded to 48 channels in
-//      the weight image (zero rows), so a head is three 16-channel tiles.  S^T = K Q^T (two MFMAs per tile pair), softmax over the <= F valid
-//      keys (cross-lane part: two lane-group exchanges), O^T = V^T P^T, normalised, packed to bf16: the B operand of the out-projection.  The
-//      8 padding channels of two heads share one tile (v_permlane32_swap), so the out-projection's reduction stays 320 long.
+//      V = xn Wv^T (D[row][ch]: the lane holds 4 frames of a channel = half a fragment of P.V over the keys).  Heads are worked in pairs whose 80
+//      channels are five 16-channel tiles (the channels 32 .. 39 of both heads share one), so nothing is padded.  S^T = K Q^T (two MFMAs per
+//      tile pair), softmax over the <= F valid keys (cross-lane part: two lane-group exchanges), O^T = V^T P^T, normalised, packed to bf16: the
+//      B operand of the out-projection, whose reduction is the 320 channels in tile order.
 //   3. out^T = Wo O^T + bias, + residual (re-read), 16-byte stores after v_permlane16_swap (gemm16.hip's epilogue idiom).
-// Weights: a fragment-major image (mmgt_amd/packing.py::pack_tleg) of 24 chunks of 30 KiB (head x {k, v, q}) and 10 chunks of 20 KiB (32
-// output columns each) streams through a 3-slot LDS ring by LDS-DMA, two chunks ahead, one barrier per chunk; the stream runs across task
-// boundaries.  Rounding points are those of the three launches it replaces (xn, q | k | v, p, the attention output and the result are bf16;
+// Weights: a fragment-major image (mmgt_amd/packing.py::pack_tleg) of 12 chunks of 30 KiB and 12 of 20 KiB (head pair x {k, v, q} x {wide,
+// narrow}) and 10 chunks of 20 KiB (32 output columns each) streams through a 3-slot LDS ring by LDS-DMA, two chunks ahead, one barrier per
+// chunk; the stream runs across task boundaries.  Rounding points are those of the three launches it replaces (xn, q | k | v, p, the attention output and the result are bf16;
 // every sum is fp32), so the two paths agree to the last bit or one bf16 ulp.
 #include <type_traits>
 
@@ -38,12 +38,15 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) float acc4;
 
 constexpr int TL_C = 320, TL_HEADS = 8, TL_HD = 40, TL_ROWS = 48, TL_NRT = 3, TL_NKS = 10, TL_NCT = 3;
-// a q / k / v chunk is 30 fragments padded to 32 KiB in the image (8 whole DMA pieces per wave), an out-projection chunk 20 fragments (5 per wave)
-constexpr int TL_QKV_CHUNK = 32 * 1024, TL_OUT_CHUNK = TL_NKS * 2 * 1024, TL_NQKV = 3 * TL_HEADS, TL_NOUT = TL_C / 32;
-constexpr int TL_NCH = TL_NQKV + TL_NOUT, TL_IMG = TL_NQKV * TL_QKV_CHUNK + TL_NOUT * TL_OUT_CHUNK;
-static_assert(TL_NKS * TL_NCT * 1024 <= TL_QKV_CHUNK && TL_OUT_CHUNK % (4 * 1024) == 0, "chunk geometry");
-constexpr int TL_NSLOT = 3, TL_SLOT = TL_QKV_CHUNK;
-static_assert(TL_SLOT >= TL_OUT_CHUNK, "ring slot");
+// Heads come in pairs (A, B) whose 80 channels are laid out as five 16-channel tiles: A0 A1 | AB2 | B0 B1 with AB2 = [A's channels 32 .. 39 |
+// B's channels 32 .. 39] -- no padding rows (three tiles per head would pad 40 to 48: +20 % of the q | k | v MFMAs and weight bytes).  A projection
+// of a pair runs as two chunks: "wide" = A0 A1 AB2 (30 fragments, padded to 32 KiB in the image: 8 whole DMA pieces per wave), "narrow" = B0 B1
+// (20 fragments, 5 pieces per wave); the out-projection's chunks (32 output columns) are narrow too.  Chunk order of a task: per pair
+// k, v, q wide | k, v, q narrow, then the ten out-projection chunks.
+constexpr int TL_WIDE = 32 * 1024, TL_NARROW = TL_NKS * 2 * 1024, TL_NPAIR = TL_HEADS / 2, TL_PAIR_BYTES = 3 * TL_WIDE + 3 * TL_NARROW;
+constexpr int TL_NQKV = 6 * TL_NPAIR, TL_NOUT = TL_C / 32, TL_NCH = TL_NQKV + TL_NOUT, TL_IMG = TL_NPAIR * TL_PAIR_BYTES + TL_NOUT * TL_NARROW;
+static_assert(TL_NKS * TL_NCT * 1024 <= TL_WIDE && TL_NARROW % (4 * 1024) == 0 && TL_WIDE % (4 * 1024) == 0, "chunk geometry");
+constexpr int TL_NSLOT = 3, TL_SLOT = TL_WIDE;
 constexpr int TL_BPE_STRIDE = TL_C * 4 + 16;                                        // beta + pe rows in LDS: 16 rows on 16 different bank groups
 constexpr int TL_L_RING = 0, TL_L_GAMMA = TL_NSLOT * TL_SLOT, TL_L_BIAS = TL_L_GAMMA + TL_C * 4, TL_L_BPE = TL_L_BIAS + TL_C * 4;
 constexpr int TL_MAXF = 24;
@@ -132,8 +135,13 @@ void tleg320_kernel(const TlegArgs a) {
   };
   auto issue_chunk = [&](int c, int slot) {               // this wave's quarter of weight chunk c into ring slot `slot`
     char* ring = smem + TL_L_RING + slot * TL_SLOT;
-    if (c < TL_NQKV) issue_pieces(TL_IC(TL_QKV_CHUNK / 4096), c * TL_QKV_CHUNK + wid * (TL_QKV_CHUNK / 4), ring + wid * (TL_QKV_CHUNK / 4));
-    else issue_pieces(TL_IC(TL_OUT_CHUNK / 4096), TL_NQKV * TL_QKV_CHUNK + (c - TL_NQKV) * TL_OUT_CHUNK + wid * (TL_OUT_CHUNK / 4), ring + wid * (TL_OUT_CHUNK / 4));
+    const int pr = c / 6, r = c - pr * 6;                 // (c < TL_NQKV) pair, chunk of the pair: 0 .. 2 wide, 3 .. 5 narrow
+    if (c < TL_NQKV && r < 3) {
+      issue_pieces(TL_IC(TL_WIDE / 4096), pr * TL_PAIR_BYTES + r * TL_WIDE + wid * (TL_WIDE / 4), ring + wid * (TL_WIDE / 4));
+    } else {
+      const int src = c < TL_NQKV ? pr * TL_PAIR_BYTES + 3 * TL_WIDE + (r - 3) * TL_NARROW : TL_NPAIR * TL_PAIR_BYTES + (c - TL_NQKV) * TL_NARROW;
+      issue_pieces(TL_IC(TL_NARROW / 4096), src + wid * (TL_NARROW / 4), ring + wid * (TL_NARROW / 4));
+    }
   };
   auto chunk_next = [&]() {                              // the consumer moves on to the next chunk
     cur_slot = cur_slot == TL_NSLOT - 1 ? 0 : cur_slot + 1;
@@ -267,9 +275,6 @@ void tleg320_kernel(const TlegArgs a) {
 
     // ---- 2. heads
     u32x4 opk[TL_NRT][TL_NKS];                           // the attention output as B fragments of the out-projection: [row tile][k-step]
-    u32x2 c2prev[TL_NRT];                                // third channel tile of the previous (even) head, waiting for its partner
-#pragma unroll
-    for (int rt = 0; rt < TL_NRT; ++rt) c2prev[rt] = (u32x2){0u, 0u};
 
     // One chunk = ten k-steps of NF weight fragments (fragment ks NF + f of the slot).  The last k-step carries the hand-over described at the top.
     auto run_chunk = [&](auto NFc, auto&& mfmas) {
@@ -284,8 +289,8 @@ void tleg320_kernel(const TlegArgs a) {
             // this wave's pieces of the next chunk have landed: everything but the pieces of the chunk after next, the wave's youngest 8 or
             // 5 operations (the stores and residual loads of the out-projection phase are older than those)
             if (!live) wait_vmcnt<0>();
-            else if (dma_c < TL_NQKV) wait_vmcnt<TL_QKV_CHUNK / 4096>();
-            else wait_vmcnt<TL_OUT_CHUNK / 4096>();
+            else if (dma_c < TL_NQKV && (dma_c % 6) < 3) wait_vmcnt<TL_WIDE / 4096>();
+            else wait_vmcnt<TL_NARROW / 4096>();
             __builtin_amdgcn_s_waitcnt(0xC07F);                      // ... and its reads of this chunk have returned
             if constexpr (!(ABL & 128)) __builtin_amdgcn_s_barrier();
           }
@@ -311,10 +316,10 @@ void tleg320_kernel(const TlegArgs a) {
       });
       chunk_next();
     };
-    // a projection pass: acc[i][j] += W tile x row tile.  SW = false: D[ch][row] (acc[ct][rt]); SW = true: D[row][ch] (acc[rt][ct])
-    auto project = [&](auto SWc, acc4 (&acc)[3][3]) {
+    // a projection pass over NT channel tiles: acc[i][j] += W tile x row tile.  SW = false: D[ch][row] (acc[ct][rt]); SW = true: D[row][ch] (acc[rt][ct])
+    auto project = [&](auto SWc, auto NTc, acc4 (&acc)[3][3]) {
       constexpr bool SW = decltype(SWc)::value;
-      run_chunk(TL_IC(TL_NCT), [&](auto kc, auto fc) {
+      run_chunk(NTc, [&](auto kc, auto fc) {
         constexpr int ks = decltype(kc)::value, ct = decltype(fc)::value;
 #pragma unroll
           for (int rt = 0; rt < TL_NRT; ++rt) {
@@ -324,51 +329,58 @@ void tleg320_kernel(const TlegArgs a) {
           }
       });
     };
-
-    for (int h = 0; h < TL_HEADS; ++h) {
-      u32x2 kp[TL_NRT][TL_NCT], vp[TL_NRT][TL_NCT], qp[TL_NRT][TL_NCT];     // [row tile][channel tile], 4 bf16 each
+    // k / v / q of a chunk into packed tiles: t[rt][j] = channel tile j of the chunk for row tile rt
+    auto project_kvq = [&](auto NTc, u32x2 (&kt_)[TL_NRT][3], u32x2 (&vt_)[TL_NRT][3], u32x2 (&qt_)[TL_NRT][3]) {
+      constexpr int NT = decltype(NTc)::value;
       {
         acc4 acc[3][3];
-        project(std::false_type{}, acc);                 // K^T: acc[ct][rt]
+        project(std::false_type{}, NTc, acc);            // K^T: acc[ct][rt]
 #pragma unroll
         for (int rt = 0; rt < TL_NRT; ++rt)
 #pragma unroll
-          for (int ct = 0; ct < TL_NCT; ++ct) kp[rt][ct] = pack4(acc[ct][rt]);
+          for (int ct = 0; ct < NT; ++ct) kt_[rt][ct] = pack4(acc[ct][rt]);
       }
       {
         acc4 acc[3][3];
-        project(std::true_type{}, acc);                  // V: acc[rt][ct], lane = channel, registers = 4 key rows
+        project(std::true_type{}, NTc, acc);             // V: acc[rt][ct], lane = channel, registers = 4 key rows
 #pragma unroll
         for (int rt = 0; rt < TL_NRT; ++rt)
 #pragma unroll
-          for (int ct = 0; ct < TL_NCT; ++ct) vp[rt][ct] = pack4(acc[rt][ct]);
+          for (int ct = 0; ct < NT; ++ct) vt_[rt][ct] = pack4(acc[rt][ct]);
       }
       {
         acc4 acc[3][3];
-        project(std::false_type{}, acc);                 // Q^T
+        project(std::false_type{}, NTc, acc);            // Q^T
 #pragma unroll
         for (int rt = 0; rt < TL_NRT; ++rt)
 #pragma unroll
-          for (int ct = 0; ct < TL_NCT; ++ct) qp[rt][ct] = pack4(acc[ct][rt]);
+          for (int ct = 0; ct < NT; ++ct) qt_[rt][ct] = pack4(acc[ct][rt]);
       }
-      // ---- attention of head h.  S^T[key][query] per tile pair inside the pixel band; lane (lm = query, lq) holds keys 4 lq + e
-      const u32x2 z2 = (u32x2){0u, 0u};
-      u32x2 otile[TL_NRT][TL_NCT];                       // normalised O^T, packed: [query row tile][channel tile]
+    };
+    const u32x2 z2 = (u32x2){0u, 0u};
+    // Attention of one head: k / v / q tiles 0, 1 are the head's own channels 0 .. 31, tile 2 is the pair's shared tile AB2, of which the head
+    // owns the lanes lq < 2 (HI = false: head A) or lq >= 2 (HI = true: head B) -- q's other half is zeroed for the scores; O^T of tile 2 comes
+    // out whole and the caller keeps the head's lanes.  otile[query row tile][tile], normalised and packed.
+    auto attention = [&](auto HIc, const u32x2 (&kp)[TL_NRT][3], const u32x2 (&vp)[TL_NRT][3], const u32x2 (&qp)[TL_NRT][3], u32x2 (&otile)[TL_NRT][3]) {
+      constexpr bool HI = decltype(HIc)::value;
       if constexpr (ABL & 2) {
 #pragma unroll
         for (int rt = 0; rt < TL_NRT; ++rt)
 #pragma unroll
           for (int ct = 0; ct < TL_NCT; ++ct) otile[rt][ct] = (u32x2){qp[rt][ct][0] ^ kp[rt][ct][1], vp[rt][ct][0]};
-      } else
+        return;
+      }
+      const bool mine = HI ? lq >= 2 : lq < 2;
       for_range(TL_IC(0), TL_IC(TL_NRT), [&](auto qc) {
         constexpr int qt = decltype(qc)::value;
+        const u32x2 q2 = mine ? qp[qt][2] : z2;
         acc4 s[TL_NRT];
         float mx = -1e30f;
         for_range(TL_IC(0), TL_IC(TL_NRT), [&](auto kc) {
           constexpr int kt = decltype(kc)::value;
           if constexpr (tl_pair<F>(kt, qt)) {
             acc4 t = mma16(frag2(kp[kt][0], kp[kt][1]), frag2(qp[qt][0], qp[qt][1]), (acc4)(0.f));
-            t = mma16(frag2(kp[kt][2], z2), frag2(qp[qt][2], z2), t);
+            t = mma16(frag2(kp[kt][2], z2), frag2(q2, z2), t);
             if constexpr (!tl_all<F>(kt, qt)) {              // one lane condition per tile pair
               const bool ok = (tmask >> (3 * qt + kt)) & 1u;
 #pragma unroll
@@ -408,31 +420,28 @@ void tleg320_kernel(const TlegArgs a) {
           otile[qt][ct] = pack4(o * inv);
         }
       });
-      // ---- into the out-projection's operand: k-step h = [tile 0 | tile 1] of head h; the 8 valid channels of tile 2 pair up over two heads
-      // (lanes lq < 2 keep head 2 g's, lanes lq >= 2 take head 2 g + 1's lanes lq - 2) and two such pairs make k-steps 8 and 9
-      u32x2 mrg[TL_NRT];
-      if (h & 1) {
-#pragma unroll
-        for (int rt = 0; rt < TL_NRT; ++rt) {
-          const auto m0 = __builtin_amdgcn_permlane32_swap(c2prev[rt][0], otile[rt][2][0], false, false);
-          const auto m1 = __builtin_amdgcn_permlane32_swap(c2prev[rt][1], otile[rt][2][1], false, false);
-          mrg[rt] = (u32x2){m0[0], m1[0]};
-        }
-      } else {
-#pragma unroll
-        for (int rt = 0; rt < TL_NRT; ++rt) c2prev[rt] = otile[rt][2];
-      }
-      for_range(TL_IC(0), TL_IC(TL_HEADS), [&](auto hc) {
-        constexpr int hh = decltype(hc)::value;
-        if (h == hh) {
+    };
+
+    for (int g = 0; g < TL_NPAIR; ++g) {
+      u32x2 kp[TL_NRT][3], vp[TL_NRT][3], qp[TL_NRT][3];     // [row tile][tile]: A0, A1, AB2; later B0, B1 (AB2 stays)
+      u32x2 oa[TL_NRT][3], ob[TL_NRT][3];
+      project_kvq(TL_IC(3), kp, vp, qp);
+      attention(std::false_type{}, kp, vp, qp, oa);          // head A = 2 g
+      project_kvq(TL_IC(2), kp, vp, qp);                     // tiles 0, 1 <- B0, B1
+      attention(std::true_type{}, kp, vp, qp, ob);           // head B = 2 g + 1
+      // into the out-projection's operand: k-step 2 g = [A0 | A1], 2 g + 1 = [B0 | B1]; AB2 (lanes lq < 2: head A's channels 32 .. 39, lq >= 2:
+      // head B's) is half of k-step 8 + g / 2
+      for_range(TL_IC(0), TL_IC(TL_NPAIR), [&](auto gc) {
+        constexpr int gg = decltype(gc)::value;
+        if (g == gg) {
 #pragma unroll
           for (int rt = 0; rt < TL_NRT; ++rt) {
-            opk[rt][hh] = (u32x4){otile[rt][0][0], otile[rt][0][1], otile[rt][1][0], otile[rt][1][1]};
-            if constexpr (hh & 1) {
-              constexpr int ks = 8 + hh / 4;
-              if constexpr ((hh >> 1) & 1) { opk[rt][ks][2] = mrg[rt][0]; opk[rt][ks][3] = mrg[rt][1]; }
-              else { opk[rt][ks][0] = mrg[rt][0]; opk[rt][ks][1] = mrg[rt][1]; }
-            }
+            opk[rt][2 * gg] = (u32x4){oa[rt][0][0], oa[rt][0][1], oa[rt][1][0], oa[rt][1][1]};
+            opk[rt][2 * gg + 1] = (u32x4){ob[rt][0][0], ob[rt][0][1], ob[rt][1][0], ob[rt][1][1]};
+            const u32x2 m = lq < 2 ? oa[rt][2] : ob[rt][2];
+            constexpr int ks = 8 + gg / 2;
+            if constexpr (gg & 1) { opk[rt][ks][2] = m[0]; opk[rt][ks][3] = m[1]; }
+            else { opk[rt][ks][0] = m[0]; opk[rt][ks][1] = m[1]; }
           }
         }
       });

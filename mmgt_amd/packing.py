@@ -119,14 +119,14 @@ TLEG_HEADS, TLEG_HD, TLEG_C = 8, 40, 320
 def pack_tleg(wq, wk, wv, wo):
     """The four (320, 320) weights of a level-0 temporal attention (motion_module.py:294-330 to_q / to_k / to_v / to_out.0) -> the fragment-major
     image of csrc/tleg.hip (mmgt_temporal_leg320), a uint8 tensor.  Fragments are 1 KiB for v_mfma_f32_16x16x32_bf16: lane l = (lm = l & 15,
-    lq = l >> 4) owns bytes 16 l .. 16 l + 15 = 8 bf16.
-      24 chunks of 30 KiB (+ 2 KiB of zeros), head h = 0 .. 7 x (k, v, q):  [k-step ks = 0 .. 9][channel tile ct = 0 .. 2]  W[40 h + 16 ct + lm][32 ks + 8 lq + j],
-                                                         zero for 16 ct + lm >= 40 (a head is padded to 48 channels)
-      10 chunks of 20 KiB, output columns 32 oc .. + 31:  [ks = 0 .. 9][nt = 0, 1]  Wo[32 oc + 16 nt + lm][ch(ks, lq, j)] with the reduction in
-                                                         the order the kernel packs the attention output: k-step h < 8 = channels 4 lq + j (j < 4)
-                                                         and 16 + 4 lq + j - 4 (j >= 4) of head h; k-steps 8 + g = the channels 32 .. 39 of heads
-                                                         4 g .. 4 g + 3: j < 4: head 4 g (lq < 2) / 4 g + 1 (lq >= 2), j >= 4: heads 4 g + 2 / 4 g + 3,
-                                                         channel 32 + 4 (lq & 1) + (j & 3)"""
+    lq = l >> 4) owns bytes 16 l .. 16 l + 15 = 8 bf16  W[row(lm)][32 ks + 8 lq + j].
+    Heads come in pairs (A, B) = (2 g, 2 g + 1) whose 80 output channels form five 16-row tiles A0 A1 AB2 B0 B1: A0 / A1 / B0 / B1 = the head's
+    channels 0 .. 15 / 16 .. 31, AB2 = [A's channels 32 .. 39 | B's channels 32 .. 39].  Per pair, for W in (k, v, q): a "wide" chunk
+    [ks = 0 .. 9][A0, A1, AB2] (30 KiB + 2 KiB of zeros), then for W in (k, v, q): a "narrow" chunk [ks][B0, B1] (20 KiB).  Then 10 narrow chunks
+    of the out-projection, output columns 32 oc .. + 31:  [ks][nt = 0, 1]  Wo[32 oc + 16 nt + lm][ch(ks, lq, j)] with the reduction in the order
+    the kernel packs the attention output: k-step h < 8 = channels 4 lq + j (j < 4) and 16 + 4 lq + j - 4 (j >= 4) of head h; k-steps 8 + u =
+    the channels 32 .. 39 of heads 4 u .. 4 u + 3: j < 4: head 4 u (lq < 2) / 4 u + 1 (lq >= 2), j >= 4: heads 4 u + 2 / 4 u + 3, channel
+    32 + 4 (lq & 1) + (j & 3)."""
     H, HD, C = TLEG_HEADS, TLEG_HD, TLEG_C
     for w in (wq, wk, wv, wo):
         assert tuple(w.shape) == (C, C)
@@ -137,25 +137,28 @@ def pack_tleg(wq, wk, wv, wo):
     ks = torch.arange(C // 32, device=dev)
     cols = 32 * ks[:, None, None] + 8 * lq[None, :, None] + j[None, None, :]                       # (ks, lane, j)
     chunks = []
-    ct = torch.arange(3, device=dev)
-    loc = 16 * ct[:, None] + lm[None, :]                                                           # (ct, lane): channel inside the head
-    valid = (loc < HD)
-    for h in range(H):
-        rows = (HD * h + loc).clamp(max=C - 1)                                                     # (ct, lane)
-        for w in (wk, wv, wq):
-            wb = w.to(torch.bfloat16)
-            img = wb[rows[None, :, :, None], cols[:, None, :, :]]                                  # (ks, ct, lane, j)
-            img = torch.where(valid[None, :, :, None], img, torch.zeros((), device=dev, dtype=torch.bfloat16))
-            chunks.append(img.contiguous().view(torch.uint8).reshape(-1))
+    bf = [w.to(torch.bfloat16) for w in (wk, wv, wq)]
+
+    def frags(w, rows):                                                                            # rows (tiles, lane) -> (ks, tiles, lane, j) bytes
+        return w[rows[None, :, :, None], cols[:, None, :, :]].contiguous().view(torch.uint8).reshape(-1)
+
+    for g in range(H // 2):
+        a0, b0 = HD * 2 * g, HD * (2 * g + 1)
+        wide = torch.stack([a0 + lm, a0 + 16 + lm, torch.where(lm < 8, a0 + 32 + lm, b0 + 32 + lm - 8)])      # (3, lane)
+        narrow = torch.stack([b0 + lm, b0 + 16 + lm])                                                      # (2, lane)
+        for w in bf:
+            chunks.append(frags(w, wide))
             chunks.append(torch.zeros(2048, device=dev, dtype=torch.uint8))                        # padded to 32 KiB: 8 whole DMA pieces per wave
+        for w in bf:
+            chunks.append(frags(w, narrow))
     # out-projection: channel of reduction slot (ks, lq, j)
     ch = torch.empty((C // 32, 64, 8), device=dev, dtype=torch.long)
     jj, lqq = j[None, :], lq[:, None]
     for k in range(H):
         ch[k] = HD * k + torch.where(jj < 4, 4 * lqq + jj, 16 + 4 * lqq + jj - 4)
-    for g in range(2):
-        head = 4 * g + torch.where(jj < 4, 0, 2) + (lqq >= 2).long()
-        ch[8 + g] = HD * head + 32 + 4 * (lqq & 1) + (jj & 3)
+    for u in range(2):
+        head = 4 * u + torch.where(jj < 4, 0, 2) + (lqq >= 2).long()
+        ch[8 + u] = HD * head + 32 + 4 * (lqq & 1) + (jj & 3)
     wob = wo.to(torch.bfloat16)
     nt = torch.arange(2, device=dev)
     for oc in range(C // 32):
@@ -163,5 +166,5 @@ def pack_tleg(wq, wk, wv, wo):
         img = wob[rows[None, :, :, None], ch[:, None, :, :]]                                       # (ks, nt, lane, j)
         chunks.append(img.contiguous().view(torch.uint8).reshape(-1))
     out = torch.cat(chunks)
-    assert out.numel() == 24 * 32768 + 10 * 20480
+    assert out.numel() == 4 * (3 * 32768 + 3 * 20480) + 10 * 20480
     return out

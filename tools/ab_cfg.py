@@ -93,6 +93,9 @@ SETS = {
     "quant": lambda: [gemm_case(12288, 1280, 1280, res=True), gemm_case(12288, 1280, 5120, res=True), gemm_case(12288, 1280, 1280),
                       gemm_case(49152, 640, 640, res=True), gemm_case(49152, 640, 2560, res=True), gemm_case(49152, 640, 640),
                       gemm_case(12288, 2560, 1280), gemm_case(49152, 1280, 640)],
+    # conv against the dense GEMM of the same M x N x K (what the gather itself costs)
+    "convdense": lambda: [conv_case(48, 64, 320, 320), gemm_case(196608, 320, 2880), conv_case(48, 64, 640, 320), gemm_case(196608, 320, 5760),
+                          conv_case(48, 32, 640, 640), gemm_case(49152, 640, 5760), conv_case(48, 16, 1280, 1280), gemm_case(12288, 1280, 11520)],
     # round 5: candidates of the 192 x 320 tile (cfg 19) at 24 and 12 frames
     "bm192": lambda: [gemm_case(49152, 640, 640, res=True), gemm_case(49152, 640, 2560, res=True), gemm_case(49152, 640, 640), gemm_case(49152, 640, 1280),
                       gemm_case(49152, 640, 320, res=True), gemm_case(12288, 1280, 1280, res=True), gemm_case(12288, 1280, 5120, res=True),
