@@ -39,21 +39,23 @@ extern "C" {
 int mmgt_abi_version(void);
 const char* mmgt_last_error(void);
 /* Benchmark-only knobs (A/B measurements and tests; the defaults are the product):
- *   "gemm_cfg" = 0 (heuristic tile choice) or 1, 3, 6, 9, 12, 16, 17, 19 (force a GEMM / conv tile configuration; 19 = gemm16's 192 x 320 tile);
+ *   "gemm_cfg" = 0 (heuristic tile choice) or 1, 3, 6, 9, 12, 16, 17, 19, 20 (force a GEMM / conv tile configuration; 19 = gemm16's 192 x 320 tile,
+ *                20 = its 256 x 128 tile: measured slower than the 128 x 128 tile everywhere, kept for the record);
  *   "bm192"    = 1 (default) / 0: the 192-row gemm16 tile for shapes whose 256-row tile count leaves the last round of the grid half empty;
  *   "attn64"   = 1 (default) / 0: the 64-queries-per-wave spatial attention kernel at head_dim 40;
  *   "gn_rows"  = 0 (default: measured choice) or the GroupNorm rows per workgroup;
  *   "splitk"   = 1 (default) / 0: split-K of long reductions on grids of at most half a tile per CU (the 8x8-level convs);
  *   "ffn_dbg"  = 0 (default) .. 2: ablation builds of mmgt_ff_fused (timing only, results are garbage for v > 0).
  *   "tleg_abl" = 0 (default) or a bit of csrc/tleg.hip's ABL list: timing ablations of mmgt_temporal_leg320 at 24 frames (results are garbage).
+ *   "gnconv_abl" = 0 (default) or a value of csrc/gnconv.hip's ABL list: timing ablations of mmgt_gn_silu_conv3x3 without residual (results are garbage).
  *   "tailsplit" = 1 (default) / 0: convs whose tile count leaves the last round of the persistent grid half empty run that round's rows
  *               as a second launch with the reduction split in two (A/B switch).
  * One kernel per family ships: the measured-slower variants of earlier rounds (gemm16s / gemm16v, the phased and register-staged
  * head_dim-40 attention kernels, the producer / consumer FeedForward) are records under tools/micro/. */
 int mmgt_tune(const char* key, int value);
 /* Host-side switches kept in the same table (what mmgt_amd/unet3d.py, pipeline.py and smga.py consult; all default 1, 0 = the
- * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "tleg", "zero_audio_skip",
- * "window_state", "smga_graph".  mmgt_tune sets them, mmgt_tune_get reads them: one state describes a run. */
+ * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "tleg", "gnconv" (mmgt_amd/vae.py),
+ * "zero_audio_skip", "window_state", "smga_graph".  mmgt_tune sets them, mmgt_tune_get reads them: one state describes a run. */
 int mmgt_tune_get(const char* key, int* value);
 /* Box calibration for bench.py's `box_calib` (csrc/calib.hip): a bare v_mfma_f32_16x16x32_bf16 loop on random operands, one wave per SIMD,
  * launched back to back for `warm_seconds` (0 .. 10); *mfma_mhz = the in-kernel clock of the last launch (delta s_memtime / delta
@@ -276,6 +278,16 @@ int mmgt_smga_ddim_step(const void* pred_uncond, const void* pred_cond, const fl
 long mmgt_temporal_leg320_image_bytes(void);
 int mmgt_temporal_leg320(const void* x, void* out, const float* ln_gamma, const float* beta_pe, int pe_rows, const void* wimg, const float* bias_o,
                          int batch, int frames, int n_pix, float scale, float eps, int dtype, void* stream);
+
+/* GroupNorm + SiLU + conv3x3 (stride 1, padding 1) in one launch for the VAE's 128-channel levels (csrc/gnconv.hip; diffusers `ResnetBlock2D.forward`
+ * norm -> nonlinearity -> conv as `AutoencoderKL.decode` runs it for src/pipelines/pipeline_pose2vid_long.py:112-125):
+ *   out = bias + conv3x3( silu( x * scale[n, c] + shift[n, c] ) ) (+ residual)
+ * x / residual / out (nb, H, W, 128) bf16 channels-last, H and W multiples of 16, x smaller than 2 GiB; scale / shift (nb, 128) fp32 = the tables of
+ * mmgt_groupnorm_affine; wimg = packing.pack_gnconv(W) (mmgt_gn_silu_conv3x3_image_bytes(128, 128) bytes); bias (128) fp32 or null; residual or null.
+ * bf16, Cin = Cout = 128 only: everything else runs mmgt_groupnorm -> mmgt_conv3x3. */
+long mmgt_gn_silu_conv3x3_image_bytes(int cin, int cout);
+int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const float* shift, const void* wimg, const float* bias, const void* residual, void* out,
+                         int nb, int H, int W, int cin, int cout, int dtype, void* stream);
 
 /* ---- conditioning producers and the output path on the device; uint8 image buffers are device pointers.
  * blur_mask: (frames, H, W) u8 -> (frames, 64, 64) u8 = cv2.resize(64x64, bilinear) -> cv2.GaussianBlur(ksize, sigma from ksize,

@@ -738,7 +738,7 @@ int launch_cfg(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, i
 
 int g_splitk = 1;     // mmgt_tune("splitk", 0 / 1): A/B switch of the split-K path
 int g_tailsplit = 1;  // mmgt_tune("tailsplit", 0 / 1): A/B switch of the tail split (below)
-int g_gemm_cfg = 0;   // 0 = heuristic; 1, 3, 6, 9, 12, 16, 17, 19 force a tile configuration (mmgt_tune("gemm_cfg", v), benchmarking only)
+int g_gemm_cfg = 0;   // 0 = heuristic; 1, 3, 6, 9, 12, 16, 17, 19, 20 force a tile configuration (mmgt_tune("gemm_cfg", v), benchmarking only)
 int g_bm192 = 1;      // mmgt_tune("bm192", 0 / 1): A/B switch of the 192-row gemm16 tile
 
 }  // namespace
@@ -863,6 +863,11 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     }
     cfg = cfg == 16 ? 9 : geglu ? 1 : 12;   // (GEGLU pairs need 64-column wave tiles: not the 320-column tile)
   }
+  if (cfg == 20) {   // gemm16.hip's 256 x 128 tile (round 5): the VAE's 128-wide levels
+    if (std::is_same<T, bf16_t>::value && ep.fast && ep.act == 0 && (((uintptr_t)ep.bias | (uintptr_t)ep.bias2 | (uintptr_t)ep.bias_post) & 15) == 0 && N % 4 == 0)
+      return mmgt_gemm16_launch(MODE, 128, &ad, W, bsw, &ep, M, N, K, batch, s);
+    cfg = 1;
+  }
   // anything beyond bias / per-batch bias / GEGLU / residual on the vectorised path runs the FULL instantiation (128x128 tile)
   if (!ep.fast || ep.act >= 2) return launch_cfg<T, MODE, 128, 128, 2, 2, 2, 128, 2>(ad, W, bsw, ep, M, N, K, batch, s);
   if (ep.row_scale || ep.alpha != 1.f || ep.bias_post) {
@@ -923,6 +928,7 @@ void mmgt_gn_set_narrow(int v);
 void mmgt_ffn_set_dbg(int v);
 void mmgt_rowgemm_set_dbg(int v);
 void mmgt_tleg_set_abl(int v);
+void mmgt_gnconv_set_abl(int v);
 // Switches of the HOST side of the operator (mmgt_amd/unet3d.py, pipeline.py, smga.py read them through mmgt_tune_get): they live here,
 // beside the kernel knobs, so that ONE state -- this table -- describes what a run executed (MMGT_TUNE="twin_attention=0,splitk=0").
 namespace {
@@ -934,6 +940,7 @@ HostSwitch g_host[] = {
     {"oz3", 1},              // the three masked audio out-projections as one GEMM
     {"rowgemm", 1},          // row-stationary LayerNorm / GroupNorm -> projection launches
     {"tleg", 1},             // a level-0 temporal-attention leg as one launch (csrc/tleg.hip)
+    {"gnconv", 1},           // the VAE's GroupNorm + SiLU + conv3x3 128 -> 128 as a statistics pass + one launch (csrc/gnconv.hip)
     {"zero_audio_skip", 1},  // skip the audio cross-attention of an all-zero (unconditional) audio row
     {"window_state", 1},     // keep what a window's audio / masks determine across the steps of a clip
     {"smga_graph", 1},       // replay the SMGA sampler loop as a HIP graph
@@ -962,6 +969,7 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "bm192")) { g_bm192 = value; return 0; }
   if (key && !strcmp(key, "tailsplit")) { g_tailsplit = value; return 0; }
   if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 2) { mmgt_ffn_set_dbg(value); return 0; }
+  if (key && !strcmp(key, "gnconv_abl") && value >= 0 && value <= 255) { mmgt_gnconv_set_abl(value); return 0; }
   if (key && !strcmp(key, "tleg_abl") && value >= 0 && value <= 128) { mmgt_tleg_set_abl(value); return 0; }
   if (key && !strcmp(key, "rowgemm_dbg") && value >= 0 && value <= 5) { mmgt_rowgemm_set_dbg(value); return 0; }
   mmgt_set_error("tune: unknown key");

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
                                                         int K, int tiles_m, int tiles_n, int pb, unsigned long long* trace) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   typedef bf16_t T;
-  static_assert(BN == 256 || BN == 320, "BN");
+  static_assert(BN == 128 || BN == 256 || BN == 320, "BN");
   static_assert(BM == 256 || BM == 192, "BM");
   constexpr int ESZ = 2, ROWB = 128, BK = 64, NW = 8;
   constexpr int WROWS = BM / 4, RT = WROWS / 16;   // rows and 16-row tiles per wave
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
   constexpr int CPR = 8, RPD = 8;               // 16-byte chunks per row; rows per 1-KiB DMA piece
   constexpr int GA = BM / RPD / NW, GB = BN / RPD / NW;   // pieces per wave and chunk: 4 x A + 4 or 5 x W
   constexpr int NPH = BN / 64, NT = BN / 32;    // phases per chunk; accumulator tiles per row tile
-  constexpr int BIAS_OFF = 2 * STAGE_BYTES, BIAS_ARR = 2048, NBP = BN == 256 ? 1 : 2;   // bias | bias2 row 0 | bias2 row 1 | post-scale bias: 512 floats each, NBP pieces
+  constexpr int BIAS_OFF = 2 * STAGE_BYTES, BIAS_ARR = 2048, NBP = BN == 320 ? 2 : 1;   // bias | bias2 row 0 | bias2 row 1 | post-scale bias: 512 floats each, NBP pieces
   auto swz = [](int row) { return (row >> 1) & 7; };
 
   const int nwg = tiles_m * tiles_n;
@@ -353,8 +353,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
           }
         }
         if (P == 1 && ch == 0 && wr == 0 && (ep.bias_post || (has_bias && vt + G < nwg))) issue_bias(has_bias && vt + G < nwg ? vt + G : -1, vt);
-        for_n(integral_constant<int, 2>{}, [&](auto Uc) {     // pieces 2 P, 2 P + 1 of [W 0 .. W GB-1 | A 0 .. A GA-1]
-          constexpr int S = 2 * P + decltype(Uc)::value;
+        // pieces 2 P, 2 P + 1 of [W 0 .. W GB-1 | A 0 .. A GA-1].  BN = 128 has two phases for its 2 + GA pieces: the W pieces in phase 0, ALL
+        // A pieces in phase 1 -- an A piece lands in the stage the current chunk is multiplied from, whose A half group 1 reads one barrier
+        // after group 0's phase-0 load part, so phase 1 is the first that may overwrite it.
+        constexpr int PLO = BN == 128 ? (P == 0 ? 0 : GB) : 2 * P, PN = BN == 128 ? (P == 0 ? GB : GA) : 2;
+        for_n(integral_constant<int, PN>{}, [&](auto Uc) {
+          constexpr int S = PLO + decltype(Uc)::value;
           if constexpr (S < GB) {
             if (moreW) issueW(stW, chW, integral_constant<int, S>{});
             if constexpr (S == GB - 1) { if (moreW) advanceW(); }
@@ -721,5 +725,6 @@ int mmgt_gemm16_launch(int mode, int bn, const void* adp, const void* W, long bs
   hipStream_t s = (hipStream_t)stream;
   if (bn == 192320) return mode == 0 ? launch16<0, 320, 192>(ad, W, bsw, ep, M, N, K, batch, s) : launch16<1, 320, 192>(ad, W, bsw, ep, M, N, K, batch, s);   // 192 x 320 tile
   if (bn == 320) return mode == 0 ? launch16<0, 320>(ad, W, bsw, ep, M, N, K, batch, s) : launch16<1, 320>(ad, W, bsw, ep, M, N, K, batch, s);
+  if (bn == 128) return mode == 0 ? launch16<0, 128>(ad, W, bsw, ep, M, N, K, batch, s) : launch16<1, 128>(ad, W, bsw, ep, M, N, K, batch, s);   // 256 x 128 tile (the VAE's 128-wide levels)
   return mode == 0 ? launch16<0, 256>(ad, W, bsw, ep, M, N, K, batch, s) : launch16<1, 256>(ad, W, bsw, ep, M, N, K, batch, s);
 }

@@ -1,0 +1,415 @@
+// GroupNorm + SiLU + conv3x3 in ONE launch for the VAE's 128-channel levels (bf16, Cin = 128, Cout = 128, stride 1, padding 1, gfx950):
+//
+//   out[n, y, x, :] = bias + sum_{ky, kx} W[ky, kx] . silu( x[n, y + ky - 1, x + kx - 1, :] * scale[n, :] + shift[n, :] )   (+ residual)
+//
+// with (scale, shift) the per-(image, channel) tables of mmgt_groupnorm_affine (the statistics pass of GroupNorm alone).  Replaces the
+// `hip.groupnorm(silu=True)` -> `hip.conv3x3` pair of mmgt_amd/vae.py::_resnet / decode_nhwc at decoder.up_blocks.3 and conv_norm_out
+// (reference: diffusers `ResnetBlock2D.forward` = norm -> nonlinearity -> conv as called by `AutoencoderKL.decode` from
+// src/pipelines/pipeline_pose2vid_long.py:112-125).  At 8 x 512 x 512 x 128 the pair cost 307 us (GroupNorm: 537 MB read twice, written once)
+// + 735 us (implicit-GEMM conv on the 128 x 128 tile: with only 128 output columns the gathered A operand is staged 9 times per tile and
+// is 2/3 of the L2 -> LDS traffic, 64 FLOP per staged byte).
+//
+// Here a workgroup owns a 16 x 16 pixel tile of one image.  Its 18 x 18 x 128 halo is read ONCE from HBM into registers, normalised, SiLU'd,
+// rounded to bf16 (the rounding point of the unfused pair) and written to LDS (pixel-major, 272-byte pixel stride: the 16 lanes of a
+// ds_read_b128 group then fall on 15 different 16-byte bank slots); out-of-image pixels are zeros AFTER the activation, as the conv's padding
+// wants.  The nine taps' A fragments (v_mfma_f32_16x16x32_bf16: lane (lm, lq) = pixel lm of an image row, channels 32 ks + 8 lq .. + 7) are
+// read straight from the halo with compile-time offsets -- no im2col staging at all.  The weights, a fragment-major image of 18 half-taps of
+// 16 KiB (mmgt_amd/packing.py::pack_gnconv), stream through a 4-slot LDS ring by LDS-DMA three half-taps ahead, ONE barrier per half-tap
+// (32 MFMAs per wave) placed between its two k-steps; the stream runs across tile boundaries (203 FLOP per staged byte).
+// 8 waves = 4 (rows) x 2 (columns): a wave owns 4 image rows x 16 pixels x 64 output channels = 4 x 4 accumulator tiles.
+// The halo of the NEXT tile is requested during half-tap 2 and normalised a vector per half-tap in the shadow of the MFMAs, so a tile
+// boundary costs the epilogue, two barriers and the LDS writes.
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "gemm_common.h"
+#include "mmgt_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float acc4;
+
+constexpr int GC_CIN = 128, GC_COUT = 128, GC_T = 16, GC_HP = GC_T + 2;     // tile edge, halo edge
+constexpr int GC_PSTR = GC_CIN * 2 + 16;                                    // bytes per halo pixel in LDS
+constexpr int GC_HALO = GC_HP * GC_HP * GC_PSTR;                            // 88 128
+constexpr int GC_NV = GC_HP * GC_HP * (GC_CIN / 8);                         // 16-byte vectors of a halo: 5184 = 10 x 512 + 64
+constexpr int GC_NVL = (GC_NV + 511) / 512;                                 // vectors per lane (the 11th: lanes 0 .. 63 only)
+constexpr int GC_SLOT = 16 * 1024, GC_NSLOT = 4, GC_NSTEP = 18;             // half-taps: 64 input channels x 128 output channels
+constexpr int GC_L_RING = (GC_HALO + 1023) / 1024 * 1024, GC_L_BIAS = GC_L_RING + GC_NSLOT * GC_SLOT, GC_L_TAB = GC_L_BIAS + GC_COUT * 4, GC_LDS = GC_L_TAB + 2 * GC_CIN * 4;
+constexpr int GC_PPW = GC_SLOT / 1024 / 8;                                  // DMA pieces per wave and half-tap (2)
+static_assert(GC_LDS <= 160 * 1024 && 6 + GC_NVL <= GC_NSTEP, "LDS / schedule");
+
+struct GcArgs {
+  const bf16_t* x;       // (nb, H, W, 128)
+  const float* scale;    // (nb, 128)
+  const float* shift;    // (nb, 128)
+  const char* wimg;      // pack_gnconv image (18 x 16 KiB)
+  const float* bias;     // (128) or null
+  const bf16_t* res;     // (nb, H, W, 128) or null
+  bf16_t* out;           // (nb, H, W, 128)
+  int nb, H, W, tiles_x, tiles_per_img, ntiles;
+};
+
+__device__ __forceinline__ acc4 gc_mma(s16x8 a, s16x8 b, acc4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float gc_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float gc_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+template <int LO, int... I, typename F>
+__device__ __forceinline__ void gc_for_impl(std::integer_sequence<int, I...>, F&& fn) { (fn(std::integral_constant<int, LO + I>{}), ...); }
+template <int LO, int HI, typename F>
+__device__ __forceinline__ void gc_for(F&& fn) { gc_for_impl<LO>(std::make_integer_sequence<int, (HI > LO ? HI - LO : 0)>{}, static_cast<F&&>(fn)); }
+
+// ABL (mmgt_tune("gnconv_abl", bit), timing only -- results are garbage): 1 no MFMAs, 2 no weight DMA after the prologue, 4 no halo loads /
+// normalisation / LDS writes after the first tile, 8 no hand-over wait, 16 no epilogue (residual loads, stores), 32 no hand-over barrier,
+// 64 halo loads but no normalisation / LDS writes, 128 normalisation / LDS writes but no halo loads
+template <bool RES, int ABL>
+__global__ __launch_bounds__(512, 2) void gnconv128_kernel(const GcArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lm = lane & 15, lq = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;                   // 4 x 2 wave grid: image rows 4 wm .. 4 wm + 3 of the tile, output channels 64 wn .. + 63
+  const int G = gridDim.x;
+  const int my_tiles = (a.ntiles - (int)blockIdx.x + G - 1) / G;
+  const int total = my_tiles * GC_NSTEP;                   // half-taps this workgroup consumes
+
+  // XCD-aware tile order (gemm.hip): XCD x = v & 7 walks a contiguous run of the tile sequence, so horizontally adjacent tiles -- which share
+  // two halo columns -- are worked on one L2 at about the same time
+  auto decode = [&](int v, int& n, int& ty, int& tx) {
+    const int q = a.ntiles >> 3, r = a.ntiles & 7, xc = v & 7;
+    const int t = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (v >> 3);
+    n = t / a.tiles_per_img;
+    const int rem = t - n * a.tiles_per_img;
+    ty = rem / a.tiles_x;
+    tx = rem - ty * a.tiles_x;
+  };
+
+  // ---- weight stream: half-tap g (counted over the workgroup's tiles) is image chunk g % 18 and lives in ring slot g % 4
+  const __amdgpu_buffer_rsrc_t rW = dma_rsrc(a.wimg);
+  const unsigned w_voff = (unsigned)(lane * 16 + wid * GC_PPW * 1024);
+  // Beyond the last half-tap the pieces still go out, against the poison offset (zeros into a slot nobody reads): every wait count below is
+  // then a compile-time constant on every path, and hipcc's own waits for the halo registers see the same number of younger operations
+  // whether or not the stream has ended (with conditional pieces it assumed none and waited for the newest pieces at every use).
+  auto issue_w = [&](int g) {
+    const int chunk = g % GC_NSTEP, slot = g & (GC_NSLOT - 1);
+    const unsigned vo = g < total ? w_voff : DMA_POISON;
+#pragma unroll
+    for (int u = 0; u < GC_PPW; ++u)
+      blds16(rW, vo, chunk * GC_SLOT + u * 1024, smem + GC_L_RING + slot * GC_SLOT + (wid * GC_PPW + u) * 1024);
+  };
+
+  // ---- halo: vector v = tid + 512 i is pixel p = v >> 4 (row-major over the 18 x 18 halo), channel octet o = tid & 15
+  const __amdgpu_buffer_rsrc_t rX = dma_rsrc(a.x), rO = dma_rsrc(a.out), rR = dma_rsrc(a.res ? a.res : a.x);
+  const int oct = tid & 15;
+  u32x4 hv[GC_NVL];
+  unsigned hmask = 0;                                      // bit i: vector i lies inside the image
+  // scale | shift of the image of the halo in flight: requested with the halo by wave 0 (one 16-byte vector per lane = the 256 floats), put into
+  // LDS once it has landed (half-tap 5), read from there by every lane for its 8 channels
+  u32x4 tabv = (u32x4)(0u);
+  int iter_ = 0;
+  auto load_halo = [&](int v) {
+    int n, ty, tx;
+    decode(v, n, ty, tx);
+    {
+      const float* pt = (lane < 32 ? a.scale : a.shift) + (long)n * GC_CIN + (lane & 31) * 4;
+      tabv = wid == 0 ? *reinterpret_cast<const u32x4*>(pt) : tabv;
+    }
+    hmask = 0;
+    int p0 = tid >> 4, o16 = oct * 16;
+    asm volatile("" : "+v"(p0), "+v"(o16));                 // opaque: the per-vector coordinates are recomputed here, not kept in 30 registers across the tile
+#pragma unroll
+    for (int i = 0; i < GC_NVL; ++i) {
+      const int p = p0 + 32 * i;
+      const int hy = (p * 3641) >> 16, hx = p - GC_HP * hy;               // p / 18, exact for p < 3 000
+      const int y = ty * GC_T - 1 + hy, x = tx * GC_T - 1 + hx;
+      const bool ok = p < GC_HP * GC_HP && y >= 0 && y < a.H && x >= 0 && x < a.W;
+      const unsigned off = (unsigned)(((n * a.H + y) * a.W + x) * (GC_CIN * 2) + o16);
+      if (!(ABL & 128) || iter_ == 0) hv[i] = __builtin_amdgcn_raw_buffer_load_b128(rX, (int)(ok ? off : DMA_POISON), 0, 0);
+      hmask |= ok ? 1u << i : 0u;
+    }
+  };
+  auto write_tab = [&]() {
+    if (wid == 0) *reinterpret_cast<u32x4*>(smem + GC_L_TAB + lane * 16) = tabv;
+  };
+  // dwords J0 .. J0 + NJ - 1 of hv[I] <- bf16( silu( . * scale + shift ) ), zeros outside the image.  Branch-free (a select on the mask made hipcc
+  // branch around the transcendentals, one basic block per pair, nothing interleaved with the MFMAs)
+  auto norm_part = [&](auto Ic, auto Jc, auto Nc) {
+    constexpr int I = decltype(Ic)::value, J0 = decltype(Jc)::value, NJ = decltype(Nc)::value;
+    static_assert(J0 % 2 == 0 && NJ % 2 == 0, "pairs of dwords");
+    const unsigned m = 0u - ((hmask >> I) & 1u);
+    int tofs = GC_L_TAB + 32 * oct;
+    asm volatile("" : "+v"(tofs));                          // opaque: the table is re-read per call (4 ds_read_b128 per vector) instead of living in 16 registers
+#pragma unroll
+    for (int jj = J0; jj < J0 + NJ; jj += 2) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(smem + tofs + 8 * jj), sh = *reinterpret_cast<const f32x4*>(smem + tofs + GC_CIN * 4 + 8 * jj);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int j = jj + u;
+        // silu(t) = t / (1 + e^-t) with v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE division sequence, packed arithmetic around them:
+        // 12 instructions per pair of elements.  They share the SIMD's vector issue with the MFMAs (an MFMA holds it 8 of its 16 cycles).
+        const f32x2 xin = {gc_lo(hv[I][j]), gc_hi(hv[I][j])};
+        const f32x2 t = __builtin_elementwise_fma(xin, (f32x2){sc[2 * u], sc[2 * u + 1]}, (f32x2){sh[2 * u], sh[2 * u + 1]});
+        const f32x2 ue = t * (f32x2){-1.4426950408889634f, -1.4426950408889634f};
+        const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(ue[0]), __builtin_amdgcn_exp2f(ue[1])} + (f32x2){1.f, 1.f};
+        const f32x2 v = t * (f32x2){__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+        const float v0 = v[0], v1 = v[1];
+        unsigned pk = pack_bf16x2(v0, v1) & m;
+        asm volatile("" : "+v"(pk));                        // pinned here: hipcc otherwise sinks the arithmetic to the tile's end, where hv is stored
+        hv[I][j] = pk;
+      }
+    }
+  };
+  auto norm_vec = [&](auto Ic) { norm_part(Ic, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); };
+  const int h_wbase = (tid >> 4) * GC_PSTR + oct * 16;
+  auto write_halo = [&]() {
+#pragma unroll
+    for (int i = 0; i < GC_NVL; ++i)
+      if (i + 1 < GC_NVL || tid < GC_NV - 512 * (GC_NVL - 1))
+        *reinterpret_cast<u32x4*>(smem + h_wbase + i * 32 * GC_PSTR) = hv[i];
+  };
+
+  // ---- fragment addressing
+  const int a_base = (4 * wm * GC_HP + lm) * GC_PSTR + lq * 16;          // + ((i + ky) 18 + kx) 272 + 128 kh + 64 ks2: compile-time
+  const int w_base = GC_L_RING + wn * 4 * 1024 + lane * 16;              // + slot 16 KiB + (8 ks2 + j) 1 KiB
+  s16x8 fa[2][4], fw[2][4];
+  auto read_a = [&](auto Sc, auto Kc, s16x8 (&f)[4]) {
+    constexpr int S = decltype(Sc)::value, KS2 = decltype(Kc)::value, tap = S / 2, kh = S & 1, ky = tap / 3, kx = tap % 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      f[i] = *reinterpret_cast<const s16x8*>(smem + a_base + ((i + ky) * GC_HP + kx) * GC_PSTR + kh * 128 + KS2 * 64);
+  };
+  auto read_w = [&](int slot, auto Kc, s16x8 (&f)[4]) {
+    constexpr int KS2 = decltype(Kc)::value;
+    const char* p = smem + w_base + slot * GC_SLOT + KS2 * 8 * 1024;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = *reinterpret_cast<const s16x8*>(p + j * 1024);
+  };
+
+  // ---- prologue: bias -> LDS, the first three half-taps, the first halo
+  if (tid < GC_COUT) reinterpret_cast<float*>(smem + GC_L_BIAS)[tid] = a.bias ? a.bias[tid] : 0.f;
+  int gstep = 0;                                           // half-taps consumed so far
+  if (my_tiles > 0) {
+    load_halo(blockIdx.x);
+    for (int g = 0; g < GC_NSLOT - 1; ++g) issue_w(g);
+    write_tab();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    gc_for<0, GC_NVL>([&](auto ic) { norm_vec(ic); });
+    write_halo();
+    wait_vmcnt<(GC_NSLOT - 2) * GC_PPW>();                 // half-tap 0 has landed
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the LDS stores above
+  __builtin_amdgcn_s_barrier();
+  if (my_tiles > 0) {
+    read_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fa[0]);
+    read_w(0, std::integral_constant<int, 0>{}, fw[0]);
+  }
+
+  int iter = 0;
+  for (int vt = blockIdx.x; vt < a.ntiles; vt += G, ++iter) {
+    int n, ty, tx;
+    decode(vt, n, ty, tx);
+    const bool has_next = vt + G < a.ntiles && !(ABL & 4);
+
+    acc4 acc[4][4];
+    {
+      const acc4* lb = reinterpret_cast<const acc4*>(smem + GC_L_BIAS) + wn * 16 + lq;   // the lane's columns 16 j + 4 lq + r
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const acc4 b = lb[4 * j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = b;
+      }
+    }
+
+    // residual vectors of the epilogue (the lane's 8 channels after the swap there), requested under the tile's last 16 MFMAs (earlier they do not fit the register file)
+    const int cofs = wn * 64 + 16 * (lq & 1) + 8 * (lq >> 1);
+    const unsigned eoff = (unsigned)((((n * a.H + ty * GC_T + 4 * wm) * a.W + tx * GC_T + lm) * GC_COUT + cofs) * 2);   // byte offset of (row 0, pair 0)
+    const int erow = a.W * GC_COUT * 2;                                                                               // bytes per image row
+    u32x4 rv[RES ? 4 : 1][2];
+
+    gc_for<0, GC_NSTEP>([&](auto sc_) {
+      constexpr int S = decltype(sc_)::value;
+      const int slot = gstep & (GC_NSLOT - 1), nslot = (gstep + 1) & (GC_NSLOT - 1);
+      // second k-step's fragments
+      read_a(sc_, std::integral_constant<int, 1>{}, fa[1]);
+      read_w(slot, std::integral_constant<int, 1>{}, fw[1]);
+      // a vector of the next tile's halo per half-tap, half of it under each k-step's MFMAs (unconditional: without a next tile it works on
+      // stale registers; a uniform branch would put it in a basic block of its own, in front of the MFMAs instead of between them)
+      constexpr bool NORM = S >= 6 && S < 6 + GC_NVL && !(ABL & 64);
+      if constexpr (NORM) norm_part(std::integral_constant<int, S - 6>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if constexpr (!(ABL & 1)) acc[i][j] = gc_mma(fw[0][j], fa[0][i], acc[i][j]); else acc[i][j][0] += __builtin_bit_cast(float, (int)fw[0][j][0] ^ (int)fa[0][i][0]);
+      if constexpr (NORM) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- hand-over: half-tap gstep + 1 has landed (this wave's pieces; the barrier collects the others').  vmcnt retires in order, so the
+      // count is the operations YOUNGER than those pieces: the pieces of half-tap gstep + 2, plus -- half-taps 0, 1 -- the previous tile's
+      // epilogue stores, plus -- half-taps 3, 4 -- the halo loads issued in half-tap 2.
+      constexpr int NST = 8, NHL = GC_NVL;   // (wave 0 also requested the table: it waits for one operation more than it must)
+      if constexpr (ABL & (2 | 8)) {
+      } else if constexpr (S <= 1) {
+        constexpr int NRL = RES ? 8 : 0;                   // (the residual loads of half-tap 17 are younger than the pieces half-taps 0 and 1 wait for)
+        if (iter > 0) wait_vmcnt<GC_PPW + NST + NRL>(); else wait_vmcnt<GC_PPW>();
+      } else if constexpr (S == 3 || S == 4) {
+        if (has_next) wait_vmcnt<GC_PPW + NHL>(); else wait_vmcnt<GC_PPW>();
+      } else {
+        wait_vmcnt<GC_PPW>();
+      }
+      if constexpr (S == 5) {                              // (the wait above has seen the halo loads land; this barrier publishes the table)
+        if (has_next) { write_tab(); __builtin_amdgcn_s_waitcnt(0xC07F); }
+      }
+      if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
+      if constexpr (!(ABL & 2)) issue_w(gstep + GC_NSLOT - 1);   // into the slot half-tap gstep - 1 left
+      if constexpr (S == 2) {
+        if (has_next) { iter_ = 1; load_halo(vt + G); }
+      }
+      if constexpr (S == GC_NSTEP - 1 && RES) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) rv[i][jp] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)eoff + 64 * jp, i * erow, 0);
+      }
+      // first k-step's fragments of the next half-tap (the next tile's A fragments wait for its halo)
+      if constexpr (S + 1 < GC_NSTEP) read_a(std::integral_constant<int, S + 1>{}, std::integral_constant<int, 0>{}, fa[0]);
+      if (gstep + 1 < total) read_w(nslot, std::integral_constant<int, 0>{}, fw[0]);
+      if constexpr (NORM) norm_part(std::integral_constant<int, S - 6>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if constexpr (!(ABL & 1)) acc[i][j] = gc_mma(fw[1][j], fa[1][i], acc[i][j]); else acc[i][j][0] += __builtin_bit_cast(float, (int)fw[1][j][0] ^ (int)fa[1][i][0]);
+      if constexpr (NORM) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      ++gstep;
+    });
+
+    // ---- epilogue (gemm16.hip's idiom): lane (lm, lq) holds pixel lm of image row 4 wm + i and, per tile j, channels 16 j + 4 lq + r;
+    // v_permlane16_swap of tiles 2 jp, 2 jp + 1 -> 8 consecutive channels 32 jp + 16 (lq & 1) + 8 (lq >> 1) .. + 7: one 16-byte store
+    if (!(ABL & 16) || acc[0][0][0] == 1.2345e-30f) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          const acc4 x = acc[i][2 * jp], y = acc[i][2 * jp + 1];
+          if (!RES) {
+            const auto s01 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[0], x[1]), pack_bf16x2(y[0], y[1]), false, false);
+            const auto s23 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[2], x[3]), pack_bf16x2(y[2], y[3]), false, false);
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){s01[0], s23[0], s01[1], s23[1]}, rO, (int)eoff + 64 * jp, i * erow, 0);
+          } else {
+            float o8[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[r]), __float_as_uint(y[r]), false, false);
+              o8[r] = __uint_as_float(sw[0]);
+              o8[4 + r] = __uint_as_float(sw[1]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o8[2 * e] += gc_lo(rv[i][jp][e]);
+              o8[2 * e + 1] += gc_hi(rv[i][jp][e]);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])},
+                                                   rO, (int)eoff + 64 * jp, i * erow, 0);
+          }
+        }
+      }
+    }
+    // ---- the next tile's halo takes the place of this one's
+    if (has_next || ((ABL & 4) && vt + G < a.ntiles)) {
+      __builtin_amdgcn_s_barrier();                        // every wave has read its last A fragments
+      if constexpr (!(ABL & (4 | 64))) write_halo();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      read_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, fa[0]);
+    }
+  }
+  wait_vmcnt<0>();                                         // (the poison pieces write LDS: none may be in flight when the workgroup's LDS is released)
+}
+
+int g_gnconv_abl = 0;
+
+}  // namespace
+
+void mmgt_gnconv_set_abl(int v) { g_gnconv_abl = v; }
+
+// x (nb, H, W, 128) bf16 channels-last, H and W multiples of 16; scale / shift (nb, 128) fp32 (mmgt_groupnorm_affine); wimg = pack_gnconv
+// image of the (128, 128, 3, 3) weight; bias (128) fp32 or null; residual (nb, H, W, 128) bf16 or null; out (nb, H, W, 128) bf16.
+extern "C" int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const float* shift, const void* wimg, const float* bias, const void* residual,
+                                    void* out, int nb, int H, int W, int cin, int cout, int dtype, void* stream) {
+  MMGT_CHECK(x && scale && shift && wimg && out && nb > 0 && H > 0 && W > 0, "gn_silu_conv3x3: bad arguments");
+  MMGT_CHECK(dtype == MMGT_BF16, "gn_silu_conv3x3: bf16 only");
+  MMGT_CHECK(cin == GC_CIN && cout == GC_COUT, "gn_silu_conv3x3: Cin = Cout = 128 only (got %d -> %d)", cin, cout);
+  MMGT_CHECK(H % GC_T == 0 && W % GC_T == 0, "gn_silu_conv3x3: H and W must be multiples of 16 (got %d x %d)", H, W);
+  MMGT_CHECK((long)nb * H * W * GC_CIN * 2 < (1l << 31), "gn_silu_conv3x3: x, residual and out must be smaller than 2 GiB each");
+  MMGT_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)wimg % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)residual % 16) == 0 &&
+                 ((uintptr_t)scale % 16) == 0 && ((uintptr_t)shift % 16) == 0,
+             "gn_silu_conv3x3: pointers must be 16-byte aligned");
+  GcArgs a;
+  a.x = reinterpret_cast<const bf16_t*>(x);
+  a.scale = scale;
+  a.shift = shift;
+  a.wimg = reinterpret_cast<const char*>(wimg);
+  a.bias = bias;
+  a.res = reinterpret_cast<const bf16_t*>(residual);
+  a.out = reinterpret_cast<bf16_t*>(out);
+  a.nb = nb;
+  a.H = H;
+  a.W = W;
+  a.tiles_x = W / GC_T;
+  a.tiles_per_img = (H / GC_T) * (W / GC_T);
+  a.ntiles = nb * a.tiles_per_img;
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+      mmgt_set_error("gn_silu_conv3x3: device query failed");
+      return 2;
+    }
+    ncu = prop.multiProcessorCount;
+  }
+  int gx = ncu / 8 * 8;
+  if (gx > a.ntiles) gx = a.ntiles;
+  hipStream_t s = (hipStream_t)stream;
+  auto go = [&](auto kern) -> int {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GC_LDS) != hipSuccess) {
+      mmgt_set_error("gn_silu_conv3x3: cannot reserve %d bytes of LDS", GC_LDS);
+      return 2;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(512), GC_LDS, s, a);
+    return 0;
+  };
+  int rc;
+  if (residual) rc = go(gnconv128_kernel<true, 0>);
+  else switch (g_gnconv_abl) {
+    case 1: rc = go(gnconv128_kernel<false, 1>); break;
+    case 2: rc = go(gnconv128_kernel<false, 2>); break;
+    case 4: rc = go(gnconv128_kernel<false, 4>); break;
+    case 8: rc = go(gnconv128_kernel<false, 8>); break;
+    case 16: rc = go(gnconv128_kernel<false, 16>); break;
+    case 32: rc = go(gnconv128_kernel<false, 32>); break;
+    case 6: rc = go(gnconv128_kernel<false, 6>); break;
+    case 22: rc = go(gnconv128_kernel<false, 22>); break;
+    case 64: rc = go(gnconv128_kernel<false, 64>); break;
+    case 128: rc = go(gnconv128_kernel<false, 128>); break;
+    default: rc = go(gnconv128_kernel<false, 0>); break;
+  }
+  if (rc) return rc;
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" long mmgt_gn_silu_conv3x3_image_bytes(int cin, int cout) { return cin == GC_CIN && cout == GC_COUT ? (long)GC_NSTEP * GC_SLOT : -1; }

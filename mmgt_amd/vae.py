@@ -13,7 +13,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
-from .packing import pack_conv3x3, pad_cols, pad_rows, round_up
+from .packing import pack_conv3x3, pack_gnconv, pad_cols, pad_rows, round_up
 
 _UP_CH = ((512, 512), (512, 512), (512, 256), (256, 128))     # (in, out) of decoder.up_blocks.0..3
 
@@ -165,6 +165,9 @@ class AutoencoderKL:
                 cin_pad, cout_pad = round_up(wt.shape[1], 64), round_up(wt.shape[0], 64)
                 w[p + ".w"] = self._t(pack_conv3x3(wt, cin_pad, cout_pad))
                 w[p + ".bias"] = self._f(pad_rows(b, cout_pad))
+                if self._dtype == torch.bfloat16 and tuple(wt.shape[:2]) == (128, 128):
+                    # the 128-channel levels: GroupNorm + SiLU + conv in one launch (csrc/gnconv.hip) wherever a GroupNorm feeds this conv
+                    w[p + ".gimg"] = pack_gnconv(wt.to(self._device, torch.float32))
             elif wt.dim() == 4:                                      # 1x1 conv as GEMM
                 m = wt.reshape(wt.shape[0], -1)
                 w[p + ".w"] = self._t(pad_rows(pad_cols(m, round_up(m.shape[1], 64)), round_up(m.shape[0], 64)))
@@ -201,15 +204,22 @@ class AutoencoderKL:
         nb, h, ww, c = x.shape
         return hip.groupnorm(x.view(nb, h * ww, c), self.w[p + ".g"], self.w[p + ".b"], 32, 1e-6, silu=silu).view(nb, h, ww, c)
 
+    def _gn_silu_conv(self, pn, pc, x, residual=None):
+        """conv3x3(silu(GroupNorm(x))) (+ residual): diffusers `ResnetBlock2D.forward`'s norm -> nonlinearity -> conv.  The 128 -> 128 convs of a
+        bf16 model run as a statistics pass + ONE fused launch (the normalised tensor is never written); everything else as two launches."""
+        nb, h, ww, c = x.shape
+        if hip.tune_get("gnconv") and (pc + ".gimg") in self.w and hip.gn_silu_conv3x3_supported(x.dtype, c, 128, h, ww) and h * ww > 256:
+            return hip.gn_silu_conv3x3(x, self.w[pn + ".g"], self.w[pn + ".b"], 32, 1e-6, self.w[pc + ".gimg"], self.w[pc + ".bias"], residual)
+        return hip.conv3x3(self._gn(pn, x, True), self.w[pc + ".w"], self.w[pc + ".bias"], residual=residual)
+
     def _resnet(self, p, x):
         nb, h, ww, cin = x.shape
-        hdn = hip.conv3x3(self._gn(p + ".norm1", x, True), self.w[p + ".conv1.w"], self.w[p + ".conv1.bias"])
-        hdn = self._gn(p + ".norm2", hdn, True)
+        hdn = self._gn_silu_conv(p + ".norm1", p + ".conv1", x)
         res = x
         if (p + ".conv_shortcut.w") in self.w:
             res = hip.gemm(x.view(nb * h * ww, cin), self.w[p + ".conv_shortcut.w"], self.w[p + ".conv_shortcut.bias"])
             res = res.view(nb, h, ww, -1)
-        return hip.conv3x3(hdn, self.w[p + ".conv2.w"], self.w[p + ".conv2.bias"], residual=res)
+        return self._gn_silu_conv(p + ".norm2", p + ".conv2", hdn, residual=res)
 
     def _mid_attention(self, x, a="decoder.mid_block.attentions.0"):
         if self._split_attention and self._dtype == torch.bfloat16 and x.shape[1] * x.shape[2] % 256 == 0 and x.shape[1] * x.shape[2] <= 8192:

@@ -1,0 +1,106 @@
+"""GroupNorm + SiLU + conv3x3 in one launch (csrc/gnconv.hip, the VAE's 128-channel levels) against fp64 with the kernel's rounding points
+(normalised activations and the result are bf16, every sum fp32) and against the two launches it replaces."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _case(nb, H, W, seed, res, bias=True):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.randn((nb, H, W, 128), generator=g) * 1.5 + 0.3).to(dev()).bfloat16()
+    w = (torch.randn((128, 128, 3, 3), generator=g) / math.sqrt(9 * 128)).to(dev())
+    b = (torch.rand(128, generator=g) - 0.5).to(dev()) if bias else None
+    r = torch.randn((nb, H, W, 128), generator=g).to(dev()).bfloat16() if res else None
+    scale = (0.5 + torch.rand((nb, 128), generator=g)).to(dev())
+    shift = (torch.rand((nb, 128), generator=g) - 0.5).to(dev())
+    return x, w, b, r, scale, shift
+
+
+def _ref(x, w, b, r, scale, shift):
+    """fp64 conv of the bf16-rounded activations (the fused kernel's rounding point) with the bf16-rounded weights"""
+    t = torch.addcmul(shift[:, None, None, :], x.float(), scale[:, None, None, :])
+    y = (t / (1 + torch.exp(-t))).bfloat16().double()
+    o = F.conv2d(y.permute(0, 3, 1, 2), w.bfloat16().double(), None if b is None else b.double(), padding=1).permute(0, 2, 3, 1)
+    if r is not None:
+        o = o + r.double()
+    return o
+
+
+@pytest.mark.parametrize("nb,H,W,res", [(1, 16, 16, False), (3, 32, 48, True), (2, 64, 64, False), (5, 48, 16, True), (300, 16, 16, True)])
+def test_gnconv_tables_vs_fp64(nb, H, W, res):
+    """One tile per image (every halo pixel is padding), several tiles per image (halos cross tile borders), more tiles than workgroups
+    (300 images: the weight stream and the halo prefetch run across tile boundaries), with and without residual."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_gnconv
+    x, w, b, r, scale, shift = _case(nb, H, W, 100 + nb, res)
+    out = hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), b, r)
+    ref = _ref(x, w, b, r, scale, shift)
+    d = (out.double() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 6e-3          # bf16 rounding of the result + one-ulp flips of activations (device exp against torch's)
+    assert (d <= tol).all(), (d.max().item(), (d / tol).max().item(), (d > tol).sum().item())
+    assert d.mean().item() < 2e-3
+    out2 = hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), b, r)
+    assert torch.equal(out, out2)                                                     # reproducible
+
+
+def test_gnconv_no_bias_and_zero_padding():
+    """shift != 0 makes silu(shift) != 0 at a zero INPUT: the padding must be zeros after the activation.  Constant input: every interior
+    pixel sees nine taps, edges six, corners four."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_gnconv
+    nb, H, W = 2, 32, 32
+    x = torch.zeros((nb, H, W, 128), device=dev(), dtype=torch.bfloat16)
+    scale = torch.ones((nb, 128), device=dev())
+    shift = torch.full((nb, 128), 2.0, device=dev())
+    w = torch.zeros((128, 128, 3, 3), device=dev())
+    w[:, 0] = 1.0                                                                     # every tap reads input channel 0
+    out = hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w)).float()
+    v = torch.tensor(2.0 / (1 + math.exp(-2.0))).bfloat16().float().item()
+    cnt = F.conv2d(torch.ones((1, 1, H, W)), torch.ones((1, 1, 3, 3)), padding=1)[0, 0].to(dev())
+    ref = (cnt * v)[None, :, :, None].expand(nb, H, W, 128)
+    torch.testing.assert_close(out, ref.bfloat16().float(), rtol=2.0 ** -7, atol=0)
+
+
+def test_gnconv_fused_groupnorm_vs_two_launches():
+    """The product call (statistics pass + fused launch) against hip.groupnorm(silu) -> hip.conv3x3 at a VAE shape: both round the
+    normalised activations to bf16; the table form x * scale + shift differs from ((x - mean) rstd) gamma + beta in the last fp32 bit."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_conv3x3, pack_gnconv
+    nb, H, W = 2, 128, 128
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = (torch.randn((nb, H, W, 128), generator=g) * 2 + 0.5).to(dev()).bfloat16()
+    w = (torch.randn((128, 128, 3, 3), generator=g) / math.sqrt(9 * 128))
+    gamma = (0.5 + torch.rand(128, generator=g)).to(dev())
+    beta = (torch.rand(128, generator=g) - 0.5).to(dev())
+    b = (torch.rand(128, generator=g) - 0.5).to(dev())
+    r = torch.randn((nb, H, W, 128), generator=g).to(dev()).bfloat16()
+    fused = hip.gn_silu_conv3x3(x, gamma, beta, 32, 1e-6, pack_gnconv(w.to(dev())), b, r)
+    y = hip.groupnorm(x.view(nb, H * W, 128), gamma, beta, 32, 1e-6, silu=True).view(nb, H, W, 128)
+    two = hip.conv3x3(y, pack_conv3x3(w).to(dev()).bfloat16(), b, residual=r)
+    d = (fused.float() - two.float()).abs()
+    assert d.max().item() < 4e-2 and d.mean().item() < 1.5e-3, (d.max().item(), d.mean().item())
+    # and against fp64 of the module (GroupNorm in fp64 from the bf16 input): the fused path must be no worse than the two launches
+    xd = x.double().permute(0, 3, 1, 2)
+    ref = F.conv2d(F.silu(F.group_norm(xd, 32, gamma.double(), beta.double(), 1e-6)), w.to(dev()).bfloat16().double(), b.double(), padding=1)
+    ref = ref.permute(0, 2, 3, 1) + r.double()
+    e_f, e_t = (fused.double() - ref).abs().mean().item(), (two.double() - ref).abs().mean().item()
+    assert e_f <= 1.1 * e_t + 1e-5, (e_f, e_t)
+
+
+def test_gnconv_rejects_unsupported():
+    from mmgt_amd import hip
+    x = torch.zeros((1, 24, 16, 128), device=dev(), dtype=torch.bfloat16)
+    assert not hip.gn_silu_conv3x3_supported(torch.bfloat16, 128, 128, 24, 16)
+    assert not hip.gn_silu_conv3x3_supported(torch.float32, 128, 128, 32, 32)
+    assert not hip.gn_silu_conv3x3_supported(torch.bfloat16, 256, 128, 32, 32)
+    with pytest.raises(AssertionError):
+        hip.gn_silu_conv3x3_tables(x, torch.ones((1, 128), device=dev()), torch.zeros((1, 128), device=dev()),
+                                   torch.zeros(18 * 16384, device=dev(), dtype=torch.uint8))

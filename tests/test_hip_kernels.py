@@ -154,7 +154,7 @@ def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize("cfg", [16, 17, 19])
+@pytest.mark.parametrize("cfg", [16, 17, 19, 20])
 def test_gemm16_persistent_workgroups_exact(cfg):
     """Several tiles per persistent workgroup (more tiles than CUs): the tile-boundary machinery of gemm16 -- bias vectors
     fetched one tile ahead into LDS, the next W chunk issued in front of the epilogue stores with a counted wait that leaves
@@ -212,9 +212,9 @@ def test_gemm16_persistent_workgroups_exact(cfg):
         hip.tune("gemm_cfg", 0)
 
 
-@pytest.mark.parametrize("cfg", [16, 17, 19])
+@pytest.mark.parametrize("cfg", [16, 17, 19, 20])
 def test_gemm16_core_exact_integers_and_geglu(cfg):
-    """The 16x16x32 ping-pong core (cfg 16: 256 x 256 tile, cfg 17: 256 x 320, cfg 19: 192 x 320; bf16 only; GEGLU runs on cfg 16 only): (a) exact small-integer operands with an ASYMMETRIC weight matrix --
+    """The 16x16x32 ping-pong core (cfg 16: 256 x 256 tile, cfg 17: 256 x 320, cfg 19: 192 x 320, cfg 20: 256 x 128; bf16 only; GEGLU runs on cfg 16 only): (a) exact small-integer operands with an ASYMMETRIC weight matrix --
     any row/column or k-order mix-up in the fragment maps, the permlane16 epilogue or the swizzle shows as a wrong integer;
     (b) GEGLU with packed weights, (c) ragged M / N edges and several tiles per persistent workgroup, (d) bias2 + residual."""
     from mmgt_amd import hip

@@ -23,7 +23,7 @@ def main():
     lat = hash_uniform("pv.lat", (1, 4, frames, 64, 64), 1.0).to(dev)
     vae.decode_video(lat, frames_per_batch=frames)                      # warm-up
     for n in ["gemm", "gemm_batched", "gemm_batched_wx", "conv3x3", "groupnorm", "attention", "softmax_rows", "nhwc_to_ncfhw", "ncfhw_to_nhwc",
-              "gemm_bf16_f32", "qk_split3", "softmax_rows_f32_bf16"]:
+              "gemm_bf16_f32", "qk_split3", "softmax_rows_f32_bf16", "gn_silu_conv3x3_tables", "groupnorm_affine"]:
         if hasattr(hip, n):
             P.wrap(n)
     torch.cuda.synchronize()
