@@ -883,7 +883,8 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     default: return launch_cfg<T, MODE, 128, 128, 2, 2, 2>(ad, W, bsw, ep, M, N, K, batch, s);
   }
 #else
-  // Tiles measured and dropped (tools/ab_gemm.py, one process, one device): 128x128 / 128x64 with a 3-deep ring, 64x64,
+  // Tiles measured and dropped (tools/ab_gemm.py, one process, one device): 128x128 / 128x64 with a 3-deep ring (round 5 again, with 4-deep
+  // rings too, on the M = 1536 / 3072 shapes of the 8x8 level: profiles/r5/ab_cfg_deep_r5.txt -- 128x64 x 3 gains 10 % at M = 1536 only), 64x64,
   // 256x128 with a 2-deep ring, 256x64, 256x256 with a 3- or 4-deep ring of 64-byte rows, 256x320 on 8 waves (accumulators +
   // double-buffered fragments spill inside the main loop; with single-buffered W fragments reloaded right after their last
   // MFMA it still spills 56-139 VGPRs and runs 1179 us at 8192^3 against 965) and 256x256 / 256x320 on 4 waves (one wave per SIMD, 512

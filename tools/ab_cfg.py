@@ -65,6 +65,10 @@ SETS = {
     "l3": lambda: [gemm_case(3072, 1280, 1280, res=True), gemm_case(3072, 1280, 1280), gemm_case(3072, 3840, 1280, bias=False),
                    gemm_case(3072, 1280, 5120, res=True), gemm_case(3072, 2560, 1280), gemm_case(3072, 10240, 1280, act=1),
                    gemm_case(49152, 640, 640), gemm_case(12288, 1280, 1280)],
+    "l3small": lambda: [gemm_case(3072, 1280, 1280, res=True), gemm_case(3072, 3840, 1280, bias=False), gemm_case(3072, 1280, 5120, res=True),
+                        gemm_case(3072, 10240, 1280, act=1), gemm_case(1536, 1280, 1280, res=True), gemm_case(1536, 3840, 1280, bias=False),
+                        gemm_case(1536, 1280, 5120, res=True), gemm_case(1536, 10240, 1280, act=1), gemm_case(6144, 1280, 1280, res=True),
+                        gemm_case(12288, 1280, 1280, res=True), gemm_case(24576, 640, 640, res=True)],
     "wx": lambda: [wx_case(48, 320, 4096, 320), wx_case(48, 640, 1024, 640), wx_case(48, 1280, 256, 1280)],
     "step2": lambda: [
         gemm_case(196608, 2560, 320, act=1), gemm_case(49152, 640, 2560, res=True), gemm_case(49152, 640, 640, res=True),
