@@ -336,18 +336,18 @@ def groupnorm_affine(x, gamma, beta, groups, eps):
     return scale, shift
 
 
-def gn_silu_conv3x3_supported(dtype, cin, cout, H, W):
-    return dtype == torch.bfloat16 and cin == 128 and cout == 128 and H % 16 == 0 and W % 16 == 0
+def gn_silu_conv3x3_supported(dtype, cin, cout, H, W, residual=False):
+    return (dtype == torch.bfloat16 and ((cin, cout) == (128, 128) or ((cin, cout) in ((256, 128), (128, 64)) and not residual))
+            and H % 16 == 0 and W % 16 == 0)
 
 
-def gn_silu_conv3x3_tables(x, scale, shift, wimg, bias=None, residual=None, out=None):
-    """bias + conv3x3(silu(x * scale[n, c] + shift[n, c])) (+ residual) in one launch (csrc/gnconv.hip): x (NB, H, W, 128) bf16 channels-last,
-    scale / shift (NB, 128) fp32 (the tables of `groupnorm_affine`), wimg = packing.pack_gnconv(weight)."""
+def gn_silu_conv3x3_tables(x, scale, shift, wimg, cout, bias=None, residual=None, out=None):
+    """bias + conv3x3(silu(x * scale[n, c] + shift[n, c])) (+ residual) in one launch (csrc/gnconv.hip): x (NB, H, W, Cin) bf16 channels-last,
+    scale / shift (NB, Cin) fp32 (the tables of `groupnorm_affine`), wimg = packing.pack_gnconv(weight (cout, Cin, 3, 3))."""
     _dev(x, scale, shift, wimg, bias, residual, out)
     assert x.dim() == 4 and x.is_contiguous()
     NB, H, W, C = x.shape
-    cout = 128
-    assert gn_silu_conv3x3_supported(x.dtype, C, cout, H, W) and x.numel() * x.element_size() <= DMA_LIMIT
+    assert gn_silu_conv3x3_supported(x.dtype, C, cout, H, W, residual is not None) and x.numel() * x.element_size() <= DMA_LIMIT
     assert scale.shape == (NB, C) and shift.shape == (NB, C) and scale.dtype == torch.float32 and shift.dtype == torch.float32
     assert scale.is_contiguous() and shift.is_contiguous()
     assert wimg.dtype == torch.uint8 and wimg.is_contiguous() and wimg.numel() == lib().mmgt_gn_silu_conv3x3_image_bytes(C, cout)
@@ -356,23 +356,25 @@ def gn_silu_conv3x3_tables(x, scale, shift, wimg, bias=None, residual=None, out=
     assert out.shape == (NB, H, W, cout) and out.is_contiguous() and out.dtype == x.dtype
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype
+    if bias is not None:
+        assert bias.numel() >= cout
     _check(lib().mmgt_gn_silu_conv3x3(_ptr(x), _ptr(scale), _ptr(shift), _ptr(wimg), _ptr(_f32(bias, "bias")), _ptr(residual), _ptr(out),
                                       NB, H, W, C, cout, dtype_code(x.dtype), _stream()), "mmgt_gn_silu_conv3x3")
     return out
 
 
-def gn_silu_conv3x3(x, gamma, beta, groups, eps, wimg, bias=None, residual=None, out=None):
+def gn_silu_conv3x3(x, gamma, beta, groups, eps, wimg, cout, bias=None, residual=None, out=None):
     """conv3x3(silu(GroupNorm(x))) (+ residual): ONE pass over x for the statistics (`groupnorm_affine`) and ONE fused launch for the rest.
-    x (NB, H, W, 128) bf16 channels-last -> (NB, H, W, 128)."""
+    x (NB, H, W, Cin) bf16 channels-last -> (NB, H, W, cout); (Cin, cout) = (128, 128), (256, 128), (128, 64)."""
     assert x.dim() == 4 and x.is_contiguous()
     NB, H, W, C = x.shape
     if out is None:
-        out = torch.empty((NB, H, W, 128), device=x.device, dtype=x.dtype)
+        out = torch.empty((NB, H, W, cout), device=x.device, dtype=x.dtype)
     step = max(1, DMA_LIMIT // (H * W * C * x.element_size()))       # 32-bit buffer offsets: runs of whole images below 2 GiB
     for n0 in range(0, NB, step):
         n1 = min(NB, n0 + step)
         scale, shift = groupnorm_affine(x[n0:n1].view(n1 - n0, H * W, C), gamma, beta, groups, eps)
-        gn_silu_conv3x3_tables(x[n0:n1], scale, shift, wimg, bias, None if residual is None else residual[n0:n1], out[n0:n1])
+        gn_silu_conv3x3_tables(x[n0:n1], scale, shift, wimg, cout, bias, None if residual is None else residual[n0:n1], out[n0:n1])
     return out
 
 

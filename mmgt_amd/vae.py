@@ -165,9 +165,11 @@ class AutoencoderKL:
                 cin_pad, cout_pad = round_up(wt.shape[1], 64), round_up(wt.shape[0], 64)
                 w[p + ".w"] = self._t(pack_conv3x3(wt, cin_pad, cout_pad))
                 w[p + ".bias"] = self._f(pad_rows(b, cout_pad))
-                if self._dtype == torch.bfloat16 and tuple(wt.shape[:2]) == (128, 128):
-                    # the 128-channel levels: GroupNorm + SiLU + conv in one launch (csrc/gnconv.hip) wherever a GroupNorm feeds this conv
-                    w[p + ".gimg"] = pack_gnconv(wt.to(self._device, torch.float32))
+                if self._dtype == torch.bfloat16 and (wt.shape[1], cout_pad) in ((128, 128), (256, 128), (128, 64)):
+                    # the 512 x 512 level: GroupNorm + SiLU + conv in one launch (csrc/gnconv.hip) wherever a GroupNorm feeds this conv
+                    wpad = torch.zeros((cout_pad, wt.shape[1], 3, 3), device=self._device, dtype=torch.float32)
+                    wpad[:wt.shape[0]] = wt.to(self._device, torch.float32)
+                    w[p + ".gimg"] = pack_gnconv(wpad)
             elif wt.dim() == 4:                                      # 1x1 conv as GEMM
                 m = wt.reshape(wt.shape[0], -1)
                 w[p + ".w"] = self._t(pad_rows(pad_cols(m, round_up(m.shape[1], 64)), round_up(m.shape[0], 64)))
@@ -206,10 +208,12 @@ class AutoencoderKL:
 
     def _gn_silu_conv(self, pn, pc, x, residual=None):
         """conv3x3(silu(GroupNorm(x))) (+ residual): diffusers `ResnetBlock2D.forward`'s norm -> nonlinearity -> conv.  The 128 -> 128 convs of a
-        bf16 model run as a statistics pass + ONE fused launch (the normalised tensor is never written); everything else as two launches."""
+        bf16 model, the 256 -> 128 conv and conv_out (128 -> 3, padded to 64) run as a statistics pass + ONE fused launch (the normalised tensor is never written); everything else as two launches."""
         nb, h, ww, c = x.shape
-        if hip.tune_get("gnconv") and (pc + ".gimg") in self.w and hip.gn_silu_conv3x3_supported(x.dtype, c, 128, h, ww) and h * ww > 256:
-            return hip.gn_silu_conv3x3(x, self.w[pn + ".g"], self.w[pn + ".b"], 32, 1e-6, self.w[pc + ".gimg"], self.w[pc + ".bias"], residual)
+        cout = self.w[pc + ".bias"].numel()
+        if (hip.tune_get("gnconv") and (pc + ".gimg") in self.w and hip.gn_silu_conv3x3_supported(x.dtype, c, cout, h, ww, residual is not None)
+                and h * ww > 256):
+            return hip.gn_silu_conv3x3(x, self.w[pn + ".g"], self.w[pn + ".b"], 32, 1e-6, self.w[pc + ".gimg"], cout, self.w[pc + ".bias"], residual)
         return hip.conv3x3(self._gn(pn, x, True), self.w[pc + ".w"], self.w[pc + ".bias"], residual=residual)
 
     def _resnet(self, p, x):
@@ -282,8 +286,7 @@ class AutoencoderKL:
             if i != 3:
                 p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
                 x = hip.conv3x3(x, self.w[p + ".w"], self.w[p + ".bias"], upsample=True)
-        x = self._gn("decoder.conv_norm_out", x, True)
-        return hip.conv3x3(x, self.w["decoder.conv_out.w"], self.w["decoder.conv_out.bias"])
+        return self._gn_silu_conv("decoder.conv_norm_out", "decoder.conv_out", x)
 
     def encode_nhwc(self, x):
         """x: (nb, H, W, 64) channels-last image in [-1, 1] (3 valid channels) -> (nb, H/8, W/8, 64) moments (channels

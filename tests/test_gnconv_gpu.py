@@ -13,14 +13,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _case(nb, H, W, seed, res, bias=True):
+def _case(nb, H, W, seed, res, bias=True, cin=128, cout=128):
     g = torch.Generator(device="cpu").manual_seed(seed)
-    x = (torch.randn((nb, H, W, 128), generator=g) * 1.5 + 0.3).to(dev()).bfloat16()
-    w = (torch.randn((128, 128, 3, 3), generator=g) / math.sqrt(9 * 128)).to(dev())
-    b = (torch.rand(128, generator=g) - 0.5).to(dev()) if bias else None
-    r = torch.randn((nb, H, W, 128), generator=g).to(dev()).bfloat16() if res else None
-    scale = (0.5 + torch.rand((nb, 128), generator=g)).to(dev())
-    shift = (torch.rand((nb, 128), generator=g) - 0.5).to(dev())
+    x = (torch.randn((nb, H, W, cin), generator=g) * 1.5 + 0.3).to(dev()).bfloat16()
+    w = (torch.randn((cout, cin, 3, 3), generator=g) / math.sqrt(9 * cin)).to(dev())
+    b = (torch.rand(cout, generator=g) - 0.5).to(dev()) if bias else None
+    r = torch.randn((nb, H, W, cout), generator=g).to(dev()).bfloat16() if res else None
+    scale = (0.5 + torch.rand((nb, cin), generator=g)).to(dev())
+    shift = (torch.rand((nb, cin), generator=g) - 0.5).to(dev())
     return x, w, b, r, scale, shift
 
 
@@ -41,14 +41,31 @@ def test_gnconv_tables_vs_fp64(nb, H, W, res):
     from mmgt_amd import hip
     from mmgt_amd.packing import pack_gnconv
     x, w, b, r, scale, shift = _case(nb, H, W, 100 + nb, res)
-    out = hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), b, r)
+    out = hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), 128, b, r)
     ref = _ref(x, w, b, r, scale, shift)
     d = (out.double() - ref).abs()
     tol = 2.0 ** -8 * ref.abs() + 6e-3          # bf16 rounding of the result + one-ulp flips of activations (device exp against torch's)
     assert (d <= tol).all(), (d.max().item(), (d / tol).max().item(), (d > tol).sum().item())
     assert d.mean().item() < 2e-3
-    out2 = hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), b, r)
+    out2 = hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), 128, b, r)
     assert torch.equal(out, out2)                                                     # reproducible
+
+
+@pytest.mark.parametrize("cin,cout", [(256, 128), (128, 64)])
+@pytest.mark.parametrize("nb,H,W", [(1, 16, 16), (3, 32, 48), (300, 16, 16)])
+def test_gnconv_other_shapes_vs_fp64(cin, cout, nb, H, W):
+    """Cin = 256 (two phases per tile: the halves of the input channels take turns in the LDS halo and accumulate into the same registers) and
+    Cout = 64 (8 x 1 wave grid), the VAE's 256 -> 128 conv and conv_out."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_gnconv
+    x, w, b, r, scale, shift = _case(nb, H, W, 200 + nb + cin, False, cin=cin, cout=cout)
+    out = hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), cout, b)
+    ref = _ref(x, w, b, None, scale, shift)
+    d = (out.double() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 6e-3
+    assert (d <= tol).all(), (d.max().item(), (d / tol).max().item(), (d > tol).sum().item())
+    assert d.mean().item() < 2e-3
+    assert torch.equal(out, hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), cout, b))
 
 
 def test_gnconv_no_bias_and_zero_padding():
@@ -62,7 +79,7 @@ def test_gnconv_no_bias_and_zero_padding():
     shift = torch.full((nb, 128), 2.0, device=dev())
     w = torch.zeros((128, 128, 3, 3), device=dev())
     w[:, 0] = 1.0                                                                     # every tap reads input channel 0
-    out = hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w)).float()
+    out = hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), 128).float()
     v = torch.tensor(2.0 / (1 + math.exp(-2.0))).bfloat16().float().item()
     cnt = F.conv2d(torch.ones((1, 1, H, W)), torch.ones((1, 1, 3, 3)), padding=1)[0, 0].to(dev())
     ref = (cnt * v)[None, :, :, None].expand(nb, H, W, 128)
@@ -82,7 +99,7 @@ def test_gnconv_fused_groupnorm_vs_two_launches():
     beta = (torch.rand(128, generator=g) - 0.5).to(dev())
     b = (torch.rand(128, generator=g) - 0.5).to(dev())
     r = torch.randn((nb, H, W, 128), generator=g).to(dev()).bfloat16()
-    fused = hip.gn_silu_conv3x3(x, gamma, beta, 32, 1e-6, pack_gnconv(w.to(dev())), b, r)
+    fused = hip.gn_silu_conv3x3(x, gamma, beta, 32, 1e-6, pack_gnconv(w.to(dev())), 128, b, r)
     y = hip.groupnorm(x.view(nb, H * W, 128), gamma, beta, 32, 1e-6, silu=True).view(nb, H, W, 128)
     two = hip.conv3x3(y, pack_conv3x3(w).to(dev()).bfloat16(), b, residual=r)
     d = (fused.float() - two.float()).abs()
@@ -100,7 +117,8 @@ def test_gnconv_rejects_unsupported():
     x = torch.zeros((1, 24, 16, 128), device=dev(), dtype=torch.bfloat16)
     assert not hip.gn_silu_conv3x3_supported(torch.bfloat16, 128, 128, 24, 16)
     assert not hip.gn_silu_conv3x3_supported(torch.float32, 128, 128, 32, 32)
-    assert not hip.gn_silu_conv3x3_supported(torch.bfloat16, 256, 128, 32, 32)
+    assert not hip.gn_silu_conv3x3_supported(torch.bfloat16, 256, 256, 32, 32)
+    assert not hip.gn_silu_conv3x3_supported(torch.bfloat16, 256, 128, 32, 32, residual=True)
     with pytest.raises(AssertionError):
         hip.gn_silu_conv3x3_tables(x, torch.ones((1, 128), device=dev()), torch.zeros((1, 128), device=dev()),
-                                   torch.zeros(18 * 16384, device=dev(), dtype=torch.uint8))
+                                   torch.zeros(18 * 16384, device=dev(), dtype=torch.uint8), 128)

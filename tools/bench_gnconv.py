@@ -45,8 +45,8 @@ def main():
         t_gn = timeit(lambda: hip.groupnorm(x.view(nb, H * H, 128), gamma, beta, 32, 1e-6, silu=True, out=y.view(nb, H * H, 128)))
         t_cv = timeit(lambda: hip.conv3x3(y, wp, b, residual=r, out=out))
         t_st = timeit(lambda: hip.groupnorm_affine(x.view(nb, H * H, 128), gamma, beta, 32, 1e-6))
-        t_fu = timeit(lambda: hip.gn_silu_conv3x3_tables(x, scale, shift, wimg, b, r, out=out))
-        t_fn = timeit(lambda: hip.gn_silu_conv3x3_tables(x, scale, shift, wimg, b, None, out=out))
+        t_fu = timeit(lambda: hip.gn_silu_conv3x3_tables(x, scale, shift, wimg, 128, b, r, out=out))
+        t_fn = timeit(lambda: hip.gn_silu_conv3x3_tables(x, scale, shift, wimg, 128, b, None, out=out))
         print(f"{nb} x {H} x {H} x 128: groupnorm+silu {t_gn:7.1f} us + conv3x3(+res) {t_cv:7.1f} us ({fl / t_cv / 1e6:5.0f} TF/s) = {t_gn + t_cv:7.1f} us | "
               f"statistics {t_st:6.1f} us + fused(+res) {t_fu:7.1f} us ({fl / t_fu / 1e6:5.0f} TF/s) = {t_st + t_fu:7.1f} us | fused without residual {t_fn:7.1f} us", flush=True)
 
@@ -68,7 +68,7 @@ def ablations():
                       (16, "no epilogue stores"), (32, "no hand-over barrier"), (6, "no weight DMA, no halo"), (22, "no weight DMA, no halo, no epilogue"),
                       (64, "halo loads, but no normalisation / LDS writes"), (128, "normalisation / LDS writes, but no halo loads")]:
         hip.tune("gnconv_abl", abl)
-        t = timeit(lambda: hip.gn_silu_conv3x3_tables(x, scale, shift, wimg, None, None, out=out))
+        t = timeit(lambda: hip.gn_silu_conv3x3_tables(x, scale, shift, wimg, 128, None, None, out=out))
         base = base or t
         print(f"  abl {abl:3d} {what:45s} {t:7.1f} us  ({t - base:+7.1f})", flush=True)
     hip.tune("gnconv_abl", 0)

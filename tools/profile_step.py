@@ -63,10 +63,10 @@ def key_of(name, args, kw):
         x = args[0]
         return f"groupnorm_affine nb={x.shape[0]} hw={x.shape[1]} c={x.shape[2]} (statistics only)", 0
     if name == "gn_silu_conv3x3_tables":
-        x = args[0]
-        res = (args[5] if len(args) > 5 else kw.get("residual")) is not None
-        return (f"gn_silu_conv3x3 nb={x.shape[0]} h={x.shape[1]} cin=128 cout=128 (GroupNorm apply + SiLU + conv{' + res' if res else ''}, one launch)",
-                2 * x.shape[0] * x.shape[1] * x.shape[2] * 128 * 9 * 128)
+        x, cout = args[0], args[4]
+        res = (args[6] if len(args) > 6 else kw.get("residual")) is not None
+        return (f"gn_silu_conv3x3 nb={x.shape[0]} h={x.shape[1]} cin={x.shape[3]} cout={cout} (GroupNorm apply + SiLU + conv{' + res' if res else ''}, one launch)",
+                2 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * x.shape[3])
     if name == "temporal_leg320":
         x, B, F, n = args[0], args[5], args[6], args[7]
         return (f"temporal_leg320 B={B} F={F} n={n} (LN + pe -> q|k|v -> attention over the frames -> to_out + res)",
