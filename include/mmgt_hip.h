@@ -279,15 +279,16 @@ long mmgt_temporal_leg320_image_bytes(void);
 int mmgt_temporal_leg320(const void* x, void* out, const float* ln_gamma, const float* beta_pe, int pe_rows, const void* wimg, const float* bias_o,
                          int batch, int frames, int n_pix, float scale, float eps, int dtype, void* stream);
 
-/* GroupNorm + SiLU + conv3x3 (stride 1, padding 1) in one launch for the VAE's 128-channel levels (csrc/gnconv.hip; diffusers `ResnetBlock2D.forward`
- * norm -> nonlinearity -> conv as `AutoencoderKL.decode` runs it for src/pipelines/pipeline_pose2vid_long.py:112-125):
- *   out = bias + conv3x3( silu( x * scale[n, c] + shift[n, c] ) ) (+ residual)
- * x / residual / out (nb, H, W, 128) bf16 channels-last, H and W multiples of 16, x smaller than 2 GiB; scale / shift (nb, 128) fp32 = the tables of
- * mmgt_groupnorm_affine; wimg = packing.pack_gnconv(W) (mmgt_gn_silu_conv3x3_image_bytes(128, 128) bytes); bias (128) fp32 or null; residual or null.
- * bf16, Cin = Cout = 128 only: everything else runs mmgt_groupnorm -> mmgt_conv3x3. */
+/* GroupNorm + SiLU + conv3x3 (stride 1, padding 1) in one launch for the VAE's 128- and 256-channel levels (csrc/gnconv.hip; diffusers
+ * `ResnetBlock2D.forward` norm -> nonlinearity -> conv as `AutoencoderKL.decode` runs it for src/pipelines/pipeline_pose2vid_long.py:112-125):
+ *   out[..., 0 .. Cout) = bias + conv3x3( silu( x * scale[n, c] + shift[n, c] ) ) (+ residual[..., 0 .. Cout))
+ * x (nb, H, W, Cin) bf16 channels-last, H and W multiples of 16, smaller than 2 GiB; scale / shift (nb, Cin) fp32 = the tables of
+ * mmgt_groupnorm_affine in ONE allocation (shift = scale + nb * Cin); wimg = packing.pack_gnconv(W) (mmgt_gn_silu_conv3x3_image_bytes(Cin, Cout) bytes); bias (Cout) fp32 or null;
+ * residual / out: bf16 tensors of ldo >= Cout channels per pixel (a 256-wide output = two launches on its 128-channel halves), residual or null.
+ * bf16; (Cin, Cout) = (128, 128), (256, 128), (128, 64: no residual).  Everything else runs mmgt_groupnorm -> mmgt_conv3x3. */
 long mmgt_gn_silu_conv3x3_image_bytes(int cin, int cout);
 int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const float* shift, const void* wimg, const float* bias, const void* residual, void* out,
-                         int nb, int H, int W, int cin, int cout, int dtype, void* stream);
+                         int nb, int H, int W, int cin, int cout, int ldo, int dtype, void* stream);
 
 /* ---- conditioning producers and the output path on the device; uint8 image buffers are device pointers.
  * blur_mask: (frames, H, W) u8 -> (frames, 64, 64) u8 = cv2.resize(64x64, bilinear) -> cv2.GaussianBlur(ksize, sigma from ksize,

@@ -50,6 +50,7 @@ struct GcArgs {
   const bf16_t* res;     // (nb, H, W, Cout) or null
   bf16_t* out;           // (nb, H, W, Cout)
   int nb, H, W, tiles_x, tiles_per_img, ntiles;
+  int ldo;               // channels per pixel of out / residual (>= Cout: a launch may write a 128-channel half of a wider tensor)
 };
 
 __device__ __forceinline__ acc4 gc_mma(s16x8 a, s16x8 b, acc4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
@@ -109,17 +110,14 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
   const int oct = tid & 15;
   u32x4 hv[GC_NVL];
   unsigned hmask = 0;                                      // bit i: vector i lies inside the image
-  // scale | shift of the (image, phase) of the halo in flight: requested with the halo by wave 0 (one 16-byte vector per lane = the 256 floats),
-  // put into LDS once it has landed (half-tap 5), read from there by every lane for its 8 channels
-  u32x4 tabv = (u32x4)(0u);
+  // scale | shift of the (image, phase) of the halo in flight: ONE LDS-DMA piece of wave 0 (lanes 0 .. 31: 128 scales, lanes 32 .. 63: 128 shifts;
+  // the two tables are one allocation, shift = scale + nb Cin), issued with the halo loads and published by the barrier of half-tap 5
+  const __amdgpu_buffer_rsrc_t rT = dma_rsrc(a.scale);
   int iter_ = 0;
   auto load_halo = [&](int v, int ph) {
     int n, ty, tx;
     decode(v, n, ty, tx);
-    {
-      const float* pt = (lane < 32 ? a.scale : a.shift) + (long)n * CIN + ph * GC_PC + (lane & 31) * 4;
-      tabv = wid == 0 ? *reinterpret_cast<const u32x4*>(pt) : tabv;
-    }
+    if (wid == 0) blds16(rT, (unsigned)((((lane >> 5) * a.nb + n) * CIN + ph * GC_PC + (lane & 31) * 4) * 4), 0, smem + GC_L_TAB);
     hmask = 0;
     int p0 = tid >> 4, o16 = oct * 16 + ph * (GC_PC * 2);
     asm volatile("" : "+v"(p0), "+v"(o16));                 // opaque: the per-vector coordinates are recomputed here, not kept in 30 registers across the tile
@@ -133,9 +131,6 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
       if (!(ABL & 128) || iter_ == 0) hv[i] = __builtin_amdgcn_raw_buffer_load_b128(rX, (int)(ok ? off : DMA_POISON), 0, 0);
       hmask |= ok ? 1u << i : 0u;
     }
-  };
-  auto write_tab = [&]() {
-    if (wid == 0) *reinterpret_cast<u32x4*>(smem + GC_L_TAB + lane * 16) = tabv;
   };
   // dwords J0 .. J0 + NJ - 1 of hv[I] <- bf16( silu( . * scale + shift ) ), zeros outside the image.  Branch-free (a select on the mask made hipcc
   // branch around the transcendentals, one basic block per pair, nothing interleaved with the MFMAs)
@@ -195,8 +190,7 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
   if (my_units > 0) {
     load_halo(blockIdx.x, 0);
     for (int g = 0; g < GC_NSLOT - 1; ++g) issue_w(g);
-    write_tab();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
+    wait_vmcnt<(GC_NSLOT - 1) * PPW>();                    // the table (and the halo) have landed
     __builtin_amdgcn_s_barrier();
     gc_for<0, GC_NVL>([&](auto ic) { norm_vec(ic); });
     write_halo();
@@ -227,12 +221,28 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
 #pragma unroll
         for (int i = 0; i < RT; ++i) acc[i][j] = b;
       }
+      if constexpr (RES && NPH > 1) {
+        // two phases: the residual enters HERE, in the accumulators' own layout (4 channels = 8 bytes per tile), not in the epilogue -- there
+        // is no register to spare for the epilogue's vectors while the accumulators live across the phase loop
+        const unsigned roff = (unsigned)((((n * a.H + ty * GC_T + RT * wm) * a.W + tx * GC_T + lm) * a.ldo + wn * 64 + 4 * lq) * 2);
+        const int rrow = a.W * a.ldo * 2;
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const u32x2 rr = __builtin_amdgcn_raw_buffer_load_b64(rR, (int)roff + 32 * j, i * rrow, 0);
+            acc[i][j][0] += gc_lo(rr[0]);
+            acc[i][j][1] += gc_hi(rr[0]);
+            acc[i][j][2] += gc_lo(rr[1]);
+            acc[i][j][3] += gc_hi(rr[1]);
+          }
+      }
     }
 
     // residual vectors of the epilogue (the lane's 8 channels after the swap there), requested under the tile's last MFMAs (earlier they do not fit the register file)
     const int cofs = wn * 64 + 16 * (lq & 1) + 8 * (lq >> 1);
-    const unsigned eoff = (unsigned)((((n * a.H + ty * GC_T + RT * wm) * a.W + tx * GC_T + lm) * COUT + cofs) * 2);   // byte offset of (row 0, pair 0)
-    const int erow = a.W * COUT * 2;                                                                                // bytes per image row
+    const unsigned eoff = (unsigned)((((n * a.H + ty * GC_T + RT * wm) * a.W + tx * GC_T + lm) * a.ldo + cofs) * 2);   // byte offset of (row 0, pair 0)
+    const int erow = a.W * a.ldo * 2;                                                                                // bytes per image row
     u32x4 rv[RES ? RT : 1][2];
 
     gc_for<0, GC_NSTEP>([&](auto sc_) {
@@ -260,25 +270,23 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
       // ---- hand-over: half-tap gstep + 1 has landed (this wave's pieces; the barrier collects the others').  vmcnt retires in order, so the
       // count is the operations YOUNGER than those pieces: the pieces of half-tap gstep + 2, plus -- half-taps 0, 1 behind an epilogue -- its
       // stores (and the residual loads of half-tap 17), plus -- half-taps 3, 4 -- the halo loads issued in half-tap 2.
-      constexpr int NST = 2 * RT, NHL = GC_NVL;   // (wave 0 also requested the table: it waits for one operation more than it must)
+      constexpr int NST = 2 * RT, NHL = GC_NVL;   // (wave 0 also issued the table piece: it waits for one operation more than it must)
       if constexpr (ABL & (2 | 8)) {
       } else if constexpr (S <= 1) {
-        constexpr int NRL = RES ? 2 * RT : 0;
+        constexpr int NRL = RES && NPH == 1 ? 2 * RT : 0;
         if (stored) wait_vmcnt<PPW + NST + NRL>(); else wait_vmcnt<PPW>();
       } else if constexpr (S == 3 || S == 4) {
         if (has_next) wait_vmcnt<PPW + NHL>(); else wait_vmcnt<PPW>();
       } else {
         wait_vmcnt<PPW>();
       }
-      if constexpr (S == 5) {                              // (the wait above has seen the halo loads land; this barrier publishes the table)
-        if (has_next) { write_tab(); __builtin_amdgcn_s_waitcnt(0xC07F); }
-      }
+      // (half-tap 5: the wait above has seen the halo loads and the table piece land; this barrier publishes the table)
       if constexpr (!(ABL & 32)) __builtin_amdgcn_s_barrier();
       if constexpr (!(ABL & 2)) issue_w(gstep + GC_NSLOT - 1);   // into the slot half-tap gstep - 1 left
       if constexpr (S == 2) {
         if (has_next) { iter_ = 1; load_halo(nvt, nph); }
       }
-      if constexpr (S == GC_NSTEP - 1 && RES) {
+      if constexpr (S == GC_NSTEP - 1 && RES && NPH == 1) {
         if (last_ph) {
 #pragma unroll
           for (int i = 0; i < RT; ++i)
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
           const acc4 x = acc[i][2 * jp], y = acc[i][2 * jp + 1];
-          if (!RES) {
+          if (!(RES && NPH == 1)) {
             const auto s01 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[0], x[1]), pack_bf16x2(y[0], y[1]), false, false);
             const auto s23 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[2], x[3]), pack_bf16x2(y[2], y[3]), false, false);
             __builtin_amdgcn_raw_buffer_store_b128((u32x4){s01[0], s23[0], s01[1], s23[1]}, rO, (int)eoff + 64 * jp, i * erow, 0);
@@ -359,19 +367,19 @@ int g_gnconv_abl = 0;
 void mmgt_gnconv_set_abl(int v) { g_gnconv_abl = v; }
 
 // x (nb, H, W, Cin) bf16 channels-last, H and W multiples of 16; scale / shift (nb, Cin) fp32 (mmgt_groupnorm_affine); wimg = pack_gnconv
-// image of the (Cout, Cin, 3, 3) weight; bias (Cout) fp32 or null; residual (nb, H, W, Cout) bf16 or null; out (nb, H, W, Cout) bf16.
-// (Cin, Cout) = (128, 128), (256, 128), (128, 64); the residual with (128, 128) only.
+// image of the (Cout, Cin, 3, 3) weight; bias (Cout) fp32 or null; residual / out: (nb, H, W, ldo) bf16 tensors of which this launch reads /
+// writes channels 0 .. Cout - 1 of the pointers it is given (ldo >= Cout, a multiple of 8: a 256-wide output runs as two launches on its
+// 128-channel halves); residual may be null.  (Cin, Cout) = (128, 128), (256, 128), (128, 64); the residual with Cout = 128 only.
 extern "C" int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const float* shift, const void* wimg, const float* bias, const void* residual,
-                                    void* out, int nb, int H, int W, int cin, int cout, int dtype, void* stream) {
+                                    void* out, int nb, int H, int W, int cin, int cout, int ldo, int dtype, void* stream) {
   MMGT_CHECK(x && scale && shift && wimg && out && nb > 0 && H > 0 && W > 0, "gn_silu_conv3x3: bad arguments");
   MMGT_CHECK(dtype == MMGT_BF16, "gn_silu_conv3x3: bf16 only");
   const bool s128 = cin == 128 && cout == 128, s256 = cin == 256 && cout == 128, s64 = cin == 128 && cout == 64;
-  MMGT_CHECK(s128 || ((s256 || s64) && !residual), "gn_silu_conv3x3: (Cin, Cout) = (128, 128), or (256, 128) / (128, 64) without residual (got %d -> %d)", cin, cout);
+  MMGT_CHECK(s128 || s256 || (s64 && !residual), "gn_silu_conv3x3: (Cin, Cout) = (128, 128), (256, 128), or (128, 64) without residual (got %d -> %d)", cin, cout);
+  MMGT_CHECK(shift == scale + (long)nb * cin, "gn_silu_conv3x3: scale and shift must be one allocation, shift = scale + nb * Cin (mmgt_amd/hip.py::groupnorm_affine)");
+  MMGT_CHECK(ldo >= cout && ldo % 8 == 0, "gn_silu_conv3x3: ldo = %d must be a multiple of 8 and >= Cout", ldo);
   MMGT_CHECK(H % GC_T == 0 && W % GC_T == 0, "gn_silu_conv3x3: H and W must be multiples of 16 (got %d x %d)", H, W);
-  MMGT_CHECK((long)nb * H * W * cin * 2 < (1l << 31), "gn_silu_conv3x3: x, residual and out must be smaller than 2 GiB each");
-  MMGT_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)wimg % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)residual % 16) == 0 &&
-                 ((uintptr_t)scale % 16) == 0 && ((uintptr_t)shift % 16) == 0,
-             "gn_silu_conv3x3: pointers must be 16-byte aligned");
+  MMGT_CHECK((long)nb * H * W * cin * 2 < (1l << 31) && (long)nb * H * W * ldo * 2 < (1l << 31), "gn_silu_conv3x3: x, residual and out must be smaller than 2 GiB each");
   GcArgs a;
   a.x = reinterpret_cast<const bf16_t*>(x);
   a.scale = scale;
@@ -386,6 +394,7 @@ extern "C" int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const flo
   a.tiles_x = W / GC_T;
   a.tiles_per_img = (H / GC_T) * (W / GC_T);
   a.ntiles = nb * a.tiles_per_img;
+  a.ldo = ldo;
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
@@ -408,7 +417,7 @@ extern "C" int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const flo
     return 0;
   };
   int rc;
-  if (s256) rc = go(gnconv_kernel<2, 128, false, 0>);
+  if (s256) rc = residual ? go(gnconv_kernel<2, 128, true, 0>) : go(gnconv_kernel<2, 128, false, 0>);
   else if (s64) rc = go(gnconv_kernel<1, 64, false, 0>);
   else if (residual) rc = go(gnconv_kernel<1, 128, true, 0>);
   else switch (g_gnconv_abl) {

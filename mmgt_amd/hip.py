@@ -68,7 +68,7 @@ _SIGS = {
     "mmgt_rowgemm320": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                 c_long, c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_gn_silu_conv3x3_image_bytes": (c_long, [c_int, c_int]),
-    "mmgt_gn_silu_conv3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_gn_silu_conv3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_temporal_leg320_image_bytes": (c_long, []),
     "mmgt_temporal_leg320": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int,
                                      c_void_p]),
@@ -329,48 +329,57 @@ def groupnorm_affine(x, gamma, beta, groups, eps):
     NB, HW, C = x.shape
     chunks = lib().mmgt_groupnorm_chunks(HW)
     ws = torch.empty((NB * chunks * groups * 2,), device=x.device, dtype=torch.float32)
-    scale = torch.empty((NB, C), device=x.device, dtype=torch.float32)
-    shift = torch.empty((NB, C), device=x.device, dtype=torch.float32)
+    tab = torch.empty((2, NB, C), device=x.device, dtype=torch.float32)       # one allocation: gn_silu_conv3x3 fetches scale | shift rows with one descriptor
+    scale, shift = tab[0], tab[1]
     _check(lib().mmgt_groupnorm_affine(_ptr(x), C, _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), _ptr(ws), _ptr(scale), _ptr(shift),
                                        NB, HW, groups, eps, dtype_code(x.dtype), _stream()), "mmgt_groupnorm_affine")
     return scale, shift
 
 
 def gn_silu_conv3x3_supported(dtype, cin, cout, H, W, residual=False):
-    return (dtype == torch.bfloat16 and ((cin, cout) == (128, 128) or ((cin, cout) in ((256, 128), (128, 64)) and not residual))
+    """(Cin, Cout) = (128, 128), (256, 128), (256, 256: two launches on the halves of the output channels), (128, 64: no residual)"""
+    return (dtype == torch.bfloat16 and ((cin, cout) in ((128, 128), (256, 128), (256, 256)) or ((cin, cout) == (128, 64) and not residual))
             and H % 16 == 0 and W % 16 == 0)
 
 
 def gn_silu_conv3x3_tables(x, scale, shift, wimg, cout, bias=None, residual=None, out=None):
-    """bias + conv3x3(silu(x * scale[n, c] + shift[n, c])) (+ residual) in one launch (csrc/gnconv.hip): x (NB, H, W, Cin) bf16 channels-last,
-    scale / shift (NB, Cin) fp32 (the tables of `groupnorm_affine`), wimg = packing.pack_gnconv(weight (cout, Cin, 3, 3))."""
+    """bias + conv3x3(silu(x * scale[n, c] + shift[n, c])) (+ residual) (csrc/gnconv.hip): x (NB, H, W, Cin) bf16 channels-last, scale / shift
+    (NB, Cin) fp32 (the tables of `groupnorm_affine`), wimg = packing.pack_gnconv(weight (cout, Cin, 3, 3)): one launch per 128 output channels."""
     _dev(x, scale, shift, wimg, bias, residual, out)
     assert x.dim() == 4 and x.is_contiguous()
     NB, H, W, C = x.shape
     assert gn_silu_conv3x3_supported(x.dtype, C, cout, H, W, residual is not None) and x.numel() * x.element_size() <= DMA_LIMIT
     assert scale.shape == (NB, C) and shift.shape == (NB, C) and scale.dtype == torch.float32 and shift.dtype == torch.float32
     assert scale.is_contiguous() and shift.is_contiguous()
-    assert wimg.dtype == torch.uint8 and wimg.is_contiguous() and wimg.numel() == lib().mmgt_gn_silu_conv3x3_image_bytes(C, cout)
+    if shift.data_ptr() != scale.data_ptr() + 4 * NB * C:                     # the kernel wants the two tables in one allocation
+        tab = torch.stack([scale, shift])
+        scale, shift = tab[0], tab[1]
+    cl = min(cout, 128)                                                # output channels per launch
+    per = lib().mmgt_gn_silu_conv3x3_image_bytes(C, cl)
+    assert wimg.dtype == torch.uint8 and wimg.is_contiguous() and wimg.numel() == per * (cout // cl)
     if out is None:
         out = torch.empty((NB, H, W, cout), device=x.device, dtype=x.dtype)
-    assert out.shape == (NB, H, W, cout) and out.is_contiguous() and out.dtype == x.dtype
+    assert out.shape == (NB, H, W, cout) and out.is_contiguous() and out.dtype == x.dtype and out.numel() * 2 <= DMA_LIMIT
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype
+    bias = _f32(bias, "bias")
     if bias is not None:
         assert bias.numel() >= cout
-    _check(lib().mmgt_gn_silu_conv3x3(_ptr(x), _ptr(scale), _ptr(shift), _ptr(wimg), _ptr(_f32(bias, "bias")), _ptr(residual), _ptr(out),
-                                      NB, H, W, C, cout, dtype_code(x.dtype), _stream()), "mmgt_gn_silu_conv3x3")
+    for h in range(cout // cl):
+        _check(lib().mmgt_gn_silu_conv3x3(_ptr(x), _ptr(scale), _ptr(shift), wimg.data_ptr() + h * per, None if bias is None else bias.data_ptr() + 4 * cl * h,
+                                          None if residual is None else residual.data_ptr() + 2 * cl * h, out.data_ptr() + 2 * cl * h,
+                                          NB, H, W, C, cl, cout, dtype_code(x.dtype), _stream()), "mmgt_gn_silu_conv3x3")
     return out
 
 
 def gn_silu_conv3x3(x, gamma, beta, groups, eps, wimg, cout, bias=None, residual=None, out=None):
-    """conv3x3(silu(GroupNorm(x))) (+ residual): ONE pass over x for the statistics (`groupnorm_affine`) and ONE fused launch for the rest.
-    x (NB, H, W, Cin) bf16 channels-last -> (NB, H, W, cout); (Cin, cout) = (128, 128), (256, 128), (128, 64)."""
+    """conv3x3(silu(GroupNorm(x))) (+ residual): ONE pass over x for the statistics (`groupnorm_affine`) and one fused launch per 128 output
+    channels for the rest.  x (NB, H, W, Cin) bf16 channels-last -> (NB, H, W, cout)."""
     assert x.dim() == 4 and x.is_contiguous()
     NB, H, W, C = x.shape
     if out is None:
         out = torch.empty((NB, H, W, cout), device=x.device, dtype=x.dtype)
-    step = max(1, DMA_LIMIT // (H * W * C * x.element_size()))       # 32-bit buffer offsets: runs of whole images below 2 GiB
+    step = max(1, DMA_LIMIT // (H * W * max(C, cout) * x.element_size()))       # 32-bit buffer offsets: runs of whole images below 2 GiB
     for n0 in range(0, NB, step):
         n1 = min(NB, n0 + step)
         scale, shift = groupnorm_affine(x[n0:n1].view(n1 - n0, H * W, C), gamma, beta, groups, eps)

@@ -171,17 +171,20 @@ def pack_tleg(wq, wk, wv, wo):
 
 
 def pack_gnconv(w):
-    """A (Cout, Cin, 3, 3) conv weight, (Cin, Cout) = (128, 128), (256, 128) or (128, 64) -> the fragment-major image of csrc/gnconv.hip
-    (mmgt_gn_silu_conv3x3), a uint8 tensor of Cin / 128 phases x 18 half-taps of 128 Cout bytes:
-    [ph][tap = 3 ky + kx][kh][ks2][ct][lane][8 bf16] = W[16 ct + (lane & 15)][128 ph + 64 kh + 32 ks2 + 8 (lane >> 4) + j][ky][kx] -- 1-KiB fragments of
-    v_mfma_f32_16x16x32_bf16 (lane (lm, lq) owns row lm of the 16-channel tile, reduction slots 8 lq .. 8 lq + 7 of the k-step)."""
+    """A (Cout, Cin, 3, 3) conv weight, (Cin, Cout) = (128, 128), (256, 128), (256, 256) or (128, 64) -> the fragment-major image of
+    csrc/gnconv.hip (mmgt_gn_silu_conv3x3), a uint8 tensor: per block of min(Cout, 128) output channels (one launch each), Cin / 128 phases x 18
+    half-taps of 128 x block bytes:
+    [blk][ph][tap = 3 ky + kx][kh][ks2][ct][lane][8 bf16] = W[128 blk + 16 ct + (lane & 15)][128 ph + 64 kh + 32 ks2 + 8 (lane >> 4) + j][ky][kx] --
+    1-KiB fragments of v_mfma_f32_16x16x32_bf16 (lane (lm, lq) owns row lm of the 16-channel tile, reduction slots 8 lq .. 8 lq + 7 of the k-step)."""
     cout, cin = w.shape[0], w.shape[1]
-    assert tuple(w.shape) == (cout, cin, 3, 3) and (cin, cout) in ((128, 128), (256, 128), (128, 64))
+    assert tuple(w.shape) == (cout, cin, 3, 3) and (cin, cout) in ((128, 128), (256, 128), (256, 256), (128, 64))
     dev = w.device
+    cl = min(cout, 128)
     lane = torch.arange(64, device=dev)
-    rows = 16 * torch.arange(cout // 16, device=dev)[:, None] + (lane & 15)[None, :]                          # (ct, lane)
+    rows = 16 * torch.arange(cl // 16, device=dev)[:, None] + (lane & 15)[None, :]                           # (ct, lane)
     kk = torch.arange(4, device=dev)                                                                         # k-steps of 32 of a phase = (kh, ks2)
     cols = 32 * kk[:, None, None] + 8 * (lane >> 4)[None, :, None] + torch.arange(8, device=dev)[None, None, :]   # (k, lane, j)
     wt = w.to(torch.bfloat16).permute(2, 3, 0, 1).reshape(9, cout, cin)                                      # (tap, cout, cin)
-    img = torch.stack([wt[:, rows[None, :, :, None], 128 * ph + cols[:, None, :, :]] for ph in range(cin // 128)])   # (ph, tap, k, ct, lane, j)
+    img = torch.stack([torch.stack([wt[:, cl * blk + rows[None, :, :, None], 128 * ph + cols[:, None, :, :]] for ph in range(cin // 128)])
+                       for blk in range(cout // cl)])                                                        # (blk, ph, tap, k, ct, lane, j)
     return img.contiguous().view(torch.uint8).reshape(-1)

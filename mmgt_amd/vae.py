@@ -165,8 +165,8 @@ class AutoencoderKL:
                 cin_pad, cout_pad = round_up(wt.shape[1], 64), round_up(wt.shape[0], 64)
                 w[p + ".w"] = self._t(pack_conv3x3(wt, cin_pad, cout_pad))
                 w[p + ".bias"] = self._f(pad_rows(b, cout_pad))
-                if self._dtype == torch.bfloat16 and (wt.shape[1], cout_pad) in ((128, 128), (256, 128), (128, 64)):
-                    # the 512 x 512 level: GroupNorm + SiLU + conv in one launch (csrc/gnconv.hip) wherever a GroupNorm feeds this conv
+                if self._dtype == torch.bfloat16 and (wt.shape[1], cout_pad) in ((128, 128), (256, 128), (256, 256), (128, 64)):
+                    # the 512 x 512 and 256 x 256 levels: GroupNorm + SiLU + conv fused (csrc/gnconv.hip) wherever a GroupNorm feeds this conv
                     wpad = torch.zeros((cout_pad, wt.shape[1], 3, 3), device=self._device, dtype=torch.float32)
                     wpad[:wt.shape[0]] = wt.to(self._device, torch.float32)
                     w[p + ".gimg"] = pack_gnconv(wpad)

@@ -51,21 +51,42 @@ def test_gnconv_tables_vs_fp64(nb, H, W, res):
     assert torch.equal(out, out2)                                                     # reproducible
 
 
-@pytest.mark.parametrize("cin,cout", [(256, 128), (128, 64)])
+@pytest.mark.parametrize("cin,cout,res", [(256, 128, False), (128, 64, False), (256, 256, True), (256, 128, True)])
 @pytest.mark.parametrize("nb,H,W", [(1, 16, 16), (3, 32, 48), (300, 16, 16)])
-def test_gnconv_other_shapes_vs_fp64(cin, cout, nb, H, W):
+def test_gnconv_other_shapes_vs_fp64(cin, cout, res, nb, H, W):
     """Cin = 256 (two phases per tile: the halves of the input channels take turns in the LDS halo and accumulate into the same registers) and
-    Cout = 64 (8 x 1 wave grid), the VAE's 256 -> 128 conv and conv_out."""
+    Cout = 64 (8 x 1 wave grid), Cout = 256 (two launches on the halves of an output with 256 channels per pixel): the VAE's 256 -> 128 conv,
+    conv_out and the 256 x 256 level."""
     from mmgt_amd import hip
     from mmgt_amd.packing import pack_gnconv
-    x, w, b, r, scale, shift = _case(nb, H, W, 200 + nb + cin, False, cin=cin, cout=cout)
-    out = hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), cout, b)
-    ref = _ref(x, w, b, None, scale, shift)
+    x, w, b, r, scale, shift = _case(nb, H, W, 200 + nb + cin, res, cin=cin, cout=cout)
+    out = hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), cout, b, r)
+    ref = _ref(x, w, b, r, scale, shift)
     d = (out.double() - ref).abs()
     tol = 2.0 ** -8 * ref.abs() + 6e-3
     assert (d <= tol).all(), (d.max().item(), (d / tol).max().item(), (d > tol).sum().item())
     assert d.mean().item() < 2e-3
-    assert torch.equal(out, hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), cout, b))
+    assert torch.equal(out, hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), cout, b, r))
+
+
+@pytest.mark.parametrize("cin,cout,nb,H,W", [(128, 128, 300, 16, 16), (256, 128, 300, 16, 16), (256, 256, 8, 64, 64)])
+def test_gnconv_residual_repeated_runs(cin, cout, nb, H, W):
+    """The residual paths (epilogue vectors requested under the last MFMAs for Cin = 128; accumulator initialisation for Cin = 256) over many
+    tiles per workgroup, ten times into a sentinel-filled output: every run equals the launch without residual + the residual added outside
+    to within the one bf16 rounding that differs.  (A first form of the two-phase path returned stale registers in 1 of ~3 runs.)"""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_gnconv
+    x, w, b, r, scale, shift = _case(nb, H, W, 300 + cin + cout, True, cin=cin, cout=cout)
+    wimg = pack_gnconv(w)
+    good = hip.gn_silu_conv3x3_tables(x, scale, shift, wimg, cout, b, None).float() + r.float()
+    first = None
+    for k in range(10):
+        out = torch.full((nb, H, W, cout), 777.0, device=dev(), dtype=torch.bfloat16)
+        hip.gn_silu_conv3x3_tables(x, scale, shift, wimg, cout, b, r, out=out)
+        d = (out.float() - good).abs()
+        assert (d <= 2.0 ** -6 * good.abs() + 4e-2).all(), (k, d.max().item(), (d > 0.1).sum().item())
+        first = out if first is None else first
+        assert torch.equal(out, first), k
 
 
 def test_gnconv_no_bias_and_zero_padding():
@@ -117,8 +138,8 @@ def test_gnconv_rejects_unsupported():
     x = torch.zeros((1, 24, 16, 128), device=dev(), dtype=torch.bfloat16)
     assert not hip.gn_silu_conv3x3_supported(torch.bfloat16, 128, 128, 24, 16)
     assert not hip.gn_silu_conv3x3_supported(torch.float32, 128, 128, 32, 32)
-    assert not hip.gn_silu_conv3x3_supported(torch.bfloat16, 256, 256, 32, 32)
-    assert not hip.gn_silu_conv3x3_supported(torch.bfloat16, 256, 128, 32, 32, residual=True)
+    assert not hip.gn_silu_conv3x3_supported(torch.bfloat16, 512, 256, 32, 32)
+    assert not hip.gn_silu_conv3x3_supported(torch.bfloat16, 128, 64, 32, 32, residual=True)
     with pytest.raises(AssertionError):
         hip.gn_silu_conv3x3_tables(x, torch.ones((1, 128), device=dev()), torch.zeros((1, 128), device=dev()),
                                    torch.zeros(18 * 16384, device=dev(), dtype=torch.uint8), 128)
