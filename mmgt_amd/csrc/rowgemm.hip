@@ -152,7 +152,13 @@ void rowgemm320_kernel(const RowGemmArgs a) {
     __builtin_amdgcn_s_barrier();
   };
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((long)a.M * a.ldo * 2), 0x00020000);
-  const unsigned obase = (unsigned)(row * a.ldo + 8 * hh) * 2u;          // (rows >= M: beyond num_records -> dropped)
+  // Store layout of a normal tile (round 5).  After the v_permlane32_swap of the epilogue lane (r, hh) owns 8 columns of ITS row: an instruction
+  // then covers 32 rows x 32 bytes = 32 quarter lines, and the CU's address path -- which the weight DMA shares -- pays per line touched
+  // (ablations: the launch at N = 960 is 167 us, 123 without its stores, 98 without its MFMAs: the stores and the MFMAs did not overlap).
+  // v_permlane16_swap of the two 16-byte vectors of a tile hands lanes r >= 16 the SECOND vector of row r - 16 and lanes r < 16 the FIRST vector
+  // of row r + 16: store A = rows 0 .. 15 x 64 bytes, store B = rows 16 .. 31 x 64 bytes -- 16 half lines per instruction.
+  const unsigned obase = (unsigned)((row0 + wid * 32 + (r & 15)) * a.ldo + 16 * (r >> 4) + 8 * hh) * 2u;   // store A; B: + 16 rows (rows >= M: beyond num_records -> dropped)
+  const unsigned ostep16 = (unsigned)(16 * a.ldo) * 2u;
   const bf16_t* rr = RES ? a.res + rowc * a.ldr + 8 * hh : nullptr;
   // transposed tiles: this lane's column is c = r, its 8-row groups start at token tok0 + 16 (k / 2) + 8 hh
   const long bt = (unsigned)row0 / (unsigned)a.n_tok;            // (M < 2^31: 32-bit division)
@@ -211,6 +217,7 @@ void rowgemm320_kernel(const RowGemmArgs a) {
       }
       // ---- epilogue.  Register group k (registers 4 k .. 4 k + 3) is D rows 8 k + 4 hh + (0..3); v_permlane32_swap of groups (k, k + 1)
       // gives lane hh = 0 rows 8 k .. 8 k + 7 and lane hh = 1 rows 8 k + 8 .. + 15 (cdna_hip_programming.md T21): 16 bytes per store
+      u32x4 pkv[2];
 #pragma unroll
       for (int k = 0; k < 4; k += 2) {
         float o8[8];
@@ -226,12 +233,21 @@ void rowgemm320_kernel(const RowGemmArgs a) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) o8[e] += bf16_to_f32(r8.e[e]);
         }
-        const u32x4 pk = (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])};
-        if (DBG == 3 && pk[0] != 0x12345678u) continue;      // (ablation: no stores)
+        pkv[k / 2] = (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])};
+      }
+      if (!(DBG == 3 && pkv[0][0] != 0x12345678u)) {             // (DBG 3: ablation without stores)
         if constexpr (!TR) {
-          __builtin_amdgcn_raw_buffer_store_b128(pk, ro, (int)(obase + 2u * (32 * t + 8 * k)), 0, 0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(pkv[0][e], pkv[1][e], false, false);
+            pkv[0][e] = sw[0];
+            pkv[1][e] = sw[1];
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(pkv[0], ro, (int)(obase + 2u * (32 * t)), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(pkv[1], ro, (int)(obase + ostep16 + 2u * (32 * t)), 0, 0);
         } else {
-          *reinterpret_cast<u32x4*>(ot + (long)(32 * (t - nt1)) * a.npad + 8 * k) = pk;
+          *reinterpret_cast<u32x4*>(ot + (long)(32 * (t - nt1)) * a.npad) = pkv[0];
+          *reinterpret_cast<u32x4*>(ot + (long)(32 * (t - nt1)) * a.npad + 16) = pkv[1];
         }
       }
     };
