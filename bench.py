@@ -315,6 +315,18 @@ def extras(pipe, unet, dev, dtype):
     by = 3.0 * x.numel() * 2
     kern = [{"kernel": "groupnorm+silu 8x262144x128 (VAE up_blocks.3)", "bound": "hbm", "ms": gms, "achieved": by / gms / 1e6, "peak": 8000.0,
              "unit": "GB/s", "frac": by / gms / 1e6 / 8000.0}]
+    if dtype == torch.bfloat16:
+        # the fused GroupNorm-apply + SiLU + conv3x3 128 -> 128 launch of the same level (csrc/gnconv.hip), against the MFMA roofline
+        from mmgt_amd.packing import pack_gnconv
+        xg = x.view(8, 512, 512, 128)
+        sc_, sh_ = hip.groupnorm_affine(x, g, b, 32, 1e-6)
+        wg = pack_gnconv(hash_uniform("bench.vae_gw", (128, 128, 3, 3), 0.03).to(dev))
+        og = o.view(8, 512, 512, 128)
+        cms = _time_ms(lambda: hip.gn_silu_conv3x3_tables(xg, sc_, sh_, wg, 128, None, None, out=og), reps=5, warm=2)
+        fl = 2.0 * x.shape[0] * x.shape[1] * 128 * 9 * 128
+        kern.append({"kernel": "gn_silu_conv3x3 8x512x512 128->128 (GroupNorm apply + SiLU + conv, one launch)", "bound": "mfma", "ms": cms,
+                     "achieved": fl / cms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / cms / 1e9 / PEAK_BF16_TFLOPS})
+        del xg, og, wg
     del x, o
     if dtype == torch.bfloat16:
         qp = hash_uniform("bench.vae_qp", (4096, 1536), 1.0).to(dev).to(dtype)

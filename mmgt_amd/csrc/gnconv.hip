@@ -408,30 +408,34 @@ extern "C" int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const flo
   int gx = ncu / 8 * 8;
   if (gx > a.ntiles) gx = a.ntiles;
   hipStream_t s = (hipStream_t)stream;
-  auto go = [&](auto kern) -> int {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GC_LDS) != hipSuccess) {
-      mmgt_set_error("gn_silu_conv3x3: cannot reserve %d bytes of LDS", GC_LDS);
-      return 2;
+  static bool ready[32] = {};                              // LDS attribute set, per kernel instantiation (slot = the call site below)
+  auto go = [&](void (*kern)(const GcArgs), int slot) -> int {
+    if (!ready[slot]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GC_LDS) != hipSuccess) {
+        mmgt_set_error("gn_silu_conv3x3: cannot reserve %d bytes of LDS", GC_LDS);
+        return 2;
+      }
+      ready[slot] = true;
     }
     hipLaunchKernelGGL(kern, dim3(gx), dim3(512), GC_LDS, s, a);
     return 0;
   };
   int rc;
-  if (s256) rc = residual ? go(gnconv_kernel<2, 128, true, 0>) : go(gnconv_kernel<2, 128, false, 0>);
-  else if (s64) rc = go(gnconv_kernel<1, 64, false, 0>);
-  else if (residual) rc = go(gnconv_kernel<1, 128, true, 0>);
+  if (s256) rc = residual ? go(gnconv_kernel<2, 128, true, 0>, 0) : go(gnconv_kernel<2, 128, false, 0>, 1);
+  else if (s64) rc = go(gnconv_kernel<1, 64, false, 0>, 2);
+  else if (residual) rc = go(gnconv_kernel<1, 128, true, 0>, 3);
   else switch (g_gnconv_abl) {
-    case 1: rc = go(gnconv_kernel<1, 128, false, 1>); break;
-    case 2: rc = go(gnconv_kernel<1, 128, false, 2>); break;
-    case 4: rc = go(gnconv_kernel<1, 128, false, 4>); break;
-    case 8: rc = go(gnconv_kernel<1, 128, false, 8>); break;
-    case 16: rc = go(gnconv_kernel<1, 128, false, 16>); break;
-    case 32: rc = go(gnconv_kernel<1, 128, false, 32>); break;
-    case 6: rc = go(gnconv_kernel<1, 128, false, 6>); break;
-    case 22: rc = go(gnconv_kernel<1, 128, false, 22>); break;
-    case 64: rc = go(gnconv_kernel<1, 128, false, 64>); break;
-    case 128: rc = go(gnconv_kernel<1, 128, false, 128>); break;
-    default: rc = go(gnconv_kernel<1, 128, false, 0>); break;
+    case 1: rc = go(gnconv_kernel<1, 128, false, 1>, 4); break;
+    case 2: rc = go(gnconv_kernel<1, 128, false, 2>, 5); break;
+    case 4: rc = go(gnconv_kernel<1, 128, false, 4>, 6); break;
+    case 8: rc = go(gnconv_kernel<1, 128, false, 8>, 7); break;
+    case 16: rc = go(gnconv_kernel<1, 128, false, 16>, 8); break;
+    case 32: rc = go(gnconv_kernel<1, 128, false, 32>, 9); break;
+    case 6: rc = go(gnconv_kernel<1, 128, false, 6>, 10); break;
+    case 22: rc = go(gnconv_kernel<1, 128, false, 22>, 11); break;
+    case 64: rc = go(gnconv_kernel<1, 128, false, 64>, 12); break;
+    case 128: rc = go(gnconv_kernel<1, 128, false, 128>, 13); break;
+    default: rc = go(gnconv_kernel<1, 128, false, 0>, 14); break;
   }
   if (rc) return rc;
   MMGT_LAUNCH_CHECK();
