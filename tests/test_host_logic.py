@@ -96,6 +96,23 @@ def test_pack_geglu_and_conv():
     assert p.shape == (64, 3, 3, 64) and torch.equal(p[:5, :, :, :3], cw.permute(0, 2, 3, 1)) and p[5:].abs().sum() == 0
 
 
+def test_pack_gnconv_fragment_image():
+    """The weight image of csrc/gnconv.hip: [block of <= 128 output channels][128-channel phase][tap][k-step of 32][16-channel tile][lane][8] with
+    lane (lm, lq) = row lm of the tile, reduction slots 8 lq .. 8 lq + 7 -- checked entry by entry against the definition."""
+    from mmgt_amd.packing import pack_gnconv
+    g = torch.Generator().manual_seed(3)
+    for cout, cin in ((128, 128), (128, 256), (256, 256), (64, 128)):
+        w = torch.randn((cout, cin, 3, 3), generator=g)
+        img = pack_gnconv(w).view(torch.bfloat16)
+        cl = min(cout, 128)
+        img = img.view(cout // cl, cin // 128, 9, 4, cl // 16, 64, 8)
+        wb = w.to(torch.bfloat16)
+        for (blk, ph, tap, k, ct, lane, j) in [(0, 0, 0, 0, 0, 0, 0), (cout // cl - 1, cin // 128 - 1, 8, 3, cl // 16 - 1, 63, 7), (0, cin // 128 - 1, 4, 2, 1, 37, 5), (cout // cl - 1, 0, 7, 1, 2, 18, 3)]:
+            co, ci = cl * blk + 16 * ct + (lane & 15), 128 * ph + 32 * k + 8 * (lane >> 4) + j
+            assert img[blk, ph, tap, k, ct, lane, j] == wb[co, ci, tap // 3, tap % 3], (cout, cin, blk, ph, tap, k, ct, lane, j)
+        assert img.numel() * 2 == (cout // cl) * (cin // 64) * 9 * 64 * cl * 2
+
+
 def test_synthetic_is_a_pure_function_of_names():
     from mmgt_amd.synthetic import hash_uniform, synth_tensor
     a = hash_uniform("a.weight", (4, 4), 1.0)
