@@ -288,7 +288,14 @@ int mmgt_temporal_leg320(const void* x, void* out, const float* ln_gamma, const 
  * bf16; (Cin, Cout) = (128, 128), (256, 128), (128, 64: no residual).  Everything else runs mmgt_groupnorm -> mmgt_conv3x3. */
 long mmgt_gn_silu_conv3x3_image_bytes(int cin, int cout);
 int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const float* shift, const void* wimg, const float* bias, const void* residual, void* out,
-                         int nb, int H, int W, int cin, int cout, int ldo, int dtype, void* stream);
+                         float* stats, int nb, int H, int W, int cin, int cout, int ldo, int dtype, void* stream);
+/* `stats` (or null; Cout = 128 launches): the launch also writes, per 16 x 16 tile and 4-channel quad of its output, the pair (sum, sum of
+ * squares) of the bf16 values it stores -- [nb * (H / 16) (W / 16)][ldo / 4][2] floats, a launch on the second half of a 256-wide output is handed
+ * stats + 64.  mmgt_gn_stats_finalize folds them (fixed order) into the (scale, shift) tables of the GroupNorm that reads that output, so the
+ * statistics pass of mmgt_groupnorm_affine over the tensor is not needed (resnet.py:20-28 `InflatedGroupNorm` / diffusers GroupNorm semantics:
+ * biased variance over (H W C / G) values, eps inside the root).  scale | shift: one allocation, shift = scale + nb * C. */
+int mmgt_gn_stats_finalize(const float* stats, const float* gamma, const float* beta, float* scale, float* shift, int nb, int tiles, int C, int G,
+                           float eps, void* stream);
 
 /* ---- conditioning producers and the output path on the device; uint8 image buffers are device pointers.
  * blur_mask: (frames, H, W) u8 -> (frames, 64, 64) u8 = cv2.resize(64x64, bilinear) -> cv2.GaussianBlur(ksize, sigma from ksize,

@@ -38,7 +38,7 @@ constexpr int GC_HALO = GC_HP * GC_HP * GC_PSTR;                            // 8
 constexpr int GC_NV = GC_HP * GC_HP * (GC_PC / 8);                          // 16-byte vectors of a halo: 5184 = 10 x 512 + 64
 constexpr int GC_NVL = (GC_NV + 511) / 512;                                 // vectors per lane (the 11th: lanes 0 .. 63 only)
 constexpr int GC_NSLOT = 4, GC_NSTEP = 18;                                  // ring slots; half-taps (64 input channels x Cout) per phase
-constexpr int GC_L_RING = (GC_HALO + 1023) / 1024 * 1024, GC_L_BIAS = GC_L_RING + GC_NSLOT * 16 * 1024, GC_L_TAB = GC_L_BIAS + 128 * 4, GC_LDS = GC_L_TAB + 2 * GC_PC * 4;
+constexpr int GC_L_RING = (GC_HALO + 1023) / 1024 * 1024, GC_L_BIAS = GC_L_RING + GC_NSLOT * 16 * 1024, GC_L_TAB = GC_L_BIAS + 128 * 4, GC_L_STAT = GC_L_TAB + 2 * GC_PC * 4, GC_LDS = GC_L_STAT + 8 * 4 * 8 * 4;
 static_assert(GC_LDS <= 160 * 1024 && 6 + GC_NVL <= GC_NSTEP, "LDS / schedule");
 
 struct GcArgs {
@@ -51,9 +51,18 @@ struct GcArgs {
   bf16_t* out;           // (nb, H, W, Cout)
   int nb, H, W, tiles_x, tiles_per_img, ntiles;
   int ldo;               // channels per pixel of out / residual (>= Cout: a launch may write a 128-channel half of a wider tensor)
+  float* stats;          // or null: per (tile, 4-channel quad of the launch's Cout) the pair (sum, sum of squares) of the STORED values, [tile][ldo / 4][2]
 };
 
-__device__ __forceinline__ acc4 gc_mma(s16x8 a, s16x8 b, acc4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// The MFMA as an asm statement with a TIED accumulator: through the builtin hipcc 7.2 moves accumulator tiles between register ranges near the
+// epilogue and emits v_mfma_f32_16x16x32_bf16 whose vDst PARTIALLY overlaps SrcC (e.g. v[120:123] <- ... + v[122:125]); the ISA wants them
+// identical or disjoint, and the tiles that came out of such an instruction were garbage in the lanes of columns 12 .. 15 in about one run of
+// three (tools/check_mfma_overlap.py scans every object of the library for the pattern; tests/test_host_logic.py runs it).  An asm statement
+// hides the MFMA's result latency from the compiler: `gc_mma_settle` stands in front of every non-MFMA read of the accumulators.
+__device__ __forceinline__ void gc_mma(acc4& c, s16x8 a, s16x8 b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void gc_mma_settle() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory"); }
 __device__ __forceinline__ float gc_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float gc_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
@@ -65,9 +74,12 @@ __device__ __forceinline__ void gc_for(F&& fn) { gc_for_impl<LO>(std::make_integ
 // NPH = Cin / 128 (1, 2); COUT = 128 (8 waves = 4 x 2: 4 image rows x 64 channels each) or 64 (8 x 1: 2 image rows x 64 channels).
 // ABL (mmgt_tune("gnconv_abl", bit), timing only -- results are garbage): 1 no MFMAs, 2 no weight DMA after the prologue, 4 no halo loads /
 // normalisation / LDS writes after the first tile, 8 no hand-over wait, 16 no epilogue (residual loads, stores), 32 no hand-over barrier,
-// 64 halo loads but no normalisation / LDS writes, 128 normalisation / LDS writes but no halo loads
-template <int NPH, int COUT, bool RES, int ABL>
+// 64 halo loads but no normalisation / LDS writes, 128 normalisation / LDS writes but no halo loads.
+// ST: the epilogue also emits, per tile and 4-channel quad, (sum, sum of squares) of the values it stores -- the statistics of the NEXT GroupNorm
+// (mmgt_gn_stats_finalize folds the tiles of an image in a fixed order), so that the pass over the tensor that recomputes them is not needed.
+template <int NPH, int COUT, bool RES, int ABL, bool ST = false>
 __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
+  static_assert(!ST || COUT == 128, "statistics: 128 output channels per launch");
   static_assert((NPH == 1 || NPH == 2) && (COUT == 64 || COUT == 128), "shape");
   constexpr int CIN = GC_PC * NPH, WN = COUT / 64, WM = 8 / WN, RT = GC_T / WM;   // waves along the channels / the rows; image rows per wave
   constexpr int NCT = COUT / 16, SLOT = 64 * COUT * 2, PPW = SLOT / 1024 / 8;     // 16-channel tiles; bytes per half-tap; DMA pieces per wave and half-tap
@@ -82,9 +94,11 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
 
   // XCD-aware tile order (gemm.hip): XCD x = v & 7 walks a contiguous run of the tile sequence, so horizontally adjacent tiles -- which share
   // two halo columns -- are worked on one L2 at about the same time
+  int t_cur = 0;                                           // position of the last decoded tile in the (image, row, column) order
   auto decode = [&](int v, int& n, int& ty, int& tx) {
     const int q = a.ntiles >> 3, r = a.ntiles & 7, xc = v & 7;
     const int t = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (v >> 3);
+    t_cur = t;
     n = t / a.tiles_per_img;
     const int rem = t - n * a.tiles_per_img;
     ty = rem / a.tiles_x;
@@ -132,33 +146,26 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
       hmask |= ok ? 1u << i : 0u;
     }
   };
-  // dwords J0 .. J0 + NJ - 1 of hv[I] <- bf16( silu( . * scale + shift ) ), zeros outside the image.  Branch-free (a select on the mask made hipcc
-  // branch around the transcendentals, one basic block per pair, nothing interleaved with the MFMAs)
-  auto norm_part = [&](auto Ic, auto Jc, auto Nc) {
-    constexpr int I = decltype(Ic)::value, J0 = decltype(Jc)::value, NJ = decltype(Nc)::value;
-    static_assert(J0 % 2 == 0 && NJ % 2 == 0, "pairs of dwords");
+  // dword J of hv[I] <- bf16( silu( . * scale + shift ) ), zeros outside the image.  Branch-free (a select on the mask made hipcc branch around
+  // the transcendentals, one basic block per pair, nothing interleaved with the MFMAs); the table is re-read per dword (two ds_read_b64)
+  // instead of living in 16 registers.
+  auto norm_dword = [&](auto Ic, auto Jc) {
+    constexpr int I = decltype(Ic)::value, J = decltype(Jc)::value;
     const unsigned m = 0u - ((hmask >> I) & 1u);
-    int tofs = GC_L_TAB + 32 * oct;
-    asm volatile("" : "+v"(tofs));                          // opaque: the table is re-read per call (4 ds_read_b128 per vector) instead of living in 16 registers
-#pragma unroll
-    for (int jj = J0; jj < J0 + NJ; jj += 2) {
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(smem + tofs + 8 * jj), sh = *reinterpret_cast<const f32x4*>(smem + tofs + GC_PC * 4 + 8 * jj);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int j = jj + u;
-        // silu(t) = t / (1 + e^-t) with v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE division sequence: 10 issue slots of 4 cycles per
-        // element beside MFMAs that hold the SIMD's vector issue for 8 of their 16 cycles.  Scalar f32 arithmetic on purpose (the file is built
-        // with -fno-slp-vectorize): packed f32 instructions cost ~25 cycles each beside MFMAs (MI355X_MICROARCH.md, per-instruction constants).
-        const float t0 = fmaf(gc_lo(hv[I][j]), sc[2 * u], sh[2 * u]), t1 = fmaf(gc_hi(hv[I][j]), sc[2 * u + 1], sh[2 * u + 1]);
-        const float v0 = t0 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t0 * -1.4426950408889634f));
-        const float v1 = t1 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t1 * -1.4426950408889634f));
-        unsigned pk = pack_bf16x2(v0, v1) & m;
-        asm volatile("" : "+v"(pk));                        // pinned here: hipcc otherwise sinks the arithmetic to the tile's end, where hv is stored
-        hv[I][j] = pk;
-      }
-    }
+    int tofs = GC_L_TAB + 32 * oct + 8 * J;
+    asm volatile("" : "+v"(tofs));                          // (opaque: no common subexpressions across calls)
+    const f32x2 sc = *reinterpret_cast<const f32x2*>(smem + tofs), sh = *reinterpret_cast<const f32x2*>(smem + tofs + GC_PC * 4);
+    // silu(t) = t / (1 + e^-t) with v_exp_f32 / v_rcp_f32 (1 ulp) instead of the IEEE division sequence: 10 issue slots of 4 cycles per
+    // element beside MFMAs that hold the SIMD's vector issue for 8 of their 16 cycles.  Scalar f32 arithmetic on purpose (the file is built
+    // with -fno-slp-vectorize): packed f32 instructions cost ~25 cycles each beside MFMAs (MI355X_MICROARCH.md, per-instruction constants).
+    const float t0 = fmaf(gc_lo(hv[I][J]), sc[0], sh[0]), t1 = fmaf(gc_hi(hv[I][J]), sc[1], sh[1]);
+    const float v0 = t0 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t0 * -1.4426950408889634f));
+    const float v1 = t1 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(t1 * -1.4426950408889634f));
+    unsigned pk = pack_bf16x2(v0, v1) & m;
+    asm volatile("" : "+v"(pk));                            // pinned here (between two MFMA statements): hipcc otherwise sinks the arithmetic to the tile's end, where hv is stored
+    hv[I][J] = pk;
   };
-  auto norm_vec = [&](auto Ic) { norm_part(Ic, std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}); };
+  auto norm_vec = [&](auto Ic) { gc_for<0, 4>([&](auto jc) { norm_dword(Ic, jc); }); };
   const int h_wbase = (tid >> 4) * GC_PSTR + oct * 16;
   auto write_halo = [&]() {
 #pragma unroll
@@ -208,6 +215,7 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
   for (int unit = 0; unit < my_units; ++unit) {
     int n, ty, tx;
     decode(vt, n, ty, tx);
+    const int t_this = t_cur;
     const bool has_next = unit + 1 < my_units && !(ABL & 4);
     const bool last_ph = NPH == 1 || ph == NPH - 1, first_ph = NPH == 1 || ph == 0;
     const int nvt = last_ph ? vt + G : vt, nph = last_ph ? 0 : ph + 1;
@@ -254,19 +262,21 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
       // a vector of the next unit's halo per half-tap, half of it under each k-step's MFMAs (unconditional: without a next unit it works on
       // stale registers; a uniform branch would put it in a basic block of its own, in front of the MFMAs instead of between them)
       constexpr bool NORM = S >= 6 && S < 6 + GC_NVL && !(ABL & 64);
-      if constexpr (NORM) norm_part(std::integral_constant<int, S - 6>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+      // the MFMAs of a k-step (asm statements: their order is the program's), two dwords of the halo vector dealt out between them
+      auto burst = [&](s16x8 (&fw_)[4], s16x8 (&fa_)[RT], auto J0c) {
+        constexpr int J0 = decltype(J0c)::value;
+        gc_for<0, RT>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
 #pragma unroll
-      for (int i = 0; i < RT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if constexpr (!(ABL & 1)) acc[i][j] = gc_mma(fw[0][j], fa[0][i], acc[i][j]); else acc[i][j][0] += __builtin_bit_cast(float, (int)fw[0][j][0] ^ (int)fa[0][i][0]);
-      if constexpr (NORM) {
-#pragma unroll
-        for (int k = 0; k < 4 * RT; ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 12 / RT, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
+          for (int j = 0; j < 4; ++j) {
+            if constexpr (!(ABL & 1)) gc_mma(acc[i][j], fw_[j], fa_[i]);
+            else acc[i][j][0] += __builtin_bit_cast(float, (int)fw_[j][0] ^ (int)fa_[i][0]);
+          }
+          if constexpr (NORM && i == 0) norm_dword(std::integral_constant<int, S - 6>{}, std::integral_constant<int, J0>{});
+          if constexpr (NORM && i == RT / 2) norm_dword(std::integral_constant<int, S - 6>{}, std::integral_constant<int, J0 + 1>{});
+        });
+      };
+      burst(fw[0], fa[0], std::integral_constant<int, 0>{});
       // ---- hand-over: half-tap gstep + 1 has landed (this wave's pieces; the barrier collects the others').  vmcnt retires in order, so the
       // count is the operations YOUNGER than those pieces: the pieces of half-tap gstep + 2, plus -- half-taps 0, 1 behind an epilogue -- its
       // stores (and the residual loads of half-tap 17), plus -- half-taps 3, 4 -- the halo loads issued in half-tap 2.
@@ -297,19 +307,7 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
       // first k-step's fragments of the next half-tap (the next unit's A fragments wait for its halo)
       if constexpr (S + 1 < GC_NSTEP) read_a(std::integral_constant<int, S + 1>{}, std::integral_constant<int, 0>{}, fa[0]);
       if (gstep + 1 < total) read_w(nslot, std::integral_constant<int, 0>{}, fw[0]);
-      if constexpr (NORM) norm_part(std::integral_constant<int, S - 6>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
-#pragma unroll
-      for (int i = 0; i < RT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if constexpr (!(ABL & 1)) acc[i][j] = gc_mma(fw[1][j], fa[1][i], acc[i][j]); else acc[i][j][0] += __builtin_bit_cast(float, (int)fw[1][j][0] ^ (int)fa[1][i][0]);
-      if constexpr (NORM) {
-#pragma unroll
-        for (int k = 0; k < 4 * RT; ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 12 / RT, 0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      burst(fw[1], fa[1], std::integral_constant<int, 2>{});
       ++gstep;
     });
 
@@ -317,16 +315,30 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
     // v_permlane16_swap of tiles 2 jp, 2 jp + 1 -> 8 consecutive channels 32 jp + 16 (lq & 1) + 8 (lq >> 1) .. + 7: one 16-byte store.
     // (Measured and dropped: exchanging a pair between lanes lm and lm ^ 8 so that a store covers 8 whole 128-byte lines instead of 16 half
     // lines -- no gain, profiles/r5/bench_gnconv_fullline_r5.txt.)
+    gc_mma_settle();                                       // (the last MFMAs' results: see gc_mma)
+#pragma unroll
+    for (int i = 0; i < RT; ++i)                            // ... and every read of an accumulator behind it: the reads hang on these (empty, ordered) statements
+      asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3]));
     if (last_ph && (!(ABL & 16) || acc[0][0][0] == 1.2345e-30f)) {
+      float st[2][2][2] = {};                              // [pair jp][quad of the lane's 8 channels][sum, sum of squares] over the wave's RT rows
+      auto tally = [&](int jp, const u32x4& pk) {          // of the ROUNDED values: what the next GroupNorm will read
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float lo = gc_lo(pk[e]), hi = gc_hi(pk[e]);
+          st[jp][e >> 1][0] += lo + hi;
+          st[jp][e >> 1][1] = fmaf(lo, lo, fmaf(hi, hi, st[jp][e >> 1][1]));
+        }
+      };
 #pragma unroll
       for (int i = 0; i < RT; ++i) {
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
           const acc4 x = acc[i][2 * jp], y = acc[i][2 * jp + 1];
+          u32x4 pk;
           if (!(RES && NPH == 1)) {
             const auto s01 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[0], x[1]), pack_bf16x2(y[0], y[1]), false, false);
             const auto s23 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[2], x[3]), pack_bf16x2(y[2], y[3]), false, false);
-            __builtin_amdgcn_raw_buffer_store_b128((u32x4){s01[0], s23[0], s01[1], s23[1]}, rO, (int)eoff + 64 * jp, i * erow, 0);
+            pk = (u32x4){s01[0], s23[0], s01[1], s23[1]};
           } else {
             float o8[8];
 #pragma unroll
@@ -340,9 +352,50 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
               o8[2 * e] += gc_lo(rv[i][jp][e]);
               o8[2 * e + 1] += gc_hi(rv[i][jp][e]);
             }
-            __builtin_amdgcn_raw_buffer_store_b128((u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])},
-                                                   rO, (int)eoff + 64 * jp, i * erow, 0);
+            pk = (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])};
           }
+          // (the row offset rides in the VECTOR offset, not in soffset: with a register in soffset hipcc's hazard recognizer does not keep the
+          //  wait states between a 16-byte store and the next write of its data registers -- "this hazard only exists if the instruction is
+          //  not using a register in the soffset field" --, and on MI355X the store then sends the overwritten values for lanes 12 .. 15 of
+          //  every 16-lane row: the wrong outputs this file produced in about one run of three; tools/check_mfma_overlap.py scans for it)
+          __builtin_amdgcn_raw_buffer_store_b128(pk, rO, (int)eoff + i * erow + 64 * jp, 0, 0);
+          if constexpr (ST) tally(jp, pk);
+        }
+      }
+      if constexpr (ST) {
+        // sum over the 16 pixels of the row tile = the 16 lanes lm of a DPP row, in a fixed order (quad, quad pairs, halves, row); lane lm = 0 of
+        // every lq then hands the wave's 4 quads x (sum, sum of squares) to the scratch [wave][lq][8]
+        float* sc = reinterpret_cast<float*>(smem + GC_L_STAT) + (wid * 4 + lq) * 8;
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+              float v = st[jp][k][w];
+              v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1, 0, 3, 2]
+              v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2, 3, 0, 1]
+              v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+              v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror
+              if (lm == 0) sc[(jp * 2 + k) * 2 + w] = v;
+            }
+      }
+    }
+    if constexpr (ST) {
+      if (last_ph) {
+        // wave 0 folds the four row groups (wm = 0 .. 3, in that order) and writes the tile's 32 quads x 2 floats
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        if (wid == 0) {
+          const int q = lane >> 1, w = lane & 1;               // quad of the launch's 128 channels, sum / sum of squares
+          const int wnq = q >> 4, c = 4 * q - 64 * wnq;        // wave column, channel inside its 64
+          const int jp = c >> 5, i8 = (c & 31) >> 3, k = (c & 7) >> 2;
+          const int lqq = (i8 >> 1) | ((i8 & 1) << 1);         // 8-channel run i8 = 2 (lq & 1) + (lq >> 1)
+          const float* sc = reinterpret_cast<const float*>(smem + GC_L_STAT) + (wnq * 4 + lqq) * 8 + (jp * 2 + k) * 2 + w;
+          float v = sc[0];
+#pragma unroll
+          for (int m = 1; m < 4; ++m) v += sc[m * WN * 4 * 8];
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dma_rsrc(a.stats), ((t_this * (a.ldo / 4) + q) * 2 + w) * 4, 0, 0);
         }
       }
     }
@@ -360,6 +413,37 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
   wait_vmcnt<0>();                                         // (the poison pieces write LDS: none may be in flight when the workgroup's LDS is released)
 }
 
+// Statistics of a GroupNorm from the per-tile partials of the launch that produced its input: stats [nb * tiles][C / 4][2] (sum, sum of squares per
+// 4-channel quad and 16 x 16 tile) -> the (scale, shift) tables, folded in a fixed order (8 interleaved runs of tiles per group, then the runs,
+// then the group's quads).  One workgroup per image, thread = (group, run).
+__global__ __launch_bounds__(256) void gn_stats_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ scale, float* __restrict__ shift, int tiles, int C, int G, float eps,
+                                                                float inv_count) {
+  __shared__ float part[8][64][2];
+  const int n = blockIdx.x, g = threadIdx.x % G, run = threadIdx.x / G, nrun = 256 / G;     // G = 32: 8 runs
+  const int qpg = C / G / 4, nq = C / 4;
+  float s1 = 0.f, s2 = 0.f;
+  for (int t = run; t < tiles; t += nrun) {
+    const float* p = stats + ((long)(n * tiles + t) * nq + g * qpg) * 2;
+    for (int k = 0; k < qpg; ++k) { s1 += p[2 * k]; s2 += p[2 * k + 1]; }
+  }
+  part[run][g][0] = s1;
+  part[run][g][1] = s2;
+  __syncthreads();
+  if (run == 0) {
+    for (int r = 1; r < nrun; ++r) { s1 += part[r][g][0]; s2 += part[r][g][1]; }
+    const float mean = s1 * inv_count;
+    const float var = fmaxf(fmaf(-mean, mean, s2 * inv_count), 0.f);
+    const float rstd = rsqrtf(var + eps);
+    const int cpg = C / G;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      const float sc = gamma[c] * rstd;
+      scale[(long)n * C + c] = sc;
+      shift[(long)n * C + c] = fmaf(-mean, sc, beta[c]);
+    }
+  }
+}
+
 int g_gnconv_abl = 0;
 
 }  // namespace
@@ -371,12 +455,14 @@ void mmgt_gnconv_set_abl(int v) { g_gnconv_abl = v; }
 // writes channels 0 .. Cout - 1 of the pointers it is given (ldo >= Cout, a multiple of 8: a 256-wide output runs as two launches on its
 // 128-channel halves); residual may be null.  (Cin, Cout) = (128, 128), (256, 128), (128, 64); the residual with Cout = 128 only.
 extern "C" int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const float* shift, const void* wimg, const float* bias, const void* residual,
-                                    void* out, int nb, int H, int W, int cin, int cout, int ldo, int dtype, void* stream) {
+                                    void* out, float* stats, int nb, int H, int W, int cin, int cout, int ldo, int dtype, void* stream) {
   MMGT_CHECK(x && scale && shift && wimg && out && nb > 0 && H > 0 && W > 0, "gn_silu_conv3x3: bad arguments");
   MMGT_CHECK(dtype == MMGT_BF16, "gn_silu_conv3x3: bf16 only");
   const bool s128 = cin == 128 && cout == 128, s256 = cin == 256 && cout == 128, s64 = cin == 128 && cout == 64;
   MMGT_CHECK(s128 || s256 || (s64 && !residual), "gn_silu_conv3x3: (Cin, Cout) = (128, 128), (256, 128), or (128, 64) without residual (got %d -> %d)", cin, cout);
   MMGT_CHECK(shift == scale + (long)nb * cin, "gn_silu_conv3x3: scale and shift must be one allocation, shift = scale + nb * Cin (mmgt_amd/hip.py::groupnorm_affine)");
+  MMGT_CHECK(!stats || (cout == 128 && ((uintptr_t)stats % 8) == 0 && (long)nb * (H / GC_T) * (W / GC_T) * (ldo / 4) * 8 < (1l << 31)),
+             "gn_silu_conv3x3: statistics come with 128 output channels per launch (and a buffer below 2 GiB)");
   MMGT_CHECK(ldo >= cout && ldo % 8 == 0, "gn_silu_conv3x3: ldo = %d must be a multiple of 8 and >= Cout", ldo);
   MMGT_CHECK(H % GC_T == 0 && W % GC_T == 0, "gn_silu_conv3x3: H and W must be multiples of 16 (got %d x %d)", H, W);
   MMGT_CHECK((long)nb * H * W * cin * 2 < (1l << 31) && (long)nb * H * W * ldo * 2 < (1l << 31), "gn_silu_conv3x3: x, residual and out must be smaller than 2 GiB each");
@@ -395,6 +481,7 @@ extern "C" int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const flo
   a.tiles_per_img = (H / GC_T) * (W / GC_T);
   a.ntiles = nb * a.tiles_per_img;
   a.ldo = ldo;
+  a.stats = stats;
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
@@ -421,7 +508,9 @@ extern "C" int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const flo
     return 0;
   };
   int rc;
-  if (s256) rc = residual ? go(gnconv_kernel<2, 128, true, 0>, 0) : go(gnconv_kernel<2, 128, false, 0>, 1);
+  if (stats && s256) rc = residual ? go(gnconv_kernel<2, 128, true, 0, true>, 15) : go(gnconv_kernel<2, 128, false, 0, true>, 16);
+  else if (stats) rc = residual ? go(gnconv_kernel<1, 128, true, 0, true>, 17) : go(gnconv_kernel<1, 128, false, 0, true>, 18);
+  else if (s256) rc = residual ? go(gnconv_kernel<2, 128, true, 0>, 0) : go(gnconv_kernel<2, 128, false, 0>, 1);
   else if (s64) rc = go(gnconv_kernel<1, 64, false, 0>, 2);
   else if (residual) rc = go(gnconv_kernel<1, 128, true, 0>, 3);
   else switch (g_gnconv_abl) {
@@ -438,6 +527,18 @@ extern "C" int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const flo
     default: rc = go(gnconv_kernel<1, 128, false, 0>, 14); break;
   }
   if (rc) return rc;
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+// stats [nb * tiles][C / 4][2] as written by mmgt_gn_silu_conv3x3 (tiles = (H / 16) (W / 16) per image) -> scale | shift (nb, C) of GroupNorm(G groups,
+// gamma, beta, eps) over the stored tensor; C / G a multiple of 4, G <= 64 and a divisor of 256.
+extern "C" int mmgt_gn_stats_finalize(const float* stats, const float* gamma, const float* beta, float* scale, float* shift, int nb, int tiles, int C,
+                                      int G, float eps, void* stream) {
+  MMGT_CHECK(stats && gamma && beta && scale && shift && nb > 0 && tiles > 0, "gn_stats_finalize: bad arguments");
+  MMGT_CHECK(G > 0 && G <= 64 && 256 % G == 0 && C % G == 0 && (C / G) % 4 == 0, "gn_stats_finalize: unsupported C = %d, G = %d", C, G);
+  hipLaunchKernelGGL(gn_stats_finalize_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta, scale, shift, tiles, C, G, eps,
+                     1.f / ((float)tiles * 256.f * (float)(C / G)));
   MMGT_LAUNCH_CHECK();
   return 0;
 }

@@ -487,7 +487,10 @@ void tleg320_kernel(const TlegArgs a) {
           o8[2 * j + 1] += bf_hi(rv[rt][j]);
         }
         const u32x4 pk = (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])};
-        if (!(ABL & 8) || pk[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(pk, ro, (int)(rowoff[rt] + 2 * cofs), 64 * oc, 0);
+        // (the chunk's column offset rides in the VECTOR offset: with a register in soffset hipcc does not keep the wait states between a 16-byte
+        //  store and the next write of its data registers, and MI355X then stores the overwritten values in lanes 12 .. 15 of every 16-lane
+        //  row -- found in csrc/gnconv.hip, round 5; tools/check_mfma_overlap.py scans every object of the library for the pattern)
+        if (!(ABL & 8) || pk[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(pk, ro, (int)(rowoff[rt] + 2 * cofs + 64 * oc), 0, 0);
       }
     }
   }

@@ -68,7 +68,8 @@ _SIGS = {
     "mmgt_rowgemm320": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                 c_long, c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_gn_silu_conv3x3_image_bytes": (c_long, [c_int, c_int]),
-    "mmgt_gn_silu_conv3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_gn_silu_conv3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_gn_stats_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "mmgt_temporal_leg320_image_bytes": (c_long, []),
     "mmgt_temporal_leg320": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int,
                                      c_void_p]),
@@ -342,10 +343,12 @@ def gn_silu_conv3x3_supported(dtype, cin, cout, H, W, residual=False):
             and H % 16 == 0 and W % 16 == 0)
 
 
-def gn_silu_conv3x3_tables(x, scale, shift, wimg, cout, bias=None, residual=None, out=None):
+def gn_silu_conv3x3_tables(x, scale, shift, wimg, cout, bias=None, residual=None, out=None, stats=None):
     """bias + conv3x3(silu(x * scale[n, c] + shift[n, c])) (+ residual) (csrc/gnconv.hip): x (NB, H, W, Cin) bf16 channels-last, scale / shift
-    (NB, Cin) fp32 (the tables of `groupnorm_affine`), wimg = packing.pack_gnconv(weight (cout, Cin, 3, 3)): one launch per 128 output channels."""
-    _dev(x, scale, shift, wimg, bias, residual, out)
+    (NB, Cin) fp32 (the tables of `groupnorm_affine`), wimg = packing.pack_gnconv(weight (cout, Cin, 3, 3)): one launch per 128 output channels.
+    stats: or a (NB * (H / 16) * (W / 16), cout / 4, 2) fp32 tensor that receives the per-tile (sum, sum of squares) of the stored values
+    (`gn_tables_from_stats` turns them into the tables of the GroupNorm that reads `out`)."""
+    _dev(x, scale, shift, wimg, bias, residual, out, stats)
     assert x.dim() == 4 and x.is_contiguous()
     NB, H, W, C = x.shape
     assert gn_silu_conv3x3_supported(x.dtype, C, cout, H, W, residual is not None) and x.numel() * x.element_size() <= DMA_LIMIT
@@ -362,29 +365,52 @@ def gn_silu_conv3x3_tables(x, scale, shift, wimg, cout, bias=None, residual=None
     assert out.shape == (NB, H, W, cout) and out.is_contiguous() and out.dtype == x.dtype and out.numel() * 2 <= DMA_LIMIT
     if residual is not None:
         assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype
+    if stats is not None:
+        assert cl == 128 and stats.dtype == torch.float32 and stats.is_contiguous() and stats.shape == (NB * (H // 16) * (W // 16), cout // 4, 2)
     bias = _f32(bias, "bias")
     if bias is not None:
         assert bias.numel() >= cout
     for h in range(cout // cl):
         _check(lib().mmgt_gn_silu_conv3x3(_ptr(x), _ptr(scale), _ptr(shift), wimg.data_ptr() + h * per, None if bias is None else bias.data_ptr() + 4 * cl * h,
                                           None if residual is None else residual.data_ptr() + 2 * cl * h, out.data_ptr() + 2 * cl * h,
+                                          None if stats is None else stats.data_ptr() + 4 * 64 * h,
                                           NB, H, W, C, cl, cout, dtype_code(x.dtype), _stream()), "mmgt_gn_silu_conv3x3")
     return out
 
 
-def gn_silu_conv3x3(x, gamma, beta, groups, eps, wimg, cout, bias=None, residual=None, out=None):
-    """conv3x3(silu(GroupNorm(x))) (+ residual): ONE pass over x for the statistics (`groupnorm_affine`) and one fused launch per 128 output
-    channels for the rest.  x (NB, H, W, Cin) bf16 channels-last -> (NB, H, W, cout)."""
+def gn_tables_from_stats(stats, gamma, beta, groups, eps, NB, C):
+    """(scale, shift) of GroupNorm(groups, gamma, beta, eps) over a tensor (NB, H, W, C) from the per-tile partial sums `gn_silu_conv3x3*` wrote
+    while storing it (stats (NB * tiles, C / 4, 2)): one small launch instead of the statistics pass over the tensor."""
+    _dev(stats, gamma, beta)
+    assert stats.dim() == 3 and stats.shape[1] == C // 4 and stats.shape[2] == 2 and stats.shape[0] % NB == 0 and stats.is_contiguous()
+    tab = torch.empty((2, NB, C), device=stats.device, dtype=torch.float32)
+    _check(lib().mmgt_gn_stats_finalize(_ptr(stats), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), _ptr(tab[0]), _ptr(tab[1]), NB, stats.shape[0] // NB,
+                                        C, groups, eps, _stream()), "mmgt_gn_stats_finalize")
+    return tab[0], tab[1]
+
+
+def gn_silu_conv3x3(x, gamma, beta, groups, eps, wimg, cout, bias=None, residual=None, out=None, tables=None, want_stats=False):
+    """conv3x3(silu(GroupNorm(x))) (+ residual): the statistics from `tables` (scale, shift) if the caller has them (`gn_tables_from_stats` of the
+    launch that produced x), else ONE pass over x (`groupnorm_affine`); then one fused launch per 128 output channels.  x (NB, H, W, Cin) bf16
+    channels-last -> (NB, H, W, cout), or (out, stats) with want_stats (stats = None where the launch cannot produce them)."""
     assert x.dim() == 4 and x.is_contiguous()
     NB, H, W, C = x.shape
     if out is None:
         out = torch.empty((NB, H, W, cout), device=x.device, dtype=x.dtype)
+    stats = None
+    if want_stats and cout % 128 == 0:
+        stats = torch.empty((NB * (H // 16) * (W // 16), cout // 4, 2), device=x.device, dtype=torch.float32)
     step = max(1, DMA_LIMIT // (H * W * max(C, cout) * x.element_size()))       # 32-bit buffer offsets: runs of whole images below 2 GiB
+    tiles = (H // 16) * (W // 16)
     for n0 in range(0, NB, step):
         n1 = min(NB, n0 + step)
-        scale, shift = groupnorm_affine(x[n0:n1].view(n1 - n0, H * W, C), gamma, beta, groups, eps)
-        gn_silu_conv3x3_tables(x[n0:n1], scale, shift, wimg, cout, bias, None if residual is None else residual[n0:n1], out[n0:n1])
-    return out
+        if tables is None:
+            scale, shift = groupnorm_affine(x[n0:n1].view(n1 - n0, H * W, C), gamma, beta, groups, eps)
+        else:
+            scale, shift = tables[0][n0:n1], tables[1][n0:n1]
+        gn_silu_conv3x3_tables(x[n0:n1], scale, shift, wimg, cout, bias, None if residual is None else residual[n0:n1], out[n0:n1],
+                               None if stats is None else stats[n0 * tiles:n1 * tiles])
+    return (out, stats) if want_stats else out
 
 
 def layernorm(x, gamma, beta, eps=1e-5, pe=None, pe_div=1, pe_mod=1, out=None):

@@ -206,24 +206,31 @@ class AutoencoderKL:
         nb, h, ww, c = x.shape
         return hip.groupnorm(x.view(nb, h * ww, c), self.w[p + ".g"], self.w[p + ".b"], 32, 1e-6, silu=silu).view(nb, h, ww, c)
 
-    def _gn_silu_conv(self, pn, pc, x, residual=None):
-        """conv3x3(silu(GroupNorm(x))) (+ residual): diffusers `ResnetBlock2D.forward`'s norm -> nonlinearity -> conv.  The 128 -> 128 convs of a
-        bf16 model, the 256 -> 128 conv and conv_out (128 -> 3, padded to 64) run as a statistics pass + ONE fused launch (the normalised tensor is never written); everything else as two launches."""
+    def _gn_silu_conv(self, pn, pc, x, residual=None, stats=None):
+        """conv3x3(silu(GroupNorm(x))) (+ residual): diffusers `ResnetBlock2D.forward`'s norm -> nonlinearity -> conv.  In a bf16 model the convs
+        of the 512 x 512 and 256 x 256 levels (128 / 256 input channels; conv_out padded to 64 outputs) run as ONE fused launch per 128 output
+        channels (the normalised tensor is never written); the GroupNorm statistics come from `stats` -- the per-tile partial sums the launch that
+        PRODUCED x wrote beside it -- or from one pass over x.  Everything else runs GroupNorm and conv as two launches.
+        Returns (out, stats of out or None)."""
         nb, h, ww, c = x.shape
         cout = self.w[pc + ".bias"].numel()
         if (hip.tune_get("gnconv") and (pc + ".gimg") in self.w and hip.gn_silu_conv3x3_supported(x.dtype, c, cout, h, ww, residual is not None)
                 and h * ww > 256):
-            return hip.gn_silu_conv3x3(x, self.w[pn + ".g"], self.w[pn + ".b"], 32, 1e-6, self.w[pc + ".gimg"], cout, self.w[pc + ".bias"], residual)
-        return hip.conv3x3(self._gn(pn, x, True), self.w[pc + ".w"], self.w[pc + ".bias"], residual=residual)
+            g, b = self.w[pn + ".g"], self.w[pn + ".b"]
+            tables = hip.gn_tables_from_stats(stats, g, b, 32, 1e-6, nb, c) if stats is not None and hip.tune_get("gnconv") >= 2 else None
+            return hip.gn_silu_conv3x3(x, g, b, 32, 1e-6, self.w[pc + ".gimg"], cout, self.w[pc + ".bias"], residual, tables=tables,
+                                       want_stats=hip.tune_get("gnconv") >= 2)
+        return hip.conv3x3(self._gn(pn, x, True), self.w[pc + ".w"], self.w[pc + ".bias"], residual=residual), None
 
-    def _resnet(self, p, x):
+    def _resnet(self, p, x, stats=None):
+        """-> (out, per-tile statistics of out or None); `stats`: those of x, from the launch that produced it"""
         nb, h, ww, cin = x.shape
-        hdn = self._gn_silu_conv(p + ".norm1", p + ".conv1", x)
+        hdn, st = self._gn_silu_conv(p + ".norm1", p + ".conv1", x, stats=stats)
         res = x
         if (p + ".conv_shortcut.w") in self.w:
             res = hip.gemm(x.view(nb * h * ww, cin), self.w[p + ".conv_shortcut.w"], self.w[p + ".conv_shortcut.bias"])
             res = res.view(nb, h, ww, -1)
-        return self._gn_silu_conv(p + ".norm2", p + ".conv2", hdn, residual=res)
+        return self._gn_silu_conv(p + ".norm2", p + ".conv2", hdn, residual=res, stats=st)
 
     def _mid_attention(self, x, a="decoder.mid_block.attentions.0"):
         if self._split_attention and self._dtype == torch.bfloat16 and x.shape[1] * x.shape[2] % 256 == 0 and x.shape[1] * x.shape[2] <= 8192:
@@ -277,16 +284,17 @@ class AutoencoderKL:
         nb, h, ww, _ = z.shape
         x = hip.gemm(z.view(nb * h * ww, 64), self.w["post_quant_conv.w"], self.w["post_quant_conv.bias"]).view(nb, h, ww, 64)
         x = hip.conv3x3(x, self.w["decoder.conv_in.w"], self.w["decoder.conv_in.bias"])
-        x = self._resnet("decoder.mid_block.resnets.0", x)
+        x, _ = self._resnet("decoder.mid_block.resnets.0", x)
         x = self._mid_attention(x)
-        x = self._resnet("decoder.mid_block.resnets.1", x)
+        x, _ = self._resnet("decoder.mid_block.resnets.1", x)
+        st = None                                            # statistics of x written by the launch that produced it (the fused launches only)
         for i in range(4):
             for j in range(3):
-                x = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", x)
+                x, st = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", x, st)
             if i != 3:
                 p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
-                x = hip.conv3x3(x, self.w[p + ".w"], self.w[p + ".bias"], upsample=True)
-        return self._gn_silu_conv("decoder.conv_norm_out", "decoder.conv_out", x)
+                x, st = hip.conv3x3(x, self.w[p + ".w"], self.w[p + ".bias"], upsample=True), None
+        return self._gn_silu_conv("decoder.conv_norm_out", "decoder.conv_out", x, stats=st)[0]
 
     def encode_nhwc(self, x):
         """x: (nb, H, W, 64) channels-last image in [-1, 1] (3 valid channels) -> (nb, H/8, W/8, 64) moments (channels
@@ -296,13 +304,13 @@ class AutoencoderKL:
         x = hip.conv3x3(x, self.w["encoder.conv_in.w"], self.w["encoder.conv_in.bias"])
         for i in range(4):
             for j in range(2):
-                x = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}", x)
+                x, _ = self._resnet(f"encoder.down_blocks.{i}.resnets.{j}", x)
             if i != 3:
                 p = f"encoder.down_blocks.{i}.downsamplers.0.conv"      # F.pad(x, (0, 1, 0, 1)) + stride-2 conv, padding 0
                 x = hip.conv3x3(x, self.w[p + ".w"], self.w[p + ".bias"], stride=2, pad_high_only=True)
-        x = self._resnet("encoder.mid_block.resnets.0", x)
+        x, _ = self._resnet("encoder.mid_block.resnets.0", x)
         x = self._mid_attention(x, "encoder.mid_block.attentions.0")
-        x = self._resnet("encoder.mid_block.resnets.1", x)
+        x, _ = self._resnet("encoder.mid_block.resnets.1", x)
         x = self._gn("encoder.conv_norm_out", x, True)
         x = hip.conv3x3(x, self.w["encoder.conv_out.w"], self.w["encoder.conv_out.bias"])
         nb, h, ww, _ = x.shape

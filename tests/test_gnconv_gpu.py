@@ -69,24 +69,63 @@ def test_gnconv_other_shapes_vs_fp64(cin, cout, res, nb, H, W):
     assert torch.equal(out, hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), cout, b, r))
 
 
-@pytest.mark.parametrize("cin,cout,nb,H,W", [(128, 128, 300, 16, 16), (256, 128, 300, 16, 16), (256, 256, 8, 64, 64)])
-def test_gnconv_residual_repeated_runs(cin, cout, nb, H, W):
-    """The residual paths (epilogue vectors requested under the last MFMAs for Cin = 128; accumulator initialisation for Cin = 256) over many
-    tiles per workgroup, ten times into a sentinel-filled output: every run equals the launch without residual + the residual added outside
-    to within the one bf16 rounding that differs.  (A first form of the two-phase path returned stale registers in 1 of ~3 runs.)"""
+@pytest.mark.parametrize("with_stats", [False, True])
+@pytest.mark.parametrize("cin,cout,nb,H,W", [(128, 128, 300, 16, 16), (256, 128, 300, 16, 16), (256, 256, 8, 64, 64), (128, 128, 4, 256, 256)])
+def test_gnconv_residual_repeated_runs(cin, cout, nb, H, W, with_stats):
+    """The residual paths (epilogue vectors requested under the last MFMAs for Cin = 128; accumulator initialisation for Cin = 256), with and
+    without the statistics epilogue, over many tiles per workgroup, ten times into a sentinel-filled output: every run equals the launch
+    without residual + the residual added outside to within the one bf16 rounding that differs, and all runs are bitwise equal.
+    (This is the test that would have caught the store-data hazard of round 5 -- a 16-byte buffer store with a register soffset whose data
+    registers the next instruction rewrites sends wrong values in lanes 12 .. 15 -- which failed one run in three at first and every run at
+    256 x 256; tools/check_mfma_overlap.py now scans the device code for the pattern.)"""
     from mmgt_amd import hip
     from mmgt_amd.packing import pack_gnconv
     x, w, b, r, scale, shift = _case(nb, H, W, 300 + cin + cout, True, cin=cin, cout=cout)
     wimg = pack_gnconv(w)
     good = hip.gn_silu_conv3x3_tables(x, scale, shift, wimg, cout, b, None).float() + r.float()
     first = None
+    st = torch.empty((nb * (H // 16) * (W // 16), cout // 4, 2), device=dev()) if with_stats else None
     for k in range(10):
         out = torch.full((nb, H, W, cout), 777.0, device=dev(), dtype=torch.bfloat16)
-        hip.gn_silu_conv3x3_tables(x, scale, shift, wimg, cout, b, r, out=out)
+        hip.gn_silu_conv3x3_tables(x, scale, shift, wimg, cout, b, r, out=out, stats=st)
         d = (out.float() - good).abs()
         assert (d <= 2.0 ** -6 * good.abs() + 4e-2).all(), (k, d.max().item(), (d > 0.1).sum().item())
         first = out if first is None else first
         assert torch.equal(out, first), k
+
+
+@pytest.mark.parametrize("cin,cout,res,nb,H,W", [(128, 128, True, 3, 64, 48), (256, 128, False, 2, 32, 32), (256, 256, True, 2, 48, 32), (128, 128, False, 300, 16, 16)])
+def test_gnconv_statistics_of_the_output(cin, cout, res, nb, H, W):
+    """The per-tile (sum, sum of squares) the launch writes beside its output, folded by mmgt_gn_stats_finalize, against the statistics pass
+    over the stored tensor (hip.groupnorm_affine) and against fp64 GroupNorm statistics of it; bitwise repeatable; the output itself is the
+    launch's without statistics."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_gnconv
+    x, w, b, r, scale, shift = _case(nb, H, W, 400 + cin + cout, res, cin=cin, cout=cout)
+    x = x + 3.0                                                                          # a mean several sigma off zero: E[x^2] - mean^2 in fp32
+    wimg = pack_gnconv(w)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    gamma, beta = (0.5 + torch.rand(cout, generator=g)).to(dev()), (torch.rand(cout, generator=g) - 0.5).to(dev())
+    tiles = (H // 16) * (W // 16)
+    stats = torch.full((nb * tiles, cout // 4, 2), float("nan"), device=dev())
+    out = hip.gn_silu_conv3x3_tables(x, scale, shift, wimg, cout, b, r, stats=stats)
+    assert torch.equal(out, hip.gn_silu_conv3x3_tables(x, scale, shift, wimg, cout, b, r))
+    assert torch.isfinite(stats).all()
+    sc, sh = hip.gn_tables_from_stats(stats, gamma, beta, 32, 1e-6, nb, cout)
+    if H * W > 256:                                                                      # (the statistics pass wants more than 256 pixels)
+        sc2, sh2 = hip.groupnorm_affine(out.view(nb, H * W, cout), gamma, beta, 32, 1e-6)
+        torch.testing.assert_close(sc, sc2, rtol=2e-4, atol=1e-6)
+        torch.testing.assert_close(sh, sh2, rtol=2e-4, atol=2e-4)
+    o = out.double().view(nb, H * W, 32, cout // 32)
+    mean, var = o.mean(dim=(1, 3)), o.var(dim=(1, 3), unbiased=False)
+    rstd = (var + 1e-6).rsqrt()
+    want_sc = gamma.double().view(1, 32, -1) * rstd[:, :, None]
+    want_sh = beta.double().view(1, 32, -1) - mean[:, :, None] * want_sc
+    torch.testing.assert_close(sc.double().view(nb, 32, -1), want_sc, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(sh.double().view(nb, 32, -1), want_sh, rtol=1e-4, atol=1e-4)
+    stats2 = torch.empty_like(stats)
+    hip.gn_silu_conv3x3_tables(x, scale, shift, wimg, cout, b, r, stats=stats2)
+    assert torch.equal(stats, stats2)
 
 
 def test_gnconv_no_bias_and_zero_padding():

@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Scan the device code of the built objects (mmgt_amd/csrc/build/*.o) for two instruction patterns hipcc 7.2 emits for gfx950 and the hardware
+does not execute as written (both found in csrc/gnconv.hip, round 5):
+
+(1) a 12- / 16-byte VMEM store whose data registers are written by a VALU instruction within the next two wait states.  The hazard recognizer
+    inserts the wait states only when the store's soffset is NOT a register (SIInstrInfo / GCNHazardRecognizer: "this hazard only exists if the
+    instruction is not using a register in the soffset field"); on MI355X the store then sends the overwritten value for the last lanes of each
+    16-lane row (wrong outputs in lanes 12 .. 15, deterministic once the overwrite is the very next instruction).
+(2) MFMA instructions whose destination registers PARTIALLY overlap their accumulator input (vDst != SrcC but sharing registers).  The ISA wants them identical or disjoint; hipcc 7.2 emits the partial form for
+v_mfma_f32_16x16x32_bf16 when it rotates accumulators between register ranges (seen in csrc/gnconv.hip, round 5: accumulator tiles that came out
+of such an instruction were garbage in some lanes in about one run of three).  Exit status 1 and a listing if any is found.
+
+    python tools/check_mfma_overlap.py [objects ...]
+"""
+import glob
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PAT = re.compile(r"(v_s?mfma\w*)\s+([av])\[(\d+):(\d+)\],\s*[av]\[\d+:\d+\],\s*[av]\[\d+:\d+\],\s*([av])\[(\d+):(\d+)\]")
+
+
+STORE = re.compile(r"((?:buffer|global|flat|scratch)_store_dwordx[34])\s+(?:v\d+,\s*|v\[\d+:\d+\],\s*)?v\[(\d+):(\d+)\]")
+VDEF = re.compile(r"^\s*(v_\w+)\s+v(?:\[(\d+):(\d+)\]|(\d+))(?:,\s*v(?:\[(\d+):(\d+)\]|(\d+)))?")
+
+
+def store_hazards(lines):
+    """(function, store, overwriting instruction) for stores of more than 8 bytes whose data is rewritten within two wait states"""
+    out, func = [], "?"
+    for k, line in enumerate(lines):
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            func = m.group(1)
+            continue
+        text = line.split("//")[0]
+        m = STORE.search(text)
+        if not m:
+            continue
+        # buffer stores: (vdata, vaddr ...): vdata is the FIRST register operand
+        ops = text.split(None, 1)[1] if len(text.split(None, 1)) > 1 else ""
+        md = re.match(r"\s*v\[(\d+):(\d+)\]", ops) if m.group(1).startswith("buffer") else None
+        d0, d1 = (int(md.group(1)), int(md.group(2))) if md else (int(m.group(2)), int(m.group(3)))
+        if d1 - d0 < 2:
+            continue
+        waited = 0
+        for nxt in lines[k + 1:k + 6]:
+            t = nxt.split("//")[0]
+            if re.match(r"^[0-9a-f]+ <", t) or waited >= 2:
+                break
+            if re.search(r"\b(s_branch|s_cbranch\w*|s_endpgm|s_setpc_b64)\b", t):
+                break                                      # (what follows in the listing is not what follows in time)
+            mn = re.search(r"s_nop\s+(\d+)", t)
+            if mn:
+                waited += int(mn.group(1)) + 1
+                continue
+            mv = VDEF.search(t)
+            if mv and not mv.group(1).startswith("v_cmp"):
+                defs = []
+                if mv.group(2) is not None:
+                    defs.append((int(mv.group(2)), int(mv.group(3))))
+                elif mv.group(4) is not None:
+                    defs.append((int(mv.group(4)), int(mv.group(4))))
+                if "swap" in mv.group(1):
+                    if mv.group(5) is not None:
+                        defs.append((int(mv.group(5)), int(mv.group(6))))
+                    elif mv.group(7) is not None:
+                        defs.append((int(mv.group(7)), int(mv.group(7))))
+                if any(a <= d1 and d0 <= b for a, b in defs):
+                    out.append((func, text.strip(), t.strip()))
+                    break
+            if t.strip():
+                waited += 1
+    return out
+
+
+def scan(obj):
+    bad, total = [], 0
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
+        subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj], check=True)
+        subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}",
+                        "--unbundle"], check=True, stderr=subprocess.DEVNULL)
+        dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+    func = "?"
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            func = m.group(1)
+            continue
+        m = PAT.search(line)
+        if not m:
+            continue
+        total += 1
+        dk, d0, d1, ck, c0, c1 = m.group(2), int(m.group(3)), int(m.group(4)), m.group(5), int(m.group(6)), int(m.group(7))
+        if dk == ck and (d0, d1) != (c0, c1) and d0 <= c1 and c0 <= d1:
+            bad.append((func, line.strip().split("//")[0].strip()))
+    return total, bad, store_hazards(dis.splitlines())
+
+
+def main():
+    objs = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "mmgt_amd", "csrc", "build", "*.o")))
+    rc = 0
+    for o in objs:
+        total, bad, sth = scan(o)
+        print(f"{os.path.basename(o):24s} {total:6d} MFMAs, {len(bad)} with vDst partially overlapping SrcC; {len(sth)} wide stores whose data is rewritten at once")
+        for f, l in bad[:20]:
+            print(f"    {f[:80]}: {l}")
+            rc = 1
+        for f, st, ov in sth[:20]:
+            print(f"    {f[:60]}: {st}   <-   {ov}")
+            rc = 1
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main())
