@@ -217,9 +217,10 @@ class AutoencoderKL:
         if (hip.tune_get("gnconv") and (pc + ".gimg") in self.w and hip.gn_silu_conv3x3_supported(x.dtype, c, cout, h, ww, residual is not None)
                 and h * ww > 256):
             g, b = self.w[pn + ".g"], self.w[pn + ".b"]
-            tables = hip.gn_tables_from_stats(stats, g, b, 32, 1e-6, nb, c) if stats is not None and hip.tune_get("gnconv") >= 2 else None
-            return hip.gn_silu_conv3x3(x, g, b, 32, 1e-6, self.w[pc + ".gimg"], cout, self.w[pc + ".bias"], residual, tables=tables,
-                                       want_stats=hip.tune_get("gnconv") >= 2)
+            chain = hip.tune_get("gnconv") >= 2                  # (1: every fused launch behind its own statistics pass)
+            tables = hip.gn_tables_from_stats(stats, g, b, 32, 1e-6, nb, c) if stats is not None and chain else None
+            r = hip.gn_silu_conv3x3(x, g, b, 32, 1e-6, self.w[pc + ".gimg"], cout, self.w[pc + ".bias"], residual, tables=tables, want_stats=chain)
+            return r if chain else (r, None)
         return hip.conv3x3(self._gn(pn, x, True), self.w[pc + ".w"], self.w[pc + ".bias"], residual=residual), None
 
     def _resnet(self, p, x, stats=None):

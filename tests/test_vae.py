@@ -55,6 +55,29 @@ def test_hip_vae_matches_oracle(dtype, tol):
 
 
 @pytest.mark.gpu
+def test_hip_vae_gnconv_modes_agree():
+    """The three forms of the decoder's GroupNorm -> SiLU -> conv legs (mmgt_tune "gnconv": 0 two launches, 1 fused launch behind a statistics
+    pass, 2 statistics from the producing launch: the default) against the oracle at the bf16 gate, and against each other."""
+    from mmgt_amd import hip
+    from mmgt_amd.vae import AutoencoderKL
+    sd = _sd()
+    lat = hash_uniform("vae.lat", (1, 4, 3, 8, 8), 1.0)
+    with torch.no_grad():
+        ref = vae_ref.decode_latents(sd, lat)
+    vae = AutoencoderKL(device="cuda:0", dtype=torch.bfloat16)
+    vae.load_state_dict(sd)
+    outs = []
+    try:
+        for mode in (0, 1, 2):
+            hip.tune("gnconv", mode)
+            outs.append(vae.decode_video(lat.cuda(), frames_per_batch=3).cpu())
+            torch.testing.assert_close(outs[-1], ref, rtol=0, atol=4e-2)
+    finally:
+        hip.tune("gnconv", 2)
+    assert (outs[1] - outs[0]).abs().max() < 3e-2 and (outs[2] - outs[1]).abs().max() < 3e-2
+
+
+@pytest.mark.gpu
 def test_split_operand_kernels():
     """The three entry points of the bf16 model's mid-block attention (include/mmgt_hip.h): bf16 x bf16 -> raw fp32 accumulators,
     the hi / lo split of q and k, fp32 logits -> bf16 probabilities."""
