@@ -54,15 +54,10 @@ struct GcArgs {
   float* stats;          // or null: per (tile, 4-channel quad of the launch's Cout) the pair (sum, sum of squares) of the STORED values, [tile][ldo / 4][2]
 };
 
-// The MFMA as an asm statement with a TIED accumulator: through the builtin hipcc 7.2 moves accumulator tiles between register ranges near the
-// epilogue and emits v_mfma_f32_16x16x32_bf16 whose vDst PARTIALLY overlaps SrcC (e.g. v[120:123] <- ... + v[122:125]); the ISA wants them
-// identical or disjoint, and the tiles that came out of such an instruction were garbage in the lanes of columns 12 .. 15 in about one run of
-// three (tools/check_mfma_overlap.py scans every object of the library for the pattern; tests/test_host_logic.py runs it).  An asm statement
-// hides the MFMA's result latency from the compiler: `gc_mma_settle` stands in front of every non-MFMA read of the accumulators.
-__device__ __forceinline__ void gc_mma(acc4& c, s16x8 a, s16x8 b) {
-  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void gc_mma_settle() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory"); }
+// (hipcc 7.2 rotates accumulator tiles between register ranges in front of the epilogue and then emits MFMAs whose vDst overlaps SrcC by two
+// registers, e.g. v[120:123] <- ... + v[122:125]; tools/micro/mfma_overlap.hip shows the hardware computes those correctly -- the wrong outputs
+// this file once produced came from the store hazard described at the epilogue's stores, not from them.)
+__device__ __forceinline__ void gc_mma(acc4& c, s16x8 a, s16x8 b) { c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float gc_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float gc_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
@@ -262,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
       // a vector of the next unit's halo per half-tap, half of it under each k-step's MFMAs (unconditional: without a next unit it works on
       // stale registers; a uniform branch would put it in a basic block of its own, in front of the MFMAs instead of between them)
       constexpr bool NORM = S >= 6 && S < 6 + GC_NVL && !(ABL & 64);
-      // the MFMAs of a k-step (asm statements: their order is the program's), two dwords of the halo vector dealt out between them
+      // the MFMAs of a k-step, two dwords of the halo vector between them
       auto burst = [&](s16x8 (&fw_)[4], s16x8 (&fa_)[RT], auto J0c) {
         constexpr int J0 = decltype(J0c)::value;
         gc_for<0, RT>([&](auto ic) {
@@ -276,7 +271,19 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
           if constexpr (NORM && i == RT / 2) norm_dword(std::integral_constant<int, S - 6>{}, std::integral_constant<int, J0 + 1>{});
         });
       };
+      // (scheduling hint: one MFMA, then a few of the normalisation's VALU instructions, ...; then the region ends)
+      auto interleave = [&]() {
+        if constexpr (NORM) {
+#pragma unroll
+          for (int k = 0; k < 4 * RT; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 12 / RT, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
       burst(fw[0], fa[0], std::integral_constant<int, 0>{});
+      interleave();
       // ---- hand-over: half-tap gstep + 1 has landed (this wave's pieces; the barrier collects the others').  vmcnt retires in order, so the
       // count is the operations YOUNGER than those pieces: the pieces of half-tap gstep + 2, plus -- half-taps 0, 1 behind an epilogue -- its
       // stores (and the residual loads of half-tap 17), plus -- half-taps 3, 4 -- the halo loads issued in half-tap 2.
@@ -308,6 +315,7 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
       if constexpr (S + 1 < GC_NSTEP) read_a(std::integral_constant<int, S + 1>{}, std::integral_constant<int, 0>{}, fa[0]);
       if (gstep + 1 < total) read_w(nslot, std::integral_constant<int, 0>{}, fw[0]);
       burst(fw[1], fa[1], std::integral_constant<int, 2>{});
+      interleave();
       ++gstep;
     });
 
@@ -315,10 +323,6 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
     // v_permlane16_swap of tiles 2 jp, 2 jp + 1 -> 8 consecutive channels 32 jp + 16 (lq & 1) + 8 (lq >> 1) .. + 7: one 16-byte store.
     // (Measured and dropped: exchanging a pair between lanes lm and lm ^ 8 so that a store covers 8 whole 128-byte lines instead of 16 half
     // lines -- no gain, profiles/r5/bench_gnconv_fullline_r5.txt.)
-    gc_mma_settle();                                       // (the last MFMAs' results: see gc_mma)
-#pragma unroll
-    for (int i = 0; i < RT; ++i)                            // ... and every read of an accumulator behind it: the reads hang on these (empty, ordered) statements
-      asm volatile("" : "+v"(acc[i][0]), "+v"(acc[i][1]), "+v"(acc[i][2]), "+v"(acc[i][3]));
     if (last_ph && (!(ABL & 16) || acc[0][0][0] == 1.2345e-30f)) {
       float st[2][2][2] = {};                              // [pair jp][quad of the lane's 8 channels][sum, sum of squares] over the wave's RT rows
       auto tally = [&](int jp, const u32x4& pk) {          // of the ROUNDED values: what the next GroupNorm will read

@@ -99,8 +99,7 @@ def test_pack_geglu_and_conv():
 def test_device_code_has_no_unguarded_store_or_mfma_hazard():
     """tools/check_mfma_overlap.py over every object of the library: no 12- / 16-byte VMEM store whose data registers are rewritten within two
     wait states (hipcc omits the wait states when the store's soffset is a register; MI355X then stores wrong values in lanes 12 .. 15 of each
-    16-lane row), and no MFMA whose destination partially overlaps its accumulator input.  Both were found in csrc/gnconv.hip in round 5; the
-    first also sat, without a failing test, in csrc/tleg.hip."""
+    16-lane row).  Found in csrc/gnconv.hip in round 5; it also sat, without a failing test, in csrc/tleg.hip."""
     import os
     import subprocess
     import sys

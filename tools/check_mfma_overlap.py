@@ -6,9 +6,8 @@ does not execute as written (both found in csrc/gnconv.hip, round 5):
     inserts the wait states only when the store's soffset is NOT a register (SIInstrInfo / GCNHazardRecognizer: "this hazard only exists if the
     instruction is not using a register in the soffset field"); on MI355X the store then sends the overwritten value for the last lanes of each
     16-lane row (wrong outputs in lanes 12 .. 15, deterministic once the overwrite is the very next instruction).
-(2) MFMA instructions whose destination registers PARTIALLY overlap their accumulator input (vDst != SrcC but sharing registers).  The ISA wants them identical or disjoint; hipcc 7.2 emits the partial form for
-v_mfma_f32_16x16x32_bf16 when it rotates accumulators between register ranges (seen in csrc/gnconv.hip, round 5: accumulator tiles that came out
-of such an instruction were garbage in some lanes in about one run of three).  Exit status 1 and a listing if any is found.
+(2) (reported, not an error) MFMA instructions whose destination registers PARTIALLY overlap their accumulator input (vDst != SrcC but sharing
+    registers): hipcc emits them where it rotates accumulator tiles; tools/micro/mfma_overlap.hip shows MI355X computes them correctly.  Exit status 1 and a listing if a store hazard is found.
 
     python tools/check_mfma_overlap.py [objects ...]
 """
@@ -108,8 +107,7 @@ def main():
         total, bad, sth = scan(o)
         print(f"{os.path.basename(o):24s} {total:6d} MFMAs, {len(bad)} with vDst partially overlapping SrcC; {len(sth)} wide stores whose data is rewritten at once")
         for f, l in bad[:20]:
-            print(f"    {f[:80]}: {l}")
-            rc = 1
+            print(f"    (harmless) {f[:80]}: {l}")
         for f, st, ov in sth[:20]:
             print(f"    {f[:60]}: {st}   <-   {ov}")
             rc = 1
