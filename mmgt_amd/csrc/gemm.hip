@@ -765,7 +765,9 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     // 59 -> 47 us at 12 frames --; between 65 and 128 tiles only long slices do: the 16x16 convs of a 12-frame window -5 %, their ff2 +10 %)
     for (int c = 8; c >= 2; --c)
       if (tiles * c <= 256 && nch % c == 0 && nch / c >= (tiles <= 64 ? 16 : 64)) { S = c; break; }
-    if (S >= 2 && tiles <= 128) return mmgt_gemm16_splitk(MODE, bn, &ad, W, &ep, M, N, K, S, s, 0);
+    // (dense shapes between 33 and 64 tiles -- ff2 of the 8x8 level at 24 frames, 3072 x 1280 x 5120 -- run 8 % faster on the 128 x 64 tile
+    //  than split four ways: 58.1 against 63.0 us, profiles/r5/ab_cfg_deep_r5.txt; the convs of that level keep the split: 126 -> 71 us)
+    if (S >= 2 && tiles <= 128 && (MODE == 1 || tiles <= 32 || tiles > 64)) return mmgt_gemm16_splitk(MODE, bn, &ad, W, &ep, M, N, K, S, s, 0);
   }
   if (cfg == 18) cfg = 0;
   if (cfg == 0) {
