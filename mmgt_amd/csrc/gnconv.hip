@@ -257,6 +257,7 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
       // a vector of the next unit's halo per half-tap, half of it under each k-step's MFMAs (unconditional: without a next unit it works on
       // stale registers; a uniform branch would put it in a basic block of its own, in front of the MFMAs instead of between them)
       constexpr bool NORM = S >= 6 && S < 6 + GC_NVL && !(ABL & 64);
+      constexpr int NV = NORM ? S - 6 : 0;                 // the halo vector of this half-tap
       // the MFMAs of a k-step, two dwords of the halo vector between them
       auto burst = [&](s16x8 (&fw_)[4], s16x8 (&fa_)[RT], auto J0c) {
         constexpr int J0 = decltype(J0c)::value;
@@ -267,8 +268,8 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
             if constexpr (!(ABL & 1)) gc_mma(acc[i][j], fw_[j], fa_[i]);
             else acc[i][j][0] += __builtin_bit_cast(float, (int)fw_[j][0] ^ (int)fa_[i][0]);
           }
-          if constexpr (NORM && i == 0) norm_dword(std::integral_constant<int, S - 6>{}, std::integral_constant<int, J0>{});
-          if constexpr (NORM && i == RT / 2) norm_dword(std::integral_constant<int, S - 6>{}, std::integral_constant<int, J0 + 1>{});
+          if constexpr (NORM && i == 0) norm_dword(std::integral_constant<int, NV>{}, std::integral_constant<int, J0>{});
+          if constexpr (NORM && i == RT / 2) norm_dword(std::integral_constant<int, NV>{}, std::integral_constant<int, J0 + 1>{});
         });
       };
       // (scheduling hint: one MFMA, then a few of the normalisation's VALU instructions, ...; then the region ends)
