@@ -45,9 +45,9 @@ const char* mmgt_last_error(void);
  *   "attn64"   = 1 (default) / 0: the 64-queries-per-wave spatial attention kernel at head_dim 40;
  *   "gn_rows"  = 0 (default: measured choice) or the GroupNorm rows per workgroup;
  *   "splitk"   = 1 (default) / 0: split-K of long reductions on grids of at most half a tile per CU (the 8x8-level convs);
- *   "ffn_dbg"  = 0 (default) .. 2: ablation builds of mmgt_ff_fused (timing only, results are garbage for v > 0).
- *   "tleg_abl" = 0 (default) or a bit of csrc/tleg.hip's ABL list: timing ablations of mmgt_temporal_leg320 at 24 frames (results are garbage).
- *   "gnconv_abl" = 0 (default) or a value of csrc/gnconv.hip's ABL list: timing ablations of mmgt_gn_silu_conv3x3 without residual (results are garbage).
+ *   "ffn_dbg", "tleg_abl", "gnconv_abl", "rowgemm_dbg" 1 .. 4: timing ablations whose RESULTS ARE GARBAGE.  The product library does not
+ *   contain them and refuses the keys with an error; they exist in libmmgt_hip_abl.so only (`make -C mmgt_amd/csrc abl`, -DMMGT_ABLATE),
+ *   which the instruments under tools/ build and load explicitly (tools/abl_lib.py).
  *   "tailsplit" = 1 (default) / 0: convs whose tile count leaves the last round of the persistent grid half empty run that round's rows
  *               as a second launch with the reduction split in two (A/B switch).
  * One kernel per family ships: the measured-slower variants of earlier rounds (gemm16s / gemm16v, the phased and register-staged

@@ -94,7 +94,7 @@ __device__ __forceinline__ s16x8 pack8(const float (&v)[8]) {
   return cv.s;
 }
 
-// DBG (mmgt_tune("ffn_dbg", v), measurements only): 1 = every weight piece takes the poison offset (nothing is fetched: the
+// DBG (mmgt_tune("ffn_dbg", v) of the -DMMGT_ABLATE build, measurements only): 1 = every weight piece takes the poison offset (nothing is fetched: the
 // compute streams alone), 2 = no MFMA / GELU (the weight stream alone); results are garbage.
 
 // ===================================================================================================================
@@ -545,12 +545,18 @@ int ff_fused_launch(const void* x, long ldx, const float* ln_gamma, const float*
     return done = true;
   };
   {
+#ifdef MMGT_ABLATE   // timing ablations (results are garbage): only in libmmgt_hip_abl.so (`make abl`), never in the product library
     auto kern = wpo ? (g_ffn_dbg == 1 ? ff_fused1_kernel<1, false, true> : g_ffn_dbg == 2 ? ff_fused1_kernel<2, false, true>
                        : g_ffn_trace ? ff_fused1_kernel<0, true, true> : ff_fused1_kernel<0, false, true>)
                     : (g_ffn_dbg == 1 ? ff_fused1_kernel<1, false, false> : g_ffn_dbg == 2 ? ff_fused1_kernel<2, false, false>
                        : g_ffn_trace ? ff_fused1_kernel<0, true, false> : ff_fused1_kernel<0, false, false>);
-    static bool attr[2][4] = {};
     const int ai = g_ffn_dbg == 1 ? 1 : g_ffn_dbg == 2 ? 2 : g_ffn_trace ? 3 : 0;
+#else
+    auto kern = wpo ? (g_ffn_trace ? ff_fused1_kernel<0, true, true> : ff_fused1_kernel<0, false, true>)
+                    : (g_ffn_trace ? ff_fused1_kernel<0, true, false> : ff_fused1_kernel<0, false, false>);
+    const int ai = g_ffn_trace ? 3 : 0;
+#endif
+    static bool attr[2][4] = {};
     if (!reserve(reinterpret_cast<const void*>(kern), attr[wpo != nullptr][ai])) return 2;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)x, ldx, ln_gamma, ln_beta, eps,
                        (const char*)wimg, inner / 32, bias2, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, M, g_ffn_trace,

@@ -971,10 +971,18 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "splitk")) { g_splitk = value; return 0; }
   if (key && !strcmp(key, "bm192")) { g_bm192 = value; return 0; }
   if (key && !strcmp(key, "tailsplit")) { g_tailsplit = value; return 0; }
+#ifdef MMGT_ABLATE   // libmmgt_hip_abl.so (`make abl`): timing ablations whose RESULTS ARE GARBAGE -- the instruments under tools/ load that library explicitly
   if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 2) { mmgt_ffn_set_dbg(value); return 0; }
   if (key && !strcmp(key, "gnconv_abl") && value >= 0 && value <= 255) { mmgt_gnconv_set_abl(value); return 0; }
   if (key && !strcmp(key, "tleg_abl") && value >= 0 && value <= 128) { mmgt_tleg_set_abl(value); return 0; }
   if (key && !strcmp(key, "rowgemm_dbg") && value >= 0 && value <= 5) { mmgt_rowgemm_set_dbg(value); return 0; }
+#else
+  if (key && !strcmp(key, "rowgemm_dbg") && (value == 0 || value == 5)) { mmgt_rowgemm_set_dbg(value); return 0; }   // 5: the stamped (correct) build
+  if (key && (!strcmp(key, "ffn_dbg") || !strcmp(key, "gnconv_abl") || !strcmp(key, "tleg_abl") || !strcmp(key, "rowgemm_dbg"))) {
+    mmgt_set_error("tune: '%s' selects a timing ablation whose results are garbage; the product library does not contain them (build libmmgt_hip_abl.so with `make -C mmgt_amd/csrc abl` and load it through MMGT_LIB)", key);
+    return 1;
+  }
+#endif
   mmgt_set_error("tune: unknown key");
   return 1;
 }

@@ -67,7 +67,7 @@ template <int LO, int HI, typename F>
 __device__ __forceinline__ void gc_for(F&& fn) { gc_for_impl<LO>(std::make_integer_sequence<int, (HI > LO ? HI - LO : 0)>{}, static_cast<F&&>(fn)); }
 
 // NPH = Cin / 128 (1, 2); COUT = 128 (8 waves = 4 x 2: 4 image rows x 64 channels each) or 64 (8 x 1: 2 image rows x 64 channels).
-// ABL (mmgt_tune("gnconv_abl", bit), timing only -- results are garbage): 1 no MFMAs, 2 no weight DMA after the prologue, 4 no halo loads /
+// ABL (mmgt_tune("gnconv_abl", bit) of the -DMMGT_ABLATE build, timing only -- results are garbage): 1 no MFMAs, 2 no weight DMA after the prologue, 4 no halo loads /
 // normalisation / LDS writes after the first tile, 8 no hand-over wait, 16 no epilogue (residual loads, stores), 32 no hand-over barrier,
 // 64 halo loads but no normalisation / LDS writes, 128 normalisation / LDS writes but no halo loads.
 // ST: the epilogue also emits, per tile and 4-channel quad, (sum, sum of squares) of the values it stores -- the statistics of the NEXT GroupNorm
@@ -487,27 +487,25 @@ extern "C" int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const flo
   a.ntiles = nb * a.tiles_per_img;
   a.ldo = ldo;
   a.stats = stats;
-  static int ncu = 0;
-  if (!ncu) {
-    int dev = 0;
+  int dev = 0;
+  static int ncu[16] = {};
+  MMGT_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "gn_silu_conv3x3: device query failed");
+  if (!ncu[dev]) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
-      mmgt_set_error("gn_silu_conv3x3: device query failed");
-      return 2;
-    }
-    ncu = prop.multiProcessorCount;
+    MMGT_CHECK(hipGetDeviceProperties(&prop, dev) == hipSuccess, "gn_silu_conv3x3: device query failed");
+    ncu[dev] = prop.multiProcessorCount;
   }
-  int gx = ncu / 8 * 8;
+  int gx = ncu[dev] / 8 * 8;
   if (gx > a.ntiles) gx = a.ntiles;
   hipStream_t s = (hipStream_t)stream;
-  static bool ready[32] = {};                              // LDS attribute set, per kernel instantiation (slot = the call site below)
+  static bool ready[16][32] = {};                          // LDS attribute set, per device and kernel instantiation (slot = the call site below)
   auto go = [&](void (*kern)(const GcArgs), int slot) -> int {
-    if (!ready[slot]) {
+    if (!ready[dev][slot]) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, GC_LDS) != hipSuccess) {
         mmgt_set_error("gn_silu_conv3x3: cannot reserve %d bytes of LDS", GC_LDS);
         return 2;
       }
-      ready[slot] = true;
+      ready[dev][slot] = true;
     }
     hipLaunchKernelGGL(kern, dim3(gx), dim3(512), GC_LDS, s, a);
     return 0;
@@ -518,18 +516,24 @@ extern "C" int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const flo
   else if (s256) rc = residual ? go(gnconv_kernel<2, 128, true, 0>, 0) : go(gnconv_kernel<2, 128, false, 0>, 1);
   else if (s64) rc = go(gnconv_kernel<1, 64, false, 0>, 2);
   else if (residual) rc = go(gnconv_kernel<1, 128, true, 0>, 3);
-  else switch (g_gnconv_abl) {
-    case 1: rc = go(gnconv_kernel<1, 128, false, 1>, 4); break;
-    case 2: rc = go(gnconv_kernel<1, 128, false, 2>, 5); break;
-    case 4: rc = go(gnconv_kernel<1, 128, false, 4>, 6); break;
-    case 8: rc = go(gnconv_kernel<1, 128, false, 8>, 7); break;
-    case 16: rc = go(gnconv_kernel<1, 128, false, 16>, 8); break;
-    case 32: rc = go(gnconv_kernel<1, 128, false, 32>, 9); break;
-    case 6: rc = go(gnconv_kernel<1, 128, false, 6>, 10); break;
-    case 22: rc = go(gnconv_kernel<1, 128, false, 22>, 11); break;
-    case 64: rc = go(gnconv_kernel<1, 128, false, 64>, 12); break;
-    case 128: rc = go(gnconv_kernel<1, 128, false, 128>, 13); break;
-    default: rc = go(gnconv_kernel<1, 128, false, 0>, 14); break;
+  else {
+    rc = -1;
+#ifdef MMGT_ABLATE   // timing ablations (results are garbage): only in libmmgt_hip_abl.so (`make abl`), never in the product library
+    switch (g_gnconv_abl) {
+      case 1: rc = go(gnconv_kernel<1, 128, false, 1>, 4); break;
+      case 2: rc = go(gnconv_kernel<1, 128, false, 2>, 5); break;
+      case 4: rc = go(gnconv_kernel<1, 128, false, 4>, 6); break;
+      case 8: rc = go(gnconv_kernel<1, 128, false, 8>, 7); break;
+      case 16: rc = go(gnconv_kernel<1, 128, false, 16>, 8); break;
+      case 32: rc = go(gnconv_kernel<1, 128, false, 32>, 9); break;
+      case 6: rc = go(gnconv_kernel<1, 128, false, 6>, 10); break;
+      case 22: rc = go(gnconv_kernel<1, 128, false, 22>, 11); break;
+      case 64: rc = go(gnconv_kernel<1, 128, false, 64>, 12); break;
+      case 128: rc = go(gnconv_kernel<1, 128, false, 128>, 13); break;
+      default: break;
+    }
+#endif
+    if (rc < 0) rc = go(gnconv_kernel<1, 128, false, 0>, 14);
   }
   if (rc) return rc;
   MMGT_LAUNCH_CHECK();

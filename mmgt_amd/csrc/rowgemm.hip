@@ -302,10 +302,15 @@ extern "C" int mmgt_rowgemm320(const void* x, long ldx, int norm, const float* l
   a.out_t = (bf16_t*)out_t; a.n_tok = n_tok > 0 ? n_tok : 128; a.npad = npad;
   a.M = M; a.N = N;
   a.trace = g_rowgemm_trace;
+#ifdef MMGT_ABLATE   // timing ablations 1 - 4 (results are garbage): only in libmmgt_hip_abl.so (`make abl`), never in the product library
   const int d = g_rowgemm_dbg;
   auto kern = residual ? (d == 1 ? rowgemm320_kernel<true, 1> : d == 2 ? rowgemm320_kernel<true, 2> : rowgemm320_kernel<true, 0>)
                        : (d == 1 ? rowgemm320_kernel<false, 1> : d == 2 ? rowgemm320_kernel<false, 2> : d == 3 ? rowgemm320_kernel<false, 3>
                           : d == 4 ? rowgemm320_kernel<false, 4> : d == 5 ? rowgemm320_kernel<false, 5> : rowgemm320_kernel<false, 0>);
+#else                // (5 = the stamped build of tools/trace_rowgemm.py: correct results, needs the trace buffer)
+  const int d = g_rowgemm_dbg == 5 && !residual && g_rowgemm_trace ? 5 : 0;
+  auto kern = residual ? rowgemm320_kernel<true, 0> : d == 5 ? rowgemm320_kernel<false, 5> : rowgemm320_kernel<false, 0>;
+#endif
   static bool attr[2][6] = {};
   if (!attr[residual != nullptr][d]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS) != hipSuccess) {

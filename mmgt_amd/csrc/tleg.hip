@@ -92,7 +92,7 @@ template <int F> constexpr bool tl_pair(int kt, int qt) { return (16 * kt) / F <
 // ... and is every pair of them in the same pixel (no mask needed)?
 template <int F> constexpr bool tl_all(int kt, int qt) { return (16 * kt) / F == (16 * kt + 15) / F && (16 * qt) / F == (16 * qt + 15) / F && (16 * kt) / F == (16 * qt) / F; }
 
-// ABL (mmgt_tune("tleg_abl", bits), 24-frame kernel, timing only -- results are garbage): 1 no LayerNorm arithmetic, 2 no attention arithmetic,
+// ABL (mmgt_tune("tleg_abl", bits) of the -DMMGT_ABLATE build, 24-frame kernel, timing only -- results are garbage): 1 no LayerNorm arithmetic, 2 no attention arithmetic,
 // 4 no weight DMA after the first chunk, 8 no epilogue (residual loads, stores), 16 no projection MFMAs, 32 no hand-over wait / barrier, 64 no row loads
 // after the first task, 128 the counted waits of the hand-over but no barrier
 template <int F, int ABL>
@@ -544,6 +544,7 @@ extern "C" int mmgt_temporal_leg320(const void* x, void* out, const float* ln_ga
   };
   static bool attr[16][13] = {};
   if (frames == 24) {
+#ifdef MMGT_ABLATE   // timing ablations (results are garbage): only in libmmgt_hip_abl.so (`make abl`), never in the product library
     switch (g_tleg_abl) {
       case 1: return go(tleg320_kernel<24, 1>, attr[dev][4]);
       case 2: return go(tleg320_kernel<24, 2>, attr[dev][5]);
@@ -554,8 +555,10 @@ extern "C" int mmgt_temporal_leg320(const void* x, void* out, const float* ln_ga
       case 64: return go(tleg320_kernel<24, 64>, attr[dev][10]);
       case 36: return go(tleg320_kernel<24, 36>, attr[dev][11]);
       case 128: return go(tleg320_kernel<24, 128>, attr[dev][12]);
-      default: return go(tleg320_kernel<24, 0>, attr[dev][0]);
+      default: break;
     }
+#endif
+    return go(tleg320_kernel<24, 0>, attr[dev][0]);
   }
   return go(tleg320_kernel<12, 0>, attr[dev][1]);
 }

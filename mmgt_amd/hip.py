@@ -118,9 +118,19 @@ def lib():
     return _lib
 
 
+_calls = {}
+
+
 def _check(rc, what):
+    _calls[what] = _calls.get(what, 0) + 1
     if rc != 0:
         raise RuntimeError(f"{what} failed (rc={rc}): {lib().mmgt_last_error().decode()}")
+
+
+def call_count(what):
+    """How often the entry point `what` (an include/mmgt_hip.h name) has been called through this binding: lets a test assert WHICH kernel a
+    dispatcher took."""
+    return _calls.get(what, 0)
 
 
 def tune(key, value):
@@ -534,14 +544,20 @@ def rowgemm320(x, wimg, N, bias=None, *, ln_gamma=None, ln_beta=None, pe_div=0, 
     return out, out_t
 
 
-def temporal_leg320_supported(dtype, C, heads, frames, n_pix):
-    return dtype == torch.bfloat16 and C == 320 and heads == 8 and frames in (12, 24) and n_pix % (4 * 48 // frames) == 0
+def temporal_leg320_supported(dtype, C, heads, frames, n_pix, batch=1):
+    """What csrc/tleg.hip is built for: bf16, 8 heads of 40, windows of 24 or 12 frames, whole 4-wave tasks, a tensor a buffer resource
+    can address (2 GiB) -- a caller with any other shape takes the three-launch path."""
+    return dtype == torch.bfloat16 and C == 320 and heads == 8 and frames in (12, 24) and n_pix % (4 * 48 // frames) == 0 and \
+        batch * frames * n_pix * 640 < (1 << 31)
 
 
 def temporal_leg320(x, ln_gamma, beta_pe, wimg, bias_o, batch, frames, n_pix, scale, eps=1e-5, out=None):
     """x + to_out(temporal attention(LayerNorm(x) + pe)) of a level-0 motion-module attention block in ONE launch (csrc/tleg.hip).  x (batch *
     frames * n_pix, 320) bf16 rows (batch, frame, pixel); beta_pe (>= frames, 320) fp32 = LayerNorm bias + pe rows; wimg = packing.pack_tleg."""
     _dev(x, ln_gamma, beta_pe, wimg, bias_o, out)
+    if not (x.dim() == 2 and temporal_leg320_supported(x.dtype, x.shape[1], 8, frames, n_pix, batch)):
+        raise RuntimeError(f"temporal_leg320: unsupported shape (dtype {x.dtype}, {tuple(x.shape)}, {frames} frames x {n_pix} pixels x batch {batch}): "
+                           "8 heads of 40 channels, 12 or 24 frames, bf16, < 2 GiB")
     assert x.dim() == 2 and x.shape == (batch * frames * n_pix, 320) and x.is_contiguous() and x.dtype == torch.bfloat16
     assert wimg.dtype == torch.uint8 and wimg.is_contiguous() and wimg.numel() == lib().mmgt_temporal_leg320_image_bytes()
     assert beta_pe.dim() == 2 and beta_pe.shape[1] == 320 and beta_pe.shape[0] >= frames

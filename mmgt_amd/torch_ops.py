@@ -199,6 +199,9 @@ def temporal_leg(x: torch.Tensor, ln_gamma: torch.Tensor, beta_pe: torch.Tensor,
     (motion_module.py:236-259,351-388): x (batch * frames * n_pix, 320) bf16 rows (batch, frame, pixel), beta_pe (>= frames, 320) fp32 =
     LayerNorm bias + positional-encoding rows, wimg = packing.pack_tleg(Wq, Wk, Wv, Wo).  frames = 24 or 12."""
     n_pix = x.shape[0] // (batch * frames)
+    if not hip.temporal_leg320_supported(x.dtype, x.shape[1], heads, frames, n_pix, batch):
+        raise RuntimeError(f"mmgt_hip::temporal_leg: built for 8 heads of 40 channels, 12 or 24 frames, bf16 (got {heads} heads, {x.shape[1]} channels, "
+                           f"{frames} frames, {x.dtype})")
     return hip.temporal_leg320(x, ln_gamma, beta_pe, wimg, bias_o, batch, frames, n_pix, (x.shape[1] // heads) ** -0.5)
 
 

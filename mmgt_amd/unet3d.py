@@ -770,7 +770,7 @@ class UNet3DConditionModel:
         hid = self._norm_proj_in(q, x)
         for i in range(2):
             a = f"{t}.attention_blocks.{i}"
-            if (a + ".tleg_img") in self.w and (f"{t}.norms.{i}.bpe") in self.w and hip.temporal_leg320_supported(self._dtype, c, self.heads, frames, n):
+            if (a + ".tleg_img") in self.w and (f"{t}.norms.{i}.bpe") in self.w and hip.temporal_leg320_supported(self._dtype, c, self.heads, frames, n, b):
                 hid = hip.temporal_leg320(hid, self.w[f"{t}.norms.{i}.g"], self.w[f"{t}.norms.{i}.bpe"], self.w[a + ".tleg_img"], self.w[a + ".o.bias"],
                                           b, frames, n, hd ** -0.5)
                 continue

@@ -73,6 +73,7 @@ def entry_specs():
     from tests import test_pipeline_gpu as TP
     from tests import test_smga as TS
     from tests import test_unet_gpu as TU
+    from tests import test_vae as TV
     pipe = (TP._inputs, TP.build_weights, pose_guider_spec, unet2d_reference_spec, vae_decoder_spec)
     return {
         "pipeline_fp32_8_12_4": ("8,12,4", pipe + (TP.oracle_pipeline_fp32,)),
@@ -81,6 +82,8 @@ def entry_specs():
         "long_video_96": ("", pipe + (TP.oracle_long_video,)),
         "unet_512x512_six_frames": (repr(sorted(TU.SIX_FRAME_CASE.items())), (TU._run_oracle,)),
         "smga_sampler_bf16_floor": ("", (TS.smga_bf16_floor,)),
+        "unet_512x512_twelve_frames": (repr(sorted(TU.TWELVE_FRAME_CASE.items())), (TU._run_oracle,)),
+        "vae_decode_512x512_frame": ("", (TV._sd, TV.oracle_full_resolution_frame, vae_decoder_spec)),
     }
 
 

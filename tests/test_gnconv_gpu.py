@@ -128,6 +128,37 @@ def test_gnconv_statistics_of_the_output(cin, cout, res, nb, H, W):
     assert torch.equal(stats, stats2)
 
 
+def test_gnconv_statistics_of_an_output_whose_mean_is_30_sigma():
+    """the epilogue's tallies are UNSHIFTED fp32 sums, so the finalize kernel's var = E[x^2] - mean^2 loses log2(mean^2 / var) bits (the
+    pass over the tensor in norm.hip shifts by a pivot).  At |mean| = 30 sigma (a conv bias of 30: ~10 bits of the 24) the tables from the producing
+    launch must still agree with the pass over the tensor and with fp64 at a level a bf16 consumer cannot see (its own rounding is 2^-8 = 4e-3)."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_gnconv
+    nb, H, W, cout = 2, 64, 64, 128
+    x, w, b, r, scale, shift = _case(nb, H, W, 77, False)
+    b = b + 30.0 * _ref(x, w, None, None, scale, shift).std().float()
+    g = torch.Generator(device="cpu").manual_seed(10)
+    gamma, beta = (0.5 + torch.rand(cout, generator=g)).to(dev()), (torch.rand(cout, generator=g) - 0.5).to(dev())
+    stats = torch.empty((nb * (H // 16) * (W // 16), cout // 4, 2), device=dev())
+    out = hip.gn_silu_conv3x3_tables(x, scale, shift, pack_gnconv(w), cout, b, None, stats=stats)
+    o = out.double().view(nb, H * W, 32, cout // 32)
+    mean, var = o.mean(dim=(1, 3)), o.var(dim=(1, 3), unbiased=False)
+    assert (mean.abs() / var.sqrt()).min() > 20
+    sc, sh = hip.gn_tables_from_stats(stats, gamma, beta, 32, 1e-6, nb, cout)
+    sc2, sh2 = hip.groupnorm_affine(out.view(nb, H * W, cout), gamma, beta, 32, 1e-6)
+    want_sc = gamma.double().view(1, 32, -1) * (var + 1e-6).rsqrt()[:, :, None]
+    e1 = ((sc.double().view(nb, 32, -1) - want_sc) / want_sc).abs().max().item()
+    e2 = ((sc2.double().view(nb, 32, -1) - want_sc) / want_sc).abs().max().item()
+    # normalised values (x * scale + shift) at the group's typical |x - mean| = sigma: the error a consumer sees, in units of sigma
+    xs = mean[:, :, None] + var.sqrt()[:, :, None]
+    y1 = xs * sc.double().view(nb, 32, -1) + sh.double().view(nb, 32, -1)
+    y0 = xs * want_sc + (beta.double().view(1, 32, -1) - mean[:, :, None] * want_sc)
+    ey = ((y1 - y0).abs() / gamma.double().view(1, 32, -1)).max().item()
+    print(f"|mean| = {(mean.abs() / var.sqrt()).mean().item():.0f} sigma: relative scale error from the launch's tallies {e1:.2e}, from the shifted pass {e2:.2e}; "
+          f"normalised-value error {ey:.2e} sigma")
+    assert e1 < 2e-3 and ey < 4e-3 and e2 < 1e-4
+
+
 def test_gnconv_no_bias_and_zero_padding():
     """shift != 0 makes silu(shift) != 0 at a zero INPUT: the padding must be zeros after the activation.  Constant input: every interior
     pixel sees nine taps, edges six, corners four."""

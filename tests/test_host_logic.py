@@ -101,13 +101,52 @@ def test_device_code_has_no_unguarded_store_or_mfma_hazard():
     wait states (hipcc omits the wait states when the store's soffset is a register; MI355X then stores wrong values in lanes 12 .. 15 of each
     16-lane row).  Found in csrc/gnconv.hip in round 5; it also sat, without a failing test, in csrc/tleg.hip."""
     import os
+    import shutil
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no hipcc / llvm-objdump on this host")
     subprocess.run(["make", "-C", os.path.join(root, "mmgt_amd", "csrc"), "-j8"], check=True, capture_output=True)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_mfma_overlap.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-4000:]
     assert "gnconv.o" in r.stdout and "tleg.o" in r.stdout and "gemm16.o" in r.stdout
+    # fails closed: an object built on MFMAs in which the scan parses none (a disassembler format change) is an error, not a pass
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_mfma_overlap.py"), os.path.join(root, "mmgt_amd", "csrc", "build", "elementwise.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and re.search(r"elementwise\.o\s+0 MFMAs", r.stdout), r.stdout
+    fake = os.path.join(root, "mmgt_amd", "csrc", "build", "_scan_selftest")
+    os.makedirs(fake, exist_ok=True)
+    try:
+        shutil.copy(os.path.join(root, "mmgt_amd", "csrc", "build", "elementwise.o"), os.path.join(fake, "gemm16.o"))     # an MFMA object's NAME, no MFMA inside
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_mfma_overlap.py"), os.path.join(fake, "gemm16.o")], capture_output=True, text=True)
+        assert r.returncode == 2 and "PARSED NOTHING" in r.stdout
+    finally:
+        shutil.rmtree(fake)
+
+
+def test_product_library_refuses_the_timing_ablations():
+    """`mmgt_tune("ffn_dbg" | "tleg_abl" | "gnconv_abl" | "rowgemm_dbg" 1..4)` select instantiations whose results are garbage.
+    They are compiled only under -DMMGT_ABLATE into libmmgt_hip_abl.so; the product library holds ONE 24-frame temporal-leg kernel, refuses the keys,
+    and an MMGT_TUNE environment that names one fails at load instead of silently producing wrong frames."""
+    import os
+    import subprocess
+    import sys
+    from mmgt_amd import hip
+    L = hip.lib()
+    for key, v in (("ffn_dbg", 1), ("tleg_abl", 16), ("gnconv_abl", 1), ("rowgemm_dbg", 2)):
+        assert L.mmgt_tune(key.encode(), v) != 0, key
+        assert "garbage" in L.mmgt_last_error().decode()
+        with pytest.raises(RuntimeError):
+            hip.tune(key, v)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    nm = subprocess.run(["nm", "-C", os.path.join(root, "mmgt_amd", "libmmgt_hip.so")], capture_output=True, text=True, check=True).stdout
+    host_stubs = lambda pat: sum(1 for line in nm.splitlines() if pat in line and "__device_stub__" in line)
+    assert host_stubs("tleg320_kernel<24") == 1 and host_stubs("tleg320_kernel<12") == 1, nm.count("tleg320_kernel")
+    assert host_stubs("ff_fused1_kernel<1") == 0 and host_stubs("ff_fused1_kernel<2") == 0
+    r = subprocess.run([sys.executable, "-c", "from mmgt_amd import hip; hip.lib()"], cwd=root, env=dict(os.environ, MMGT_TUNE="tleg_abl=16"),
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "garbage" in r.stderr
 
 
 def test_pack_gnconv_fragment_image():

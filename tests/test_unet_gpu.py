@@ -249,6 +249,46 @@ def test_unet_full_resolution_512x512_six_frames(full_sd, golden_dir):
     assert d16.max() <= FLOOR_SLACK * fmax and d16.mean() <= FLOOR_SLACK * fmean
 
 
+TWELVE_FRAME_CASE = dict(gc.UNET_CASES["full_cfg1"], frames=12, latent=64, timestep=499)
+
+
+def test_unet_shipped_window_512x512_twelve_frames(full_sd, golden_dir):
+    """The reference's SHIPPED window (`context_frames=12`: /root/reference/src/pipelines/pipeline_pose2vid_long.py:360-362) at the benchmarked
+    spatial size: M = 98 304 token rows at level 0 -- `tleg320_kernel<12>` (4 pixels x 12 frames per wave), the 192-row `gemm16` tiles and
+    every dispatcher branch that differs from the 24-frame shape.  fp32-I/O mode against the CPU oracle at the north-star tolerance; bf16
+    product mode within 1.5x the CPU-bf16 floor; the fused temporal leg must have been the path taken (its launch count is read back), and
+    the three-launch form of the same legs must agree with it at the rounding level of the floor."""
+    from mmgt_amd import hip
+    sd_gpu, sd_cpu = full_sd
+    case = TWELVE_FRAME_CASE
+    ref = cached("unet_512x512_twelve_frames", lambda: _run_oracle(sd_cpu, case))
+    out = _run_hip(sd_gpu, case, torch.float32)
+    d = (out - ref).abs()
+    print("512x512x12 fp32 mode: max|d|", d.max().item(), "mean|x|", ref.abs().mean().item())
+    torch.testing.assert_close(out, ref, rtol=1e-3, atol=1e-4)
+    del out
+    fmax, fmean = _floor_cfg2(golden_dir)
+    n0 = hip.call_count("mmgt_temporal_leg320")
+    out16 = _run_hip(sd_gpu, case, torch.bfloat16)
+    legs = hip.call_count("mmgt_temporal_leg320") - n0
+    assert legs == 10, f"the fused temporal leg ran {legs} times in a 12-frame forward (5 level-0 motion modules x 2 legs expected)"
+    d16 = (out16 - ref).abs()
+    print(f"512x512x12 bf16 mode: max|d| {d16.max().item():.3e} mean|d| {d16.mean().item():.3e} (floor {fmax:.3e} / {fmean:.3e})")
+    assert torch.isfinite(out16).all()
+    assert d16.max() <= FLOOR_SLACK * fmax and d16.mean() <= FLOOR_SLACK * fmean
+    assert torch.equal(_run_hip(sd_gpu, case, torch.bfloat16), out16)
+    try:
+        hip.tune("tleg", 0)
+        n0 = hip.call_count("mmgt_temporal_leg320")
+        three = _run_hip(sd_gpu, case, torch.bfloat16)
+        assert hip.call_count("mmgt_temporal_leg320") == n0
+    finally:
+        hip.tune("tleg", 1)
+    d3 = (three - ref).abs()
+    assert d3.max() <= FLOOR_SLACK * fmax and d3.mean() <= FLOOR_SLACK * fmean
+    assert not torch.equal(three, out16)            # two different computations of the same legs
+
+
 def test_unet_benchmarked_shape_512x512x24_matches_reference_golden(full_sd, golden_dir):
     """G4: BASELINE config 2 = exactly what bench.py times -- latent (2,4,24,64,64), M = 196608 token rows at
     level 0, the tile choices that only trigger at 24 frames.  The fixture is a strided sub-sample + moments of the

@@ -152,9 +152,20 @@ def test_hip_vae_split_attention(gain):
     torch.testing.assert_close(out, ref, rtol=0, atol=4e-2)
 
 
+def oracle_full_resolution_frame():
+    """The oracle's decode of frame 1 of the full-resolution test latent (64 x 64 latent -> one 512 x 512 frame, ~2.5 TFLOP of CPU work):
+    tests/golden/oracle_cache/vae_decode_512x512_frame.pt (tests/oracle_cache.py)."""
+    with torch.no_grad():
+        return vae_ref.decode_latents(_sd(), hash_uniform("vae.lat512", (1, 4, 2, 64, 64), 1.0)[:, :, 1:2])
+
+
 @pytest.mark.gpu
-def test_hip_vae_full_resolution_frame_is_finite():
-    """One 512x512 frame (64x64 latent) in bf16: the size the sampler decodes; checked through frame independence."""
+def test_hip_vae_full_resolution_frame():
+    """One 512x512 frame (64x64 latent) in bf16: the size the sampler decodes (pipeline_pose2vid_long.py:112-125), against the ORACLE's decode of
+    the same latent at the bf16 gate in all three forms of the GroupNorm -> SiLU -> conv legs -- only a full-resolution frame has `gnconv`
+    tiles in the interior, on every edge and many tiles per workgroup, the statistics chain across its 12 launches and the two-launch
+    256-wide split -- and through frame independence."""
+    from tests.oracle_cache import cached
     from mmgt_amd.vae import AutoencoderKL
     vae = AutoencoderKL(device="cuda:0", dtype=torch.bfloat16)
     vae.load_state_dict(_sd("cuda:0"))
@@ -162,6 +173,13 @@ def test_hip_vae_full_resolution_frame_is_finite():
     both = vae.decode_video(lat, frames_per_batch=2)
     single = vae.decode_video(lat[:, :, 1:2].contiguous(), frames_per_batch=1)
     assert both.shape == (1, 3, 2, 512, 512) and torch.isfinite(both).all()
+    ref = cached("vae_decode_512x512_frame", oracle_full_resolution_frame)
+    assert ref.shape == (1, 3, 1, 512, 512)
+    for name, got in (("two frames", both[:, :, 1:2]), ("one frame", single)):
+        d = (got.cpu() - ref).abs()
+        print(f"512x512 VAE frame, {name}, vs oracle: max|d| {d.max().item():.3e} mean|d| {d.mean().item():.3e}")
+        torch.testing.assert_close(got.cpu(), ref, rtol=0, atol=4e-2)
+        assert d.mean() <= 4e-3
     # A frame's pixels do not depend on its batch mates beyond bf16 rounding: the GEMM dispatcher may pick another tile for M = 1
     # frame than for 2 (gemm16 adds the bias in fp32 as the accumulator's start, the 32x32 tiles as a bf16 head + tail), so the
     # comparison is at the rounding level of a 30-layer bf16 decoder, not bitwise.  Measured: max 2.1e-2, mean 2.0e-3 (1.7e-3 with the
@@ -182,6 +200,7 @@ def test_hip_vae_full_resolution_frame_is_finite():
     for other in (two, one):
         d = (both - other).abs()
         assert d.max() <= 5e-2 and d.mean() <= 3e-3, (d.max().item(), d.mean().item())
+        torch.testing.assert_close(other[:, :, 1:2].cpu(), ref, rtol=0, atol=4e-2)          # each form against the oracle, not only against each other
     assert torch.equal(both, vae.decode_video(lat, frames_per_batch=2))                      # repeatable
 
 

@@ -15,7 +15,10 @@ from mmgt_amd import hip  # noqa: E402
 
 dev = torch.device("cuda:0")
 libs = {}
-for path in sorted(glob.glob(os.path.join(ROOT, "mmgt_amd", "libmmgt_hip*.so"))):
+paths = [os.path.join(ROOT, "mmgt_amd", "libmmgt_hip.so")] + sorted(glob.glob(os.path.join(ROOT, "mmgt_amd", "csrc", "build", "libmmgt_hip_v*.so")))
+if len(paths) < 2:
+    sys.exit("ab_gemm: no variant library under mmgt_amd/csrc/build/ -- run `make -C mmgt_amd/csrc ab` first (nothing to compare)")
+for path in paths:
     L = ctypes.CDLL(path)
     for name in ("mmgt_gemm", "mmgt_conv3x3_nhwc", "mmgt_tune"):
         fn = getattr(L, name)

@@ -9,6 +9,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tools import abl_lib  # noqa: E402
+abl_lib.use()             # the timing ablations live in libmmgt_hip_abl.so only (make abl); the product library refuses their keys
 from mmgt_amd import hip  # noqa: E402
 from mmgt_amd.packing import pack_conv3x3, pack_gnconv  # noqa: E402
 

@@ -7,6 +7,8 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools import abl_lib  # noqa: E402
+abl_lib.use()             # the timing ablations live in libmmgt_hip_abl.so only (make abl); the product library refuses their keys
 from mmgt_amd import hip  # noqa: E402
 from mmgt_amd.packing import pack_rowgemm, pack_tleg  # noqa: E402
 from mmgt_amd.synthetic import hash_uniform  # noqa: E402

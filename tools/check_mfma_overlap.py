@@ -27,8 +27,9 @@ STORE = re.compile(r"((?:buffer|global|flat|scratch)_store_dwordx[34])\s+(?:v\d+
 VDEF = re.compile(r"^\s*(v_\w+)\s+v(?:\[(\d+):(\d+)\]|(\d+))(?:,\s*v(?:\[(\d+):(\d+)\]|(\d+)))?")
 
 
-def store_hazards(lines):
-    """(function, store, overwriting instruction) for stores of more than 8 bytes whose data is rewritten within two wait states"""
+def store_hazards(lines, count=None):
+    """(function, store, overwriting instruction) for stores of more than 8 bytes whose data is rewritten within two wait states; count[0] += the
+    wide stores parsed"""
     out, func = [], "?"
     for k, line in enumerate(lines):
         m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
@@ -45,6 +46,8 @@ def store_hazards(lines):
         d0, d1 = (int(md.group(1)), int(md.group(2))) if md else (int(m.group(2)), int(m.group(3)))
         if d1 - d0 < 2:
             continue
+        if count is not None:
+            count[0] += 1
         waited = 0
         for nxt in lines[k + 1:k + 6]:
             t = nxt.split("//")[0]
@@ -97,15 +100,32 @@ def scan(obj):
         dk, d0, d1, ck, c0, c1 = m.group(2), int(m.group(3)), int(m.group(4)), m.group(5), int(m.group(6)), int(m.group(7))
         if dk == ck and (d0, d1) != (c0, c1) and d0 <= c1 and c0 <= d1:
             bad.append((func, line.strip().split("//")[0].strip()))
-    return total, bad, store_hazards(dis.splitlines())
+    nst = [0]
+    sth = store_hazards(dis.splitlines(), nst)
+    return total, bad, sth, nst[0]
+
+
+# objects whose kernels are built on MFMAs and 16-byte stores: the scan must FIND both in them -- a disassembler whose text no longer matches the
+# patterns above (or an empty build directory) must fail the check, not pass it vacuously
+MFMA_OBJECTS = ("gemm.o", "gemm16.o", "ffn.o", "rowgemm.o", "attention.o", "attn64.o", "tleg.o", "gnconv.o")
+NO_WIDE_STORES = ("attn64.o",)          # (its outputs leave as 8-byte stores)
 
 
 def main():
     objs = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, "mmgt_amd", "csrc", "build", "*.o")))
     rc = 0
+    if not sys.argv[1:]:
+        missing = [m for m in MFMA_OBJECTS if m not in {os.path.basename(o) for o in objs}]
+        if missing:
+            print(f"check_mfma_overlap: objects not built: {missing} (run make -C mmgt_amd/csrc first)")
+            return 2
     for o in objs:
-        total, bad, sth = scan(o)
-        print(f"{os.path.basename(o):24s} {total:6d} MFMAs, {len(bad)} with vDst partially overlapping SrcC; {len(sth)} wide stores whose data is rewritten at once")
+        total, bad, sth, nst = scan(o)
+        print(f"{os.path.basename(o):24s} {total:6d} MFMAs, {len(bad)} with vDst partially overlapping SrcC; {nst} wide stores, {len(sth)} whose data is rewritten at once")
+        base = os.path.basename(o).replace("abl_", "")
+        if base in MFMA_OBJECTS and (total == 0 or (nst == 0 and base not in NO_WIDE_STORES)):
+            print(f"    PARSED NOTHING: {total} MFMAs / {nst} wide stores in an object that is built on them -- the disassembly no longer matches this tool's patterns")
+            rc = 2
         for f, l in bad[:20]:
             print(f"    (harmless) {f[:80]}: {l}")
         for f, st, ov in sth[:20]:

@@ -51,6 +51,16 @@ def main():
         case = TU.SIX_FRAME_CASE
         emit("unet_512x512_six_frames", lambda: TU._run_oracle(sd_cpu, case))
         del sd_cpu
+    if want("unet_512x512_twelve_frames"):
+        from mmgt_amd.synthetic import synth_state_dict
+        from mmgt_amd.unet3d_spec import unet3d_spec
+        from tests import test_unet_gpu as TU
+        sd_cpu = synth_state_dict(unet3d_spec(), device="cpu")
+        emit("unet_512x512_twelve_frames", lambda: TU._run_oracle(sd_cpu, TU.TWELVE_FRAME_CASE))
+        del sd_cpu
+    if want("vae_decode_512x512_frame"):
+        from tests import test_vae as TV
+        emit("vae_decode_512x512_frame", TV.oracle_full_resolution_frame)
     if want("smga_sampler_bf16_floor"):
         from tests import test_smga as TS
         gold = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(ROOT, "tests", "golden", "smga.npz")).items()}
