@@ -54,7 +54,7 @@ const char* mmgt_last_error(void);
  * head_dim-40 attention kernels, the producer / consumer FeedForward) are records under tools/micro/. */
 int mmgt_tune(const char* key, int value);
 /* Host-side switches kept in the same table (what mmgt_amd/unet3d.py, pipeline.py and smga.py consult; all default 1, 0 = the
- * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "tleg", "gnconv" (mmgt_amd/vae.py),
+ * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "tleg", "rconv" (1: the 320-wide resnets, 2: + 640, 3: all), "gnconv" (mmgt_amd/vae.py),
  * "zero_audio_skip", "window_state", "smga_graph".  mmgt_tune sets them, mmgt_tune_get reads them: one state describes a run. */
 int mmgt_tune_get(const char* key, int* value);
 /* Box calibration for bench.py's `box_calib` (csrc/calib.hip): a bare v_mfma_f32_16x16x32_bf16 loop on random operands, one wave per SIMD,
@@ -107,6 +107,10 @@ int mmgt_groupnorm_chunks(int HW);
  * HW > 256): mmgt_rowgemm320(norm = 2) applies them while it loads x -- transformer_3d.py:174-188 (norm -> proj_in), motion_module.py:156-170. */
 int mmgt_groupnorm_affine(const void* x, int C, const float* gamma, const float* beta, float* workspace, float* scale, float* shift,
                           int NB, int HW, int G, float eps, int dtype, void* stream);
+/* ... of the channel concatenation x0 | x1 (a resnet's norm1 behind a skip connection: unet_3d_blocks.py:941-969; groups may straddle the seam);
+ * x1 NULL / C1 0: one tensor. */
+int mmgt_groupnorm_affine2(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta, float* workspace, float* scale,
+                           float* shift, int NB, int HW, int G, float eps, int dtype, void* stream);
 int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta, void* out,
                         float* workspace, int NB, int HW, int G, float eps, int silu, int dtype, void* stream);
 
@@ -296,6 +300,21 @@ int mmgt_gn_silu_conv3x3(const void* x, const float* scale, const float* shift, 
  * biased variance over (H W C / G) values, eps inside the root).  scale | shift: one allocation, shift = scale + nb * C. */
 int mmgt_gn_stats_finalize(const float* stats, const float* gamma, const float* beta, float* scale, float* shift, int nb, int tiles, int C, int G,
                            float eps, void* stream);
+
+/* GroupNorm-apply + SiLU + conv3x3 (stride 1, padding 1) of the UNet's resnets in one launch (csrc/rconv.hip; ResnetBlock3D.forward,
+ * src/models/resnet.py:217-247: norm1 -> nonlinearity -> conv1 (+ temb) and norm2 -> nonlinearity -> conv2 (+ shortcut), per frame as
+ * InflatedGroupNorm / InflatedConv3d of :20-28, :156-196 run them):
+ *   out = bias + bias2[n / b2_imgs] + conv3x3( silu( (x0 | x1) * scale[n, c] + shift[n, c] ) ) (+ residual)
+ * x0 (nb, H, W, C0) and optionally x1 (nb, H, W, C1): the two halves of the channel concatenation in front of an up-block resnet; H, W multiples
+ * of 16; C0, C1 multiples of 64; Cout a multiple of 320; scale_shift (2, nb, C0 + C1) fp32 = the tables of mmgt_groupnorm_affine2 in one
+ * allocation; wimg = packing.pack_rconv(W) (mmgt_gn_silu_conv3x3_unet_image_bytes(C0 + C1, Cout) bytes); bias (Cout), bias2 (rows, Cout) fp32 or
+ * null (the time-embedding projection: image n takes row n / b2_imgs); residual / out (nb, H, W, Cout) bf16.  bf16 only; everything else runs
+ * mmgt_groupnorm_nhwc -> mmgt_conv3x3_nhwc. */
+long mmgt_gn_silu_conv3x3_unet_image_bytes(int cin, int cout);
+/* Debug (tools/trace_rconv.py): a device buffer of [workgroups][512] u64 receives 100-MHz stamps of the launches that follow; NULL = off. */
+void mmgt_rconv_set_trace(void* buf);
+int mmgt_gn_silu_conv3x3_unet(const void* x0, int C0, const void* x1, int C1, const float* scale_shift, const void* wimg, const float* bias,
+                              const float* bias2, int b2_imgs, const void* residual, void* out, int nb, int H, int W, int cout, int dtype, void* stream);
 
 /* ---- conditioning producers and the output path on the device; uint8 image buffers are device pointers.
  * blur_mask: (frames, H, W) u8 -> (frames, 64, 64) u8 = cv2.resize(64x64, bilinear) -> cv2.GaussianBlur(ksize, sigma from ksize,

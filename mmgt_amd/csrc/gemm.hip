@@ -932,6 +932,8 @@ void mmgt_ffn_set_dbg(int v);
 void mmgt_rowgemm_set_dbg(int v);
 void mmgt_tleg_set_abl(int v);
 void mmgt_gnconv_set_abl(int v);
+void mmgt_rconv_set_abl(int v);
+void mmgt_rconv_set_stagger(int v);
 // Switches of the HOST side of the operator (mmgt_amd/unet3d.py, pipeline.py, smga.py read them through mmgt_tune_get): they live here,
 // beside the kernel knobs, so that ONE state -- this table -- describes what a run executed (MMGT_TUNE="twin_attention=0,splitk=0").
 namespace {
@@ -943,6 +945,7 @@ HostSwitch g_host[] = {
     {"oz3", 1},              // the three masked audio out-projections as one GEMM
     {"rowgemm", 1},          // row-stationary LayerNorm / GroupNorm -> projection launches
     {"tleg", 1},             // a level-0 temporal-attention leg as one launch (csrc/tleg.hip)
+    {"rconv", 1},            // the UNet resnets' GroupNorm + SiLU + conv3x3 legs as one launch (csrc/rconv.hip): 1 the 320-wide level, 2 + 640, 3 every level, 0 off
     {"gnconv", 2},           // the VAE's GroupNorm + SiLU + conv3x3 as one launch (csrc/gnconv.hip): 1 with a statistics pass, 2 statistics from the producing launch
     {"zero_audio_skip", 1},  // skip the audio cross-attention of an all-zero (unconditional) audio row
     {"window_state", 1},     // keep what a window's audio / masks determine across the steps of a clip
@@ -971,14 +974,16 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "splitk")) { g_splitk = value; return 0; }
   if (key && !strcmp(key, "bm192")) { g_bm192 = value; return 0; }
   if (key && !strcmp(key, "tailsplit")) { g_tailsplit = value; return 0; }
+  if (key && !strcmp(key, "rconv_stagger") && value >= 0 && value <= 8192) { mmgt_rconv_set_stagger(value); return 0; }
 #ifdef MMGT_ABLATE   // libmmgt_hip_abl.so (`make abl`): timing ablations whose RESULTS ARE GARBAGE -- the instruments under tools/ load that library explicitly
   if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 2) { mmgt_ffn_set_dbg(value); return 0; }
   if (key && !strcmp(key, "gnconv_abl") && value >= 0 && value <= 255) { mmgt_gnconv_set_abl(value); return 0; }
   if (key && !strcmp(key, "tleg_abl") && value >= 0 && value <= 128) { mmgt_tleg_set_abl(value); return 0; }
+  if (key && !strcmp(key, "rconv_abl") && value >= 0 && value <= 31) { mmgt_rconv_set_abl(value); return 0; }
   if (key && !strcmp(key, "rowgemm_dbg") && value >= 0 && value <= 5) { mmgt_rowgemm_set_dbg(value); return 0; }
 #else
   if (key && !strcmp(key, "rowgemm_dbg") && (value == 0 || value == 5)) { mmgt_rowgemm_set_dbg(value); return 0; }   // 5: the stamped (correct) build
-  if (key && (!strcmp(key, "ffn_dbg") || !strcmp(key, "gnconv_abl") || !strcmp(key, "tleg_abl") || !strcmp(key, "rowgemm_dbg"))) {
+  if (key && (!strcmp(key, "ffn_dbg") || !strcmp(key, "gnconv_abl") || !strcmp(key, "tleg_abl") || !strcmp(key, "rconv_abl") || !strcmp(key, "rowgemm_dbg"))) {
     mmgt_set_error("tune: '%s' selects a timing ablation whose results are garbage; the product library does not contain them (build libmmgt_hip_abl.so with `make -C mmgt_amd/csrc abl` and load it through MMGT_LIB)", key);
     return 1;
   }

@@ -348,12 +348,12 @@ __global__ __launch_bounds__(256) void gn_apply_narrow_kernel(const T* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void gn_affine_kernel(const T* __restrict__ x0, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ partial, float* __restrict__ scale, float* __restrict__ shift,
-                                                        int C, int HW, int G, int chunks, float eps) {
+                                                        int C, int HW, int G, int chunks, float eps, const T* __restrict__ x1 = nullptr, int C1 = 0) {
   __shared__ float smean[64], srstd[64];
-  const int n = blockIdx.x, cg = C / G;
+  const int n = blockIdx.x, cg = C / G, C0 = C - C1;
   {
-    const int g = threadIdx.x >> 2;
-    const float piv = Elem<T>::ld(x0 + (long)n * HW * C + (g < G ? g : 0) * cg);   // the pivot gn_stats_kernel shifted this group's values by
+    const int g = threadIdx.x >> 2, c0 = (g < G ? g : 0) * cg;                     // the pivot gn_stats_kernel shifted this group's values by
+    const float piv = c0 < C0 ? Elem<T>::ld(x0 + (long)n * HW * C0 + c0) : Elem<T>::ld(x1 + (long)n * HW * C1 + (c0 - C0));
     gn_group_stats(partial, n, chunks, G, (float)HW * (float)cg, eps, piv, smean, srstd);
   }
   __syncthreads();
@@ -617,16 +617,19 @@ extern "C" int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C
   return 0;
 }
 
-extern "C" int mmgt_groupnorm_affine(const void* x, int C, const float* gamma, const float* beta, float* workspace, float* scale,
-                                     float* shift, int NB, int HW, int G, float eps, int dtype, void* stream) {
+// The same for the channel concatenation of TWO tensors (x0 | x1: a resnet's input behind a skip connection, unet_3d_blocks.py:941-969), whose
+// groups may straddle the seam (1280 + 640 channels in 32 groups of 60); x1 == null: one tensor.
+extern "C" int mmgt_groupnorm_affine2(const void* x, int C0, const void* x1, int C1, const float* gamma, const float* beta, float* workspace,
+                                      float* scale, float* shift, int NB, int HW, int G, float eps, int dtype, void* stream) {
   MMGT_CHECK(x && gamma && beta && workspace && scale && shift, "groupnorm_affine: null pointer");
   MMGT_CHECK(dtype == MMGT_F32 || dtype == MMGT_BF16, "groupnorm_affine: bad dtype %d", dtype);
-  const int vec = dtype == MMGT_BF16 ? 8 : 4;
-  MMGT_CHECK(C <= GN_MAXC && C % G == 0 && G <= 64 && C % vec == 0, "groupnorm_affine: unsupported channels C=%d G=%d", C, G);
+  MMGT_CHECK((x1 != nullptr) == (C1 > 0), "groupnorm_affine: x1 / C1 mismatch");
+  const int vec = dtype == MMGT_BF16 ? 8 : 4, C = C0 + C1;
+  MMGT_CHECK(C <= GN_MAXC && C % G == 0 && G <= 64 && C0 % vec == 0 && C1 % vec == 0, "groupnorm_affine: unsupported channels C=%d + %d G=%d", C0, C1, G);
   MMGT_CHECK(NB > 0 && HW > 0 && NB <= 65535, "groupnorm_affine: bad NB=%d HW=%d", NB, HW);
   hipStream_t s = (hipStream_t)stream;
   const int nvec = C / vec, maxs = GN_MAXC / (vec * 64);
-  if (gn_narrow_fits(nvec, 0, HW)) {
+  if (!x1 && gn_narrow_fits(nvec, 0, HW)) {
     const int chunks = gn_narrow_chunks(HW, NB, nvec);
     dim3 grid(chunks, NB);
     if (dtype == MMGT_BF16) {
@@ -645,14 +648,21 @@ extern "C" int mmgt_groupnorm_affine(const void* x, int C, const float* gamma, c
   while (lpr < 64 && (lpr * maxs < nvec || nvec % lpr != 0)) lpr <<= 1;
   const int il = g_gn_interleave >= 0 ? g_gn_interleave : 1;
   if (dtype == MMGT_BF16) {
-    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, C, (const bf16_t*)nullptr, 0, workspace, HW, G, chunks, lpr, il);
-    hipLaunchKernelGGL(gn_affine_kernel<bf16_t>, dim3(NB), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, workspace, scale, shift, C, HW, G, chunks, eps);
+    hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, C0, (const bf16_t*)x1, C1, workspace, HW, G, chunks, lpr, il);
+    hipLaunchKernelGGL(gn_affine_kernel<bf16_t>, dim3(NB), dim3(256), 0, s, (const bf16_t*)x, gamma, beta, workspace, scale, shift, C, HW, G, chunks, eps,
+                       (const bf16_t*)x1, C1);
   } else {
-    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, C, (const float*)nullptr, 0, workspace, HW, G, chunks, lpr, il);
-    hipLaunchKernelGGL(gn_affine_kernel<float>, dim3(NB), dim3(256), 0, s, (const float*)x, gamma, beta, workspace, scale, shift, C, HW, G, chunks, eps);
+    hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x, C0, (const float*)x1, C1, workspace, HW, G, chunks, lpr, il);
+    hipLaunchKernelGGL(gn_affine_kernel<float>, dim3(NB), dim3(256), 0, s, (const float*)x, gamma, beta, workspace, scale, shift, C, HW, G, chunks, eps,
+                       (const float*)x1, C1);
   }
   MMGT_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int mmgt_groupnorm_affine(const void* x, int C, const float* gamma, const float* beta, float* workspace, float* scale,
+                                     float* shift, int NB, int HW, int G, float eps, int dtype, void* stream) {
+  return mmgt_groupnorm_affine2(x, C, nullptr, 0, gamma, beta, workspace, scale, shift, NB, HW, G, eps, dtype, stream);
 }
 
 extern "C" int mmgt_layernorm(const void* x, long ldx, const float* gamma, const float* beta, float eps, const float* pe,

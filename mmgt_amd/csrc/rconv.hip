@@ -1,0 +1,550 @@
+// GroupNorm-apply + SiLU + conv3x3 of the UNet's resnets in ONE launch (bf16, stride 1, padding 1, gfx950):
+//
+//   out[n, y, x, :] = bias + temb[n] + sum_{ky, kx} W[ky, kx] . silu( in[n, y + ky - 1, x + kx - 1, :] * scale[n, :] + shift[n, :] )   (+ residual)
+//
+// in = the channel concatenation of up to two channels-last tensors (hidden | skip: unet_3d_blocks.py:941-969 concatenates first), (scale, shift)
+// the per-(image, channel) tables of the GroupNorm in front of the conv (mmgt_groupnorm_affine2: the statistics pass alone), temb the
+// time-embedding row of the image's batch entry.  Replaces the `hip.groupnorm(silu=True)` -> `hip.conv3x3` pairs of
+// mmgt_amd/unet3d.py::_resnet (reference: ResnetBlock3D.forward, /root/reference/src/models/resnet.py:217-247: norm1 -> nonlinearity -> conv1
+// -> + temb -> norm2 -> nonlinearity -> conv2 -> + shortcut; InflatedGroupNorm / InflatedConv3d of :20-28, :156-196 are per-frame operators, so a
+// frame is an image here).  The unfused pair wrote the normalised tensor to HBM and read it back nine times through gemm16's im2col gather.
+//
+// Structure (csrc/gnconv.hip's, re-cut for 320 .. 2560 input channels and 320-wide output blocks).  A workgroup owns a UNIT = a 16 x 16 pixel
+// tile of one image x a block of CB = 32 NT output channels, and walks the input channels in PHASES of 64:
+//   * the phase's 18 x 18 x 64-channel halo goes global -> LDS RAW by LDS-DMA (41 pieces of 1 KiB, no registers), one phase ahead, into the
+//     second of two halo buffers, and is normalised + SiLU'd + rounded to bf16 IN PLACE by the thread that issued its pieces (so its own
+//     vmcnt covers the hand-over; the table of the phase's 64 scales / shifts rides with it), a dword at a time between the MFMAs of the
+//     running phase; out-of-image pixels are zeros AFTER the activation, as the conv's padding wants;
+//   * LDS image of a halo: pixel R = 18 hy + hx is a 128-byte row, 16-byte chunk c of it at slot c ^ (R & 7) -- the DMA writes 64 lanes x 16 B
+//     contiguously, so the swizzle sits in the per-lane SOURCE offset (chunk (lane & 7) ^ (lane >> 3) of pixel 8 piece + (lane >> 3): a lane
+//     constant), and the sixteen lanes of every ds_read_b128 group of an A fragment (16 consecutive pixels, any start) hit sixteen bank groups;
+//   * the nine taps' A fragments (v_mfma_f32_16x16x32_bf16: lane (lm, lq) = pixel lm of an image row, channels 32 ks + 8 lq .. + 7) are read
+//     straight from the halo -- no im2col staging --, the weights (fragment-major image, mmgt_amd/packing.py::pack_rconv: per output block,
+//     phase, tap and k-step of 32 channels 2 NT pieces of 1 KiB) stream through an NSLOT-deep LDS ring by LDS-DMA, ONE barrier per k-step
+//     (4 NT MFMAs per wave) placed behind the MFMAs that still read the slot being freed;
+//   * 8 waves = 4 (rows) x 2 (columns): a wave owns 4 image rows x 16 pixels x CB / 2 output channels = 4 x NT accumulator tiles (160 registers
+//     at NT = 10), W fragments in a rolling window of four, the next k-step's A fragments read under the last MFMAs of the current one;
+//   * the accumulators start from bias + temb row (LDS copy fetched one unit ahead); epilogue as gemm16's (v_permlane16_swap pairs -> 16-byte
+//     stores, residual added in fp32).
+// Staged bytes per MFMA: the weights only (64 CB bytes per 256 x CB x 32 MACs) -- 0.56 of gemm16's 256 x 320 conv tile.
+#include <type_traits>
+#include <utility>
+
+#include "common.h"
+#include "gemm_common.h"
+#include "mmgt_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float acc4;
+
+constexpr int RC_T = 16, RC_HP = RC_T + 2, RC_NPIX = RC_HP * RC_HP;          // tile edge, halo edge, halo pixels (324)
+constexpr int RC_PC = 64;                                                   // channels per phase
+constexpr int RC_HPIECES = (RC_NPIX * (RC_PC / 8) + 63) / 64;               // 1-KiB DMA pieces of a halo: 41 (the last one half used)
+constexpr int RC_HALO = RC_HPIECES * 1024;                                  // bytes per halo buffer
+constexpr int RC_NHV = (RC_HPIECES + 7) / 8;                                // pieces (= 16-byte vectors per lane) per wave and phase: 6
+constexpr int RC_NSTEP = 18;                                                // k-steps (tap, 32-channel half) per phase
+constexpr int RC_FWD = 4;                                                   // W fragments in flight per wave
+
+struct RcArgs {
+  const bf16_t* x0; const bf16_t* x1;   // (nb, H, W, C0) [, (nb, H, W, C1)]
+  int C0, C1;
+  const float* scale;                   // (2, nb, C0 + C1): scale | shift
+  const char* wimg;                     // pack_rconv image
+  const float* bias;                    // (Cout) or null
+  const float* bias2;                   // (rows, Cout) or null: row n / b2_imgs is added to image n
+  int b2_imgs;
+  const bf16_t* res;                    // (nb, H, W, Cout) or null
+  bf16_t* out;                          // (nb, H, W, Cout)
+  int nb, H, W, tiles_x, tiles_per_img, ncb, nunits, nph, cout;
+  unsigned long long* trace;            // debug: [workgroup][512] 100-MHz stamps of wave 0 (k-step starts; 2 per epilogue), or null
+  int stagger;                          // start delay of workgroup group (blockIdx.x >> 3) & 7, in units of 64 cycles per group index
+  int abl;                              // -DMMGT_ABLATE builds only (timing ablations, results are garbage): 1 no weight data, 2 no halo data, 4 no normalisation, 8 no barriers, 16 no stores
+};
+
+// Accumulators live in the accumulation registers, tied in place (through the builtin hipcc rotates the 160 registers of a wave's tiles through
+// other ranges with copies -- and spills: DESIGN 4, round 4, gemm16v).
+// With two waves per SIMD hipcc splits the wave's 256 registers 128 | 128, so the first eight column tiles of a row (4 x 8 x 4 = 128 registers) sit in
+// AGPRs and the rest in VGPRs, as in gemm16v.
+template <bool AGPR>
+__device__ __forceinline__ void rc_mma(acc4& c, s16x8 a, s16x8 b) {
+  if constexpr (AGPR) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+  else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// An accumulator tile -> four VGPR floats, at THIS point of the program (left to hipcc, all 128 AGPR reads of an epilogue are hoisted to its top and
+// the VGPR-resident tiles are spilled to make room -- straight behind the asm MFMAs whose result latency it does not know).
+template <bool AGPR>
+__device__ __forceinline__ acc4 rc_get(const acc4& c) {
+  if constexpr (AGPR) {
+    acc4 r;
+    asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "a"(c[0]), "a"(c[1]), "a"(c[2]), "a"(c[3]));
+    return r;
+  } else {
+    return c;
+  }
+}
+__device__ __forceinline__ float rc_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float rc_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// a wave-uniform 64-bit base in SGPRs (a SELECT between two descriptors would put every DMA into a waterfall loop).  A free function: a captureless
+// helper lambda called from another lambda inside a __global__ function makes hipcc's host pass drop the kernel's stub.
+__device__ __forceinline__ const void* rc_uni(const void* ptr) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(ptr);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+  return reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+}
+
+template <int LO, int... I, typename F>
+__device__ __forceinline__ void rc_for_impl(std::integer_sequence<int, I...>, F&& fn) { (fn(std::integral_constant<int, LO + I>{}), ...); }
+template <int LO, int HI, typename F>
+__device__ __forceinline__ void rc_for(F&& fn) { rc_for_impl<LO>(std::make_integer_sequence<int, (HI > LO ? HI - LO : 0)>{}, static_cast<F&&>(fn)); }
+
+template <int NT> struct RcCfg {
+  static constexpr int CB = 32 * NT, SLOT = CB * 64, NPC = 2 * NT, PPW = (NPC + 7) / 8;   // output block; bytes and pieces per k-step; pieces per wave
+  static constexpr int NSLOT = NT >= 10 ? 3 : 4;
+  static constexpr int L_RING = 2 * RC_HALO, L_BIAS = L_RING + NSLOT * SLOT, L_TAB = L_BIAS + 4096, L_DUMMY = L_TAB + 1024, LDS = L_DUMMY + 1024;
+  static_assert(LDS <= 160 * 1024 && NT % 2 == 0 && NPC >= RC_FWD && (RC_NSTEP * NT) % RC_FWD == 0, "LDS / shape");
+};
+
+template <int NT, bool RES>
+__global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
+  using Cfg = RcCfg<NT>;
+  constexpr int CB = Cfg::CB, SLOT = Cfg::SLOT, NPC = Cfg::NPC, PPW = Cfg::PPW, NSLOT = Cfg::NSLOT;
+  constexpr int RT = 4, NPAIR = NT / 2, NST = RT * NPAIR;                   // image rows per wave; tile pairs; 16-byte stores per wave and unit
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lm = lane & 15, lq = lane >> 4;
+  const int wm = wid >> 1, wn = wid & 1;                   // image rows 4 wm .. + 3 of the tile, output channels (CB / 2) wn .. of the block
+#ifdef MMGT_ABLATE
+  const int abl = a.abl;
+#else
+  constexpr int abl = 0;
+#endif
+  int trace_n = 0;                                         // debug (tools/trace_rconv.py, as gemm16's): 100-MHz stamps of wave 0; a.trace == NULL: off
+  auto stamp = [&]() {
+    if (a.trace) {
+      if (tid == 0 && trace_n < 512) a.trace[(long)blockIdx.x * 512 + trace_n] = wall_clock64();
+      ++trace_n;
+    }
+  };
+  const int G = gridDim.x;
+  const int cin = a.C0 + a.C1;
+  const int my_units = (a.nunits - (int)blockIdx.x + G - 1) / G;
+  const int ksteps_per_unit = a.nph * RC_NSTEP;
+  const int total = my_units * ksteps_per_unit;            // k-steps this workgroup consumes
+
+  // XCD-aware unit order (gemm.hip): XCD x = v & 7 walks a contiguous run of the sequence s = tile * ncb + block, so the blocks of a tile and
+  // horizontally adjacent tiles -- which share halo columns -- are worked on one L2 at about the same time
+  auto decode = [&](int v, int& n, int& ty, int& tx, int& cb) {
+    const int q = a.nunits >> 3, r = a.nunits & 7, xc = v & 7;
+    const int s = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + (v >> 3);
+    const int t = s / a.ncb;
+    cb = s - t * a.ncb;
+    n = t / a.tiles_per_img;
+    const int rem = t - n * a.tiles_per_img;
+    ty = rem / a.tiles_x;
+    tx = rem - ty * a.tiles_x;
+  };
+
+  // ---- weight stream: k-step wg (counted over the workgroup's units) lives in ring slot wg % NSLOT
+  const __amdgpu_buffer_rsrc_t rW = dma_rsrc(a.wimg);
+  int wg = 0, w_vt = blockIdx.x, w_ch = 0, w_cboff = 0, w_slot = 0;
+  {
+    int n, ty, tx, cb;
+    decode(w_vt < a.nunits ? w_vt : 0, n, ty, tx, cb);
+    w_cboff = cb * ksteps_per_unit * SLOT;
+  }
+  // Beyond the last k-step the pieces still go out against the poison offset (zeros into a slot nobody reads), and the pieces a wave has too
+  // many (PPW 8 > NPC) into a dummy KiB: every wait count below is a compile-time constant on every path.
+  auto issue_w = [&]() {
+    const int soff = w_cboff + w_ch * SLOT;
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) {
+      const int q = wid * PPW + u;
+      const bool real = q < NPC;
+      blds16(rW, (real && wg < total && !(abl & 1)) ? (unsigned)(lane * 16 + q * 1024) : DMA_POISON, soff,
+             smem + (real ? Cfg::L_RING + w_slot * SLOT + q * 1024 : Cfg::L_DUMMY));
+    }
+    ++wg;
+    w_slot = w_slot == NSLOT - 1 ? 0 : w_slot + 1;
+    if (++w_ch == ksteps_per_unit) {
+      w_ch = 0;
+      w_vt += G;
+      if (w_vt < a.nunits) {
+        int n, ty, tx, cb;
+        decode(w_vt, n, ty, tx, cb);
+        w_cboff = cb * ksteps_per_unit * SLOT;
+      }
+    }
+  };
+
+  // ---- halo stream: piece q = wid + 8 i of a phase holds vectors 64 q + lane = pixel R = 8 q + (lane >> 3), slot lane & 7, i.e. the source chunk
+  // (lane & 7) ^ (R & 7) = (lane & 7) ^ (lane >> 3).  The thread that issues a vector normalises it (same buffer position), so `hmask` (bit i:
+  // vector i lies inside the image) is the only state that crosses from the issue to the normalisation.
+  unsigned hmask = 0;
+  const int hl_chunk = (lane & 7) ^ (lane >> 3);
+  const int hl_R = 8 * wid + (lane >> 3);                                  // pixel of vector 0 (vector i: + 64 i)
+  const int hl_pos = hl_R * 128 + (lane & 7) * 16;                         // its byte position inside a halo buffer (vector i: + 8192 i)
+  // One vector (= one piece per wave) of the halo of phase (h_n, h_ty, h_tx; source h_src, h_cs channels per pixel, channel offset h_choff) per
+  // hand-over of k-steps 0 .. 5: ~15 full-rate VALU (24-bit multiplies) and one DMA each, instead of ~150 instructions in one k-step of every
+  // wave at once (stamps, tools/trace_rconv.py: k-step 0 of a phase took 3.2 us against 1.05).
+  int h_n = 0, h_base = 0, h_ty = 0, h_tx = 0, h_cs2 = 0, h_choff2 = 0, h_c0 = 0;
+  const bf16_t* h_src = a.x0;
+  auto halo_target = [&](int v, int ph) {                    // scalars of the phase whose halo is fetched next
+    int cb;
+    decode(v, h_n, h_ty, h_tx, cb);
+    const int c0 = ph * RC_PC;
+    const bool second = c0 >= a.C0;
+    h_c0 = c0;
+    h_cs2 = (second ? a.C1 : a.C0) * 2;
+    h_choff2 = (second ? c0 - a.C0 : c0) * 2;
+    h_src = second ? a.x1 : a.x0;
+    h_base = (h_n * a.H + h_ty * RC_T - 1) * a.W + h_tx * RC_T - 1;          // pixel index of halo pixel (0, 0) (may be negative: masked below)
+  };
+  auto issue_halo_vec = [&](auto Ic, int buf) {
+    constexpr int i = decltype(Ic)::value;
+    const __amdgpu_buffer_rsrc_t rX = dma_rsrc(rc_uni(h_src));
+    int R = hl_R + 64 * i;
+    asm volatile("" : "+v"(R));                             // opaque: recomputed here, not kept across the phase
+    const int hy = (int)__umul24(R, 3641) >> 16, hx = R - RC_HP * hy;           // R / 18, exact for R < 3 000
+    const int y = h_ty * RC_T - 1 + hy, x = h_tx * RC_T - 1 + hx;
+    const bool ok = R < RC_NPIX && y >= 0 && y < a.H && x >= 0 && x < a.W;
+    const unsigned pix = (unsigned)(h_base + (int)__umul24(hy, a.W) + hx);
+    const unsigned off = __umul24(pix, (unsigned)h_cs2) + (unsigned)(h_choff2 + hl_chunk * 16);
+    const bool piece = wid + 8 * i < RC_HPIECES;                                // (wave-uniform: only wave 0 has a sixth piece)
+    blds16(rX, (ok && !(abl & 2)) ? off : DMA_POISON, 0, piece ? smem + buf * RC_HALO + (wid + 8 * i) * 1024 : smem + Cfg::L_DUMMY);
+    if constexpr (i == 0) hmask = 0;
+    hmask |= ok ? 1u << i : 0u;
+    // with the first vector: the phase's 64 scales (lanes 0 .. 15) | 64 shifts (lanes 16 .. 31), one piece of wave 0
+    if constexpr (i == 0) {
+      if (wid == 0)
+        blds16(dma_rsrc(a.scale), lane < 32 ? (unsigned)((((lane >> 4) * a.nb + h_n) * cin + h_c0 + (lane & 15) * 4) * 4) : DMA_POISON, 0,
+               smem + Cfg::L_TAB);
+    }
+  };
+  // bias | temb row of unit v -> LDS (waves 0 .. 3: array wid >> 1, piece wid & 1 of 256 floats; null pointers read as zeros)
+  auto issue_bias = [&](int v) {
+    if (wid < 4) {
+      int n, ty, tx, cb;
+      decode(v, n, ty, tx, cb);
+      const int arr = wid >> 1, pc = wid & 1, col = pc * 256 + lane * 4;
+      const float* src = arr == 0 ? a.bias : a.bias2 ? a.bias2 + (long)(n / a.b2_imgs) * a.cout : nullptr;
+      blds16(dma_rsrc(rc_uni(src ? src : a.scale)), (src && col < CB) ? (unsigned)((cb * CB + col) * 4) : DMA_POISON, 0, smem + Cfg::L_BIAS + arr * 2048 + pc * 1024);
+    }
+  };
+  // Dwords J, J + 1 (four channels) of vector I of the halo in buffer `buf`: bf16 <- bf16( silu( . * scale + shift ) ), zeros outside the image, in five
+  // STAGES that the k-step deals out behind its first five MFMA groups -- as one block its chain of dependent instructions (LDS read -> fma ->
+  // exp -> rcp -> convert -> LDS write, ~300 cycles of latency) stood in front of the wave's next MFMAs (stamps: +0.15 us on a 0.9-us k-step).
+  // Branch-free, scalar f32 arithmetic (csrc/gnconv.hip: packed f32 instructions cost ~25 cycles beside MFMAs); every stage's results are pinned
+  // where the stage stands.
+  const int tab_ofs = Cfg::L_TAB + hl_chunk * 32;
+  u32x2 n_raw;
+  f32x4 n_sc, n_sh, n_t, n_x;
+  int n_pos = 0;
+  auto norm_stage = [&](auto Kc, int buf, auto Ic, auto Jc) {
+    constexpr int K = decltype(Kc)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
+    if ((I == RC_NHV - 1 && wid != 0) || (abl & 4)) return;  // (only wave 0 has a sixth vector)
+    if constexpr (K == 0) {
+      n_pos = buf * RC_HALO + hl_pos + I * 8192 + 4 * J;
+      int tofs = tab_ofs + 8 * J;
+      asm volatile("" : "+v"(n_pos), "+v"(tofs));           // (opaque: no common subexpressions across calls)
+      n_raw = *reinterpret_cast<const u32x2*>(smem + n_pos);
+      n_sc = *reinterpret_cast<const f32x4*>(smem + tofs);
+      n_sh = *reinterpret_cast<const f32x4*>(smem + tofs + RC_PC * 4);
+    } else if constexpr (K == 1) {
+      n_t = (f32x4){fmaf(rc_lo(n_raw[0]), n_sc[0], n_sh[0]), fmaf(rc_hi(n_raw[0]), n_sc[1], n_sh[1]), fmaf(rc_lo(n_raw[1]), n_sc[2], n_sh[2]),
+                    fmaf(rc_hi(n_raw[1]), n_sc[3], n_sh[3])};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { n_x[e] = n_t[e] * -1.4426950408889634f; asm volatile("" : "+v"(n_x[e]), "+v"(n_t[e])); }
+    } else if constexpr (K == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { n_x[e] = __builtin_amdgcn_exp2f(n_x[e]); asm volatile("" : "+v"(n_x[e])); }
+    } else if constexpr (K == 3) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { n_x[e] = __builtin_amdgcn_rcpf(1.f + n_x[e]); asm volatile("" : "+v"(n_x[e])); }
+    } else {
+      const unsigned m = 0u - ((hmask >> I) & 1u);
+      u32x2 pk = {pack_bf16x2(n_t[0] * n_x[0], n_t[1] * n_x[1]) & m, pack_bf16x2(n_t[2] * n_x[2], n_t[3] * n_x[3]) & m};
+      asm volatile("" : "+v"(pk));
+      *reinterpret_cast<u32x2*>(smem + n_pos) = pk;
+    }
+  };
+  auto norm_dword = [&](int buf, auto Ic, auto Jc) {         // (prologue: the first halo, all at once; Jc even)
+    rc_for<0, 5>([&](auto kc) { norm_stage(kc, buf, Ic, Jc); });
+  };
+
+  // ---- fragment addressing.  A: pixel R = rl + K with rl = 18 (4 wm) + lm and K = 18 (i + ky) + kx a compile-time constant: row R of the
+  // buffer, slot (4 ks + lq) ^ (R & 7); R & 7 = (rl + (K & 7)) & 7, so eight per-lane offsets (one per K & 7) serve every tap.
+  const int rl = RC_HP * RT * wm + lm;
+  int aofs[8];
+#pragma unroll
+  for (int k7 = 0; k7 < 8; ++k7) aofs[k7] = rl * 128 + ((lq ^ ((rl + k7) & 7)) << 4);
+  const int w_lane = Cfg::L_RING + wn * NT * 1024 + lane * 16;             // + slot SLOT + j 1 KiB
+  s16x8 fa[RT], fw[RC_FWD];
+  auto read_a1 = [&](int buf, auto Sc, auto Ic) {             // A fragment of image row i of the wave for k-step S
+    constexpr int S = decltype(Sc)::value, i = decltype(Ic)::value, tap = S >> 1, ks = S & 1, ky = tap / 3, kx = tap % 3, K = RC_HP * (i + ky) + kx;
+    return *reinterpret_cast<const s16x8*>(smem + buf * RC_HALO + ((aofs[K & 7] ^ (ks ? 64 : 0)) + K * 128));
+  };
+  auto read_w = [&](int slot, int j) { return *reinterpret_cast<const s16x8*>(smem + w_lane + slot * SLOT + j * 1024); };
+
+  // Start stagger.  Every unit of a launch is the same length, so the persistent workgroups of the whole chip reach their epilogues together: a
+  // burst of nunits-per-round x 160 KB that HBM takes ~10 - 18 us to absorb while every wave's in-order vmcnt queue holds its next weight pieces
+  // behind its stores.  Eight groups of workgroups start a few microseconds apart so that the bursts are spread over that time.
+  for (int d = ((blockIdx.x >> 3) & 7) * a.stagger; d > 0; d -= 64) __builtin_amdgcn_s_sleep(64);
+
+  // ---- prologue: bias of the first unit, its first halo (normalised here), the first NSLOT - 1 k-steps of weights
+  int vt = blockIdx.x, ph = 0, fp = 0;                      // current unit, its phase, phases done (buffer parity)
+  if (my_units > 0) {
+    issue_bias(vt);
+    halo_target(vt, 0);
+    rc_for<0, RC_NHV>([&](auto ic) { issue_halo_vec(ic, 0); });
+    for (int g = 0; g < NSLOT - 1; ++g) issue_w();
+    wait_vmcnt<(NSLOT - 1) * PPW>();                        // bias, table, halo have landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();                           // ... everybody's: the table is complete
+    rc_for<0, RC_NHV>([&](auto ic) { norm_dword(0, ic, std::integral_constant<int, 0>{}); norm_dword(0, ic, std::integral_constant<int, 2>{}); });
+    wait_vmcnt<(NSLOT - 2) * PPW>();                        // k-step 0 has landed
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0): the LDS stores above
+  __builtin_amdgcn_s_barrier();
+  int c_slot = 0;                                           // ring slot of the k-step being multiplied
+  if (my_units > 0) {
+    rc_for<0, RT>([&](auto ic) { fa[decltype(ic)::value] = read_a1(0, std::integral_constant<int, 0>{}, ic); });
+#pragma unroll
+    for (int j = 0; j < RC_FWD; ++j) fw[j] = read_w(0, j);
+  }
+
+  const __amdgpu_buffer_rsrc_t rO = dma_rsrc(a.out), rR = dma_rsrc(a.res ? a.res : a.out);
+  acc4 acc[RT][NT];
+  bool stored = false;                                      // the previous phase ended in an epilogue: its stores are in the vmcnt queue
+  while (vt < a.nunits) {
+    const bool first_ph = ph == 0, last_ph = ph == a.nph - 1;
+    const int nvt = last_ph ? vt + G : vt, nph = last_ph ? 0 : ph + 1;
+    const bool has_next = nvt < a.nunits;
+    const int buf = fp & 1, nbuf = buf ^ 1;
+    if (has_next) halo_target(nvt, nph);
+
+    if (first_ph) {
+      const acc4* lb = reinterpret_cast<const acc4*>(smem + Cfg::L_BIAS) + wn * (CB / 8) + lq;   // the lane's columns 16 j + 4 lq + r
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const acc4 b = lb[4 * j] + lb[128 + 4 * j];               // bias + temb row (2 KiB apart)
+#pragma unroll
+        for (int i = 0; i < RT; ++i) acc[i][j] = b;
+      }
+      asm volatile("s_nop 7" ::: "memory");                   // (accumulator writes -> the first asm MFMA that reads them)
+    }
+
+    rc_for<0, RC_NSTEP>([&](auto sc_) {
+      constexpr int S = decltype(sc_)::value;
+      stamp();
+      const int n_slot = c_slot == NSLOT - 1 ? 0 : c_slot + 1;
+      // two dwords of the next phase's halo per k-step, S = 3 .. 14 (its pieces and table have landed behind the barrier of k-step 2)
+      constexpr bool NORM = S >= 3 && S < 3 + 2 * RC_NHV;
+      constexpr int NV = NORM ? (S - 3) >> 1 : 0, NJ = NORM ? 2 * ((S - 3) & 1) : 0;
+      auto fwi = [](int j) constexpr { return (S * NT + j) % RC_FWD; };      // the rolling window's register of W tile j of this k-step
+      // ---- W tiles 0 .. NT - 3: tile-major (a W fragment serves the wave's four image rows, then its register takes the tile four ahead)
+      rc_for<0, NT - 2>([&](auto jc_) {
+        constexpr int j = decltype(jc_)::value;
+        rc_for<0, RT>([&](auto ic) { rc_mma<(j < 8)>(acc[decltype(ic)::value][j], fw[fwi(j)], fa[decltype(ic)::value]); });
+        if constexpr (NORM && j < 5) norm_stage(std::integral_constant<int, j>{}, nbuf, std::integral_constant<int, NV>{}, std::integral_constant<int, NJ>{});
+        if constexpr (j + RC_FWD < NT) fw[fwi(j)] = read_w(c_slot, j + RC_FWD);
+        if constexpr (j + RC_FWD == NT) {
+          // ---- hand-over, behind the last read of the current slot: k-step g + 1 has landed (this wave's pieces; the barrier collects the
+          // others').  vmcnt retires in order, so the count is the operations YOUNGER than those pieces: the pieces of the k-steps behind
+          // it, the halo pieces of the earlier hand-overs (waves that issued a table / bias piece too wait for one operation more than they
+          // must), the stores of an epilogue in front of k-step 0.
+          constexpr int BASE = (NSLOT - 3) * PPW;
+          constexpr int HLO = S + 2 - NSLOT > 0 ? S + 2 - NSLOT : 0, HHI = S - 1 < RC_NHV - 1 ? S - 1 : RC_NHV - 1;
+          constexpr int NH = HHI >= HLO ? HHI - HLO + 1 : 0;            // halo pieces issued behind the pieces waited for (one per hand-over 0 .. 5)
+          constexpr bool EPI = S <= NSLOT - 3;                          // ... and the stores of an epilogue in front of k-step 0
+          if constexpr (NH > 0 && EPI) {
+            if (stored) { if (has_next) wait_vmcnt<BASE + NH + NST>(); else wait_vmcnt<BASE + NST>(); }
+            else { if (has_next) wait_vmcnt<BASE + NH>(); else wait_vmcnt<BASE>(); }
+          } else if constexpr (NH > 0) {
+            if (has_next) wait_vmcnt<BASE + NH>(); else wait_vmcnt<BASE>();
+          } else if constexpr (EPI) {
+            if (stored) wait_vmcnt<BASE + NST>(); else wait_vmcnt<BASE>();
+          } else {
+            wait_vmcnt<BASE>();
+          }
+          if constexpr (S == RC_NSTEP - 1) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this thread's normalised dwords are in LDS
+          if (!(abl & 8)) __builtin_amdgcn_s_barrier();
+          issue_w();                                          // into the slot k-step g - 1 left
+          if constexpr (S < RC_NHV) {
+            if (has_next) {
+              issue_halo_vec(std::integral_constant<int, S>{}, nbuf);
+              if constexpr (S == 0) { if (last_ph) issue_bias(nvt); }
+            }
+          }
+        }
+        if constexpr (j + RC_FWD >= NT) {
+          // (no fragments are carried across an epilogue: it needs their 32 registers, and the unit's first reads cost one LDS round trip per ~100 000 cycles)
+          if (S + 1 < RC_NSTEP || !last_ph) fw[fwi(j)] = read_w(n_slot, j + RC_FWD - NT);
+        }
+      });
+      // ---- the last two W tiles row-major: an A fragment's register takes the next k-step's fragment as soon as its two MFMAs have issued
+      // (k-step 17: from the next phase's halo, complete behind the barrier above)
+      rc_for<0, RT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        rc_mma<(NT - 2 < 8)>(acc[i][NT - 2], fw[fwi(NT - 2)], fa[i]);
+        rc_mma<(NT - 1 < 8)>(acc[i][NT - 1], fw[fwi(NT - 1)], fa[i]);
+        if constexpr (S + 1 < RC_NSTEP) fa[i] = read_a1(buf, std::integral_constant<int, S + 1>{}, ic);
+        else if (!last_ph) fa[i] = read_a1(nbuf, std::integral_constant<int, 0>{}, ic);
+      });
+      if (S + 1 < RC_NSTEP || !last_ph) {
+        fw[fwi(NT - 2)] = read_w(n_slot, RC_FWD - 2);
+        fw[fwi(NT - 1)] = read_w(n_slot, RC_FWD - 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      c_slot = n_slot;
+    });
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");        // (the asm MFMAs hide their result latency from hipcc: nothing below reads an accumulator earlier)
+    stored = false;
+
+    if (last_ph) {
+      // ---- epilogue (gemm16.hip's idiom): lane (lm, lq) holds pixel lm of image row 4 wm + i and, per tile j, channels 16 j + 4 lq + r;
+      // v_permlane16_swap of tiles 2 jp, 2 jp + 1 -> 8 consecutive channels 32 jp + 16 (lq & 1) + 8 (lq >> 1) .. + 7: one 16-byte store.
+      stamp();
+      int n, ty, tx, cb;
+      decode(vt, n, ty, tx, cb);
+      int lme = lm, lqe = lq;
+      asm volatile("" : "+v"(lme), "+v"(lqe));               // (nothing of this is hoisted above the main loop)
+      const int cofs = cb * CB + wn * (CB / 2) + 16 * (lqe & 1) + 8 * (lqe >> 1);
+      const unsigned eoff = (unsigned)((((n * a.H + ty * RC_T + RT * wm) * a.W + tx * RC_T + lme) * a.cout + cofs) * 2);   // byte offset of (row 0, pair 0)
+      const int erow = a.W * a.cout * 2;                      // bytes per image row
+      u32x4 rv[2][RES ? NPAIR : 1];                           // residual vectors, one image row ahead of their use (one at a time: 0.8 us of latency each, 16 us per unit)
+      if constexpr (RES) {
+#pragma unroll
+        for (int jp = 0; jp < NPAIR; ++jp) rv[0][jp] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)eoff + 64 * jp, 0, 0);
+      }
+      rc_for<0, RT * NPAIR>([&](auto qc) {
+        constexpr int q = decltype(qc)::value, i = q / NPAIR, jp = q % NPAIR;
+        if constexpr (RES && jp == 0 && i + 1 < RT) {
+#pragma unroll
+          for (int j2 = 0; j2 < NPAIR; ++j2) rv[(i + 1) & 1][j2] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)eoff + (i + 1) * erow + 64 * j2, 0, 0);
+        }
+        const acc4 x = rc_get<(2 * jp < 8)>(acc[i][2 * jp]), y = rc_get<(2 * jp + 1 < 8)>(acc[i][2 * jp + 1]);
+        u32x4 pk;
+        if constexpr (!RES) {
+          const auto s01 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[0], x[1]), pack_bf16x2(y[0], y[1]), false, false);
+          const auto s23 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[2], x[3]), pack_bf16x2(y[2], y[3]), false, false);
+          pk = (u32x4){s01[0], s23[0], s01[1], s23[1]};
+        } else {
+          float o8[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[r]), __float_as_uint(y[r]), false, false);
+            o8[r] = __uint_as_float(sw[0]);
+            o8[4 + r] = __uint_as_float(sw[1]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o8[2 * e] += rc_lo(rv[i & 1][jp][e]);
+            o8[2 * e + 1] += rc_hi(rv[i & 1][jp][e]);
+          }
+          pk = (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])};
+        }
+        // (the row offset rides in the VECTOR offset, not in soffset: see csrc/gnconv.hip -- the store-data hazard tools/check_mfma_overlap.py scans for)
+        if (!(abl & 16) || pk[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(pk, rO, (int)eoff + i * erow + 64 * jp, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // the next unit's first fragments (its halo and its first k-step are in LDS behind the barrier of k-step 17)
+      if (has_next) {
+        rc_for<0, RT>([&](auto ic) { fa[decltype(ic)::value] = read_a1(nbuf, std::integral_constant<int, 0>{}, ic); });
+#pragma unroll
+        for (int j = 0; j < RC_FWD; ++j) fw[j] = read_w(c_slot, j);
+      }
+      stored = true;
+      stamp();
+    }
+    vt = nvt;
+    ph = nph;
+    ++fp;
+  }
+  wait_vmcnt<0>();                                           // (the poison pieces write LDS: none may be in flight when the workgroup's LDS is released)
+}
+
+int g_rconv_abl = 0, g_rconv_stagger = 0;
+unsigned long long* g_rconv_trace = nullptr;
+
+}  // namespace
+
+void mmgt_rconv_set_abl(int v) { g_rconv_abl = v; }
+void mmgt_rconv_set_stagger(int v) { g_rconv_stagger = v; }
+extern "C" void mmgt_rconv_set_trace(void* p) { g_rconv_trace = reinterpret_cast<unsigned long long*>(p); }
+
+// x0 (nb, H, W, C0) [+ x1 (nb, H, W, C1)] bf16 channels-last, H and W multiples of 16; scale | shift (2, nb, C0 + C1) fp32 in one allocation;
+// wimg = pack_rconv image of the (Cout, C0 + C1, 3, 3) weight; bias (Cout) / bias2 (rows, Cout) fp32 or null, image n takes row n / b2_imgs;
+// residual / out (nb, H, W, Cout) bf16.  C0, C1 multiples of 64, Cout a multiple of 320.
+extern "C" int mmgt_gn_silu_conv3x3_unet(const void* x0, int C0, const void* x1, int C1, const float* scale_shift, const void* wimg, const float* bias,
+                                         const float* bias2, int b2_imgs, const void* residual, void* out, int nb, int H, int W, int cout, int dtype,
+                                         void* stream) {
+  MMGT_CHECK(x0 && scale_shift && wimg && out && nb > 0 && H > 0 && W > 0, "gn_silu_conv3x3_unet: bad arguments");
+  MMGT_CHECK(dtype == MMGT_BF16, "gn_silu_conv3x3_unet: bf16 only (the fp32-I/O mode runs GroupNorm / conv)");
+  MMGT_CHECK((x1 != nullptr) == (C1 > 0) && C0 > 0 && C0 % RC_PC == 0 && C1 % RC_PC == 0, "gn_silu_conv3x3_unet: C0 = %d, C1 = %d must be multiples of %d", C0, C1, RC_PC);
+  MMGT_CHECK(cout > 0 && cout % 320 == 0, "gn_silu_conv3x3_unet: Cout = %d must be a multiple of 320", cout);
+  MMGT_CHECK(H % RC_T == 0 && W % RC_T == 0, "gn_silu_conv3x3_unet: H and W must be multiples of 16 (got %d x %d)", H, W);
+  MMGT_CHECK(!bias2 || b2_imgs > 0, "gn_silu_conv3x3_unet: bias2 needs b2_imgs > 0");
+  const long cin = (long)C0 + C1;
+  MMGT_CHECK((long)nb * H * W * (C0 > C1 ? C0 : C1) * 2 < (1l << 31) && (long)nb * H * W * cout * 2 < (1l << 31) && (long)cout * cin * 18 < (1l << 31) &&
+                 2l * nb * cin * 4 < (1l << 31),
+             "gn_silu_conv3x3_unet: every operand must be smaller than 2 GiB");
+  MMGT_CHECK((((uintptr_t)x0 | (uintptr_t)x1 | (uintptr_t)scale_shift | (uintptr_t)wimg | (uintptr_t)bias | (uintptr_t)bias2 | (uintptr_t)residual | (uintptr_t)out) & 15) == 0,
+             "gn_silu_conv3x3_unet: pointers must be 16-byte aligned");
+  RcArgs a;
+  a.x0 = reinterpret_cast<const bf16_t*>(x0);
+  a.x1 = reinterpret_cast<const bf16_t*>(x1);
+  a.C0 = C0;
+  a.C1 = C1;
+  a.scale = scale_shift;
+  a.wimg = reinterpret_cast<const char*>(wimg);
+  a.bias = bias;
+  a.bias2 = bias2;
+  a.b2_imgs = b2_imgs > 0 ? b2_imgs : 1;
+  a.res = reinterpret_cast<const bf16_t*>(residual);
+  a.out = reinterpret_cast<bf16_t*>(out);
+  a.nb = nb;
+  a.H = H;
+  a.W = W;
+  a.tiles_x = W / RC_T;
+  a.tiles_per_img = (H / RC_T) * (W / RC_T);
+  a.ncb = cout / 320;
+  a.nunits = nb * a.tiles_per_img * a.ncb;
+  a.nph = (int)(cin / RC_PC);
+  a.cout = cout;
+  a.abl = g_rconv_abl;
+  a.stagger = g_rconv_stagger;
+  a.trace = g_rconv_trace;
+  int dev = 0;
+  static int ncu[16] = {};
+  MMGT_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "gn_silu_conv3x3_unet: device query failed");
+  if (!ncu[dev]) {
+    hipDeviceProp_t prop;
+    MMGT_CHECK(hipGetDeviceProperties(&prop, dev) == hipSuccess, "gn_silu_conv3x3_unet: device query failed");
+    ncu[dev] = prop.multiProcessorCount;
+  }
+  int gx = ncu[dev] / 8 * 8;
+  if (gx > a.nunits) gx = a.nunits;
+  static bool ready[16][2] = {};
+  auto go = [&](void (*kern)(const RcArgs), int slot) -> int {
+    constexpr int lds = RcCfg<10>::LDS;
+    if (!ready[dev][slot]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        mmgt_set_error("gn_silu_conv3x3_unet: cannot reserve %d bytes of LDS", lds);
+        return 2;
+      }
+      ready[dev][slot] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, (hipStream_t)stream, a);
+    return 0;
+  };
+  const int rc = residual ? go(rconv_kernel<10, true>, 1) : go(rconv_kernel<10, false>, 0);
+  if (rc) return rc;
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" long mmgt_gn_silu_conv3x3_unet_image_bytes(int cin, int cout) {
+  return (cin > 0 && cin % RC_PC == 0 && cout > 0 && cout % 320 == 0) ? (long)cin * 9 * cout * 2 : -1;
+}

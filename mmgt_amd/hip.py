@@ -26,6 +26,7 @@ _SIGS = {
     "mmgt_box_calib": (c_int, [c_float, ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_void_p]),
     "mmgt_gemm16_set_trace": (None, [c_void_p]),
     "mmgt_ffn_set_trace": (None, [c_void_p]),
+    "mmgt_rconv_set_trace": (None, [c_void_p]),
     "mmgt_gemm": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_long,
                           c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_long, c_long, c_int,
                           c_void_p]),
@@ -69,6 +70,11 @@ _SIGS = {
                                 c_long, c_void_p, c_long, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_gn_silu_conv3x3_image_bytes": (c_long, [c_int, c_int]),
     "mmgt_gn_silu_conv3x3": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_gn_silu_conv3x3_unet_image_bytes": (c_long, [c_int, c_int]),
+    "mmgt_gn_silu_conv3x3_unet": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                          c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_groupnorm_affine2": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       c_float, c_int, c_void_p]),
     "mmgt_gn_stats_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "mmgt_temporal_leg320_image_bytes": (c_long, []),
     "mmgt_temporal_leg320": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_int,
@@ -332,19 +338,57 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x1=None, out=None):
     return out
 
 
-def groupnorm_affine(x, gamma, beta, groups, eps):
-    """x (NB, HW, C), HW > 256 -> (scale, shift), fp32 (NB, C) each: GroupNorm(x)[n, p, c] = x[n, p, c] * scale[n, c] + shift[n, c].
-    The statistics pass of `groupnorm` alone; `rowgemm320(pre_scale=, pre_shift=)` applies the tables while it loads x."""
-    _dev(x, gamma, beta)
+def groupnorm_affine(x, gamma, beta, groups, eps, x1=None):
+    """x (NB, HW, C) [+ x1 (NB, HW, C1): the channel concatenation], HW > 256 -> (scale, shift), fp32 (NB, C + C1) each:
+    GroupNorm(x | x1)[n, p, c] = (x | x1)[n, p, c] * scale[n, c] + shift[n, c].
+    The statistics pass of `groupnorm` alone; `rowgemm320(pre_scale=, pre_shift=)` / `gn_silu_conv3x3_unet` apply the tables while they load x."""
+    _dev(x, gamma, beta, x1)
     assert x.dim() == 3 and x.is_contiguous() and x.shape[1] > 256
     NB, HW, C = x.shape
+    C1 = 0
+    if x1 is not None:
+        assert x1.is_contiguous() and x1.shape[:2] == x.shape[:2] and x1.dtype == x.dtype
+        C1 = x1.shape[2]
     chunks = lib().mmgt_groupnorm_chunks(HW)
     ws = torch.empty((NB * chunks * groups * 2,), device=x.device, dtype=torch.float32)
-    tab = torch.empty((2, NB, C), device=x.device, dtype=torch.float32)       # one allocation: gn_silu_conv3x3 fetches scale | shift rows with one descriptor
+    tab = torch.empty((2, NB, C + C1), device=x.device, dtype=torch.float32)       # one allocation: the fused convs fetch scale | shift rows with one descriptor
     scale, shift = tab[0], tab[1]
-    _check(lib().mmgt_groupnorm_affine(_ptr(x), C, _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), _ptr(ws), _ptr(scale), _ptr(shift),
-                                       NB, HW, groups, eps, dtype_code(x.dtype), _stream()), "mmgt_groupnorm_affine")
+    _check(lib().mmgt_groupnorm_affine2(_ptr(x), C, _ptr(x1), C1, _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), _ptr(ws), _ptr(scale),
+                                        _ptr(shift), NB, HW, groups, eps, dtype_code(x.dtype), _stream()), "mmgt_groupnorm_affine2")
     return scale, shift
+
+
+def gn_silu_conv3x3_unet_supported(dtype, c0, c1, cout, H, W):
+    """csrc/rconv.hip: bf16, 16 x 16 pixel tiles, 64-channel phases, 320-wide output blocks"""
+    return dtype == torch.bfloat16 and c0 % 64 == 0 and c1 % 64 == 0 and c0 > 0 and cout % 320 == 0 and H % 16 == 0 and W % 16 == 0
+
+
+def gn_silu_conv3x3_unet(x, scale, shift, wimg, cout, bias=None, bias2=None, b2_imgs=0, residual=None, x1=None, out=None):
+    """bias + bias2[n // b2_imgs] + conv3x3(silu((x | x1) * scale[n, c] + shift[n, c])) (+ residual) in one launch (csrc/rconv.hip): x (NB, H, W, C0)
+    [, x1 (NB, H, W, C1)] bf16 channels-last, (scale, shift) the tables of `groupnorm_affine` (one allocation), wimg = packing.pack_rconv(weight)."""
+    _dev(x, scale, shift, wimg, bias, bias2, residual, x1, out)
+    assert x.dim() == 4 and x.is_contiguous()
+    NB, H, W, C0 = x.shape
+    C1 = 0
+    if x1 is not None:
+        assert x1.is_contiguous() and x1.shape[:3] == x.shape[:3] and x1.dtype == x.dtype
+        C1 = x1.shape[3]
+    assert gn_silu_conv3x3_unet_supported(x.dtype, C0, C1, cout, H, W)
+    C = C0 + C1
+    assert scale.shape == (NB, C) and shift.shape == (NB, C) and scale.dtype == torch.float32 and scale.is_contiguous() and shift.is_contiguous()
+    assert shift.data_ptr() == scale.data_ptr() + 4 * NB * C, "scale and shift must be the two halves of one allocation (groupnorm_affine)"
+    assert wimg.dtype == torch.uint8 and wimg.is_contiguous() and wimg.numel() == lib().mmgt_gn_silu_conv3x3_unet_image_bytes(C, cout)
+    if out is None:
+        out = torch.empty((NB, H, W, cout), device=x.device, dtype=x.dtype)
+    assert out.shape == (NB, H, W, cout) and out.is_contiguous() and out.dtype == x.dtype
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype
+    if bias2 is not None:
+        assert bias2.dim() == 2 and bias2.shape[1] == cout and bias2.is_contiguous() and b2_imgs > 0 and (NB + b2_imgs - 1) // b2_imgs <= bias2.shape[0]
+    _check(lib().mmgt_gn_silu_conv3x3_unet(_ptr(x), C0, _ptr(x1), C1, _ptr(scale), _ptr(wimg), _ptr(_f32(bias, "bias")), _ptr(_f32(bias2, "bias2")),
+                                           b2_imgs, _ptr(residual), _ptr(out), NB, H, W, cout, dtype_code(x.dtype), _stream()),
+           "mmgt_gn_silu_conv3x3_unet")
+    return out
 
 
 def gn_silu_conv3x3_supported(dtype, cin, cout, H, W, residual=False):

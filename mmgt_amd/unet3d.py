@@ -19,7 +19,7 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from . import hip
-from .packing import pack_conv3x3, pack_ff_fused, pack_ff_proj_out, pack_geglu, pack_rowgemm, pack_tleg, pad_cols, pad_rows, round_up
+from .packing import pack_conv3x3, pack_ff_fused, pack_ff_proj_out, pack_geglu, pack_rconv, pack_rowgemm, pack_tleg, pad_cols, pad_rows, round_up
 from .unet3d_spec import unet3d_spec
 
 SD15_CONFIG = dict(  # SD-1.5 unet/config.json + unet_3d.py:649-662 + config/prompts/animation.yaml:47-75
@@ -121,6 +121,8 @@ class UNet3DConditionModel:
         self._fuse_oz = bool(hip.tune_get("oz3"))                 # 0: the three masked audio out-projections as separate launches
         self._fuse_ln = bool(hip.tune_get("rowgemm"))             # 0: LayerNorm and q / k / v GEMMs as separate launches
         self._fuse_tleg = bool(hip.tune_get("tleg"))              # 0: a level-0 temporal-attention leg as three launches
+        self._rconv = hip.tune_get("rconv")                        # resnets whose GroupNorm -> SiLU -> conv3x3 legs run as one launch (csrc/rconv.hip): 0 none,
+                                                                   # 1 the 320-wide level, 2 + the 640-wide level, 3 every level with 16 x 16 tiles
         self.spec = unet3d_spec(boc, cfg["cross_attention_dim"], cfg["audio_attention_dim"], self.in_channels,
                                 self.out_channels, cfg["layers_per_block"],
                                 cfg["motion_module_kwargs"].get("temporal_position_encoding_max_len", 32))
@@ -310,6 +312,12 @@ class UNet3DConditionModel:
             conv(p + ".conv1")
             conv(p + ".conv2")
             cout = self.spec[p + ".conv1.weight"][0]
+            if self._rconv and self._dtype == torch.bfloat16 and cout <= (320, 640, 1280)[min(self._rconv, 3) - 1] and \
+                    has(p + ".conv1.weight") and has(p + ".conv2.weight"):
+                for cv in (".conv1", ".conv2"):                        # fragment-major images of the fused GroupNorm + SiLU + conv launch
+                    wt = sd[p + cv + ".weight"]
+                    if hip.gn_silu_conv3x3_unet_supported(self._dtype, wt.shape[1], 0, wt.shape[0], 16, 16):
+                        w[p + cv + ".rimg"] = pack_rconv(wt.to(self._device))
             self._temb_slices[p] = (off, cout)
             off += cout
             if has(p + ".time_emb_proj.weight"):
@@ -506,12 +514,23 @@ class UNet3DConditionModel:
         nb, h, ww, c0 = x.shape
         hw = h * ww
         cout = self.spec[p + ".conv1.weight"][0]
-        hdn = self._gn(p + ".norm1", x, self.config.norm_eps, silu=True, x1=skip)
-        b2rows = (nb // temb[p].shape[0]) * hw
-        if temb[p].shape[0] == 1:
-            b2rows = max(b2rows, 256)       # one row for every output row: any count >= M is the same sum, and >= 256 keeps the vectorised epilogue
-        hdn = hip.conv3x3(hdn, self.w[p + ".conv1.w"], self.w[p + ".conv1.bias"], bias2=temb[p], bias2_rows=b2rows)
-        hdn = self._gn(p + ".norm2", hdn, self.config.norm_eps, silu=True)
+        c1 = 0 if skip is None else skip.shape[3]
+        # GroupNorm-apply + SiLU + conv3x3 as ONE launch behind the statistics pass (csrc/rconv.hip): the normalised tensor is never written
+        fused = hw > 256 and (p + ".conv1.rimg") in self.w and (p + ".conv2.rimg") in self.w and \
+            hip.gn_silu_conv3x3_unet_supported(self._dtype, c0, c1, cout, h, ww) and hip.gn_silu_conv3x3_unet_supported(self._dtype, cout, 0, cout, h, ww)
+        if fused:
+            eps = self.config.norm_eps
+            sc, sh = hip.groupnorm_affine(x.view(nb, hw, c0), self.w[p + ".norm1.g"], self.w[p + ".norm1.b"], 32, eps,
+                                          x1=None if skip is None else skip.view(nb, hw, c1))
+            hdn = hip.gn_silu_conv3x3_unet(x, sc, sh, self.w[p + ".conv1.rimg"], cout, self.w[p + ".conv1.bias"], temb[p], nb // temb[p].shape[0], x1=skip)
+            sc, sh = hip.groupnorm_affine(hdn.view(nb, hw, cout), self.w[p + ".norm2.g"], self.w[p + ".norm2.b"], 32, eps)
+        else:
+            hdn = self._gn(p + ".norm1", x, self.config.norm_eps, silu=True, x1=skip)
+            b2rows = (nb // temb[p].shape[0]) * hw
+            if temb[p].shape[0] == 1:
+                b2rows = max(b2rows, 256)       # one row for every output row: any count >= M is the same sum, and >= 256 keeps the vectorised epilogue
+            hdn = hip.conv3x3(hdn, self.w[p + ".conv1.w"], self.w[p + ".conv1.bias"], bias2=temb[p], bias2_rows=b2rows)
+            hdn = self._gn(p + ".norm2", hdn, self.config.norm_eps, silu=True)
         if (p + ".sc.w") in self.w:
             wsc = self.w[p + ".sc.w"]
             if skip is None:
@@ -524,6 +543,8 @@ class UNet3DConditionModel:
         else:
             assert skip is None
             res = x
+        if fused:
+            return hip.gn_silu_conv3x3_unet(hdn, sc, sh, self.w[p + ".conv2.rimg"], cout, self.w[p + ".conv2.bias"], residual=res, out=out)
         return hip.conv3x3(hdn, self.w[p + ".conv2.w"], self.w[p + ".conv2.bias"], residual=res, out=out)
 
     def _sc_split(self, p, c0, which):

@@ -79,6 +79,48 @@ def store_hazards(lines, count=None):
     return out
 
 
+MFMA_DST = re.compile(r"^\s*v_s?mfma\w*\s+([av])\[(\d+):(\d+)\]")
+REGS = re.compile(r"\b([av])(?:\[(\d+):(\d+)\]|(\d+))\b")
+EARLY_SLOTS = 11       # wait states between an MFMA and a non-MFMA instruction that touches its result (GCNHazardRecognizer: passes + 3: 7 for the 4-pass
+                       # 16x16 shapes, 11 for the 8-pass 32x32 shapes); an instruction counts 1, s_nop N counts N + 1, an MFMA in between at least 4
+
+
+def early_result_uses(lines):
+    """(function, mfma, user) for non-MFMA instructions that touch an MFMA's destination registers within EARLY_SLOTS issue slots behind it (s_nop N
+    counts N + 1).  hipcc keeps these distances for the builtins; an INLINE-ASM MFMA (csrc/rconv.hip, csrc/calib.hip) hides its latency from the
+    compiler, which may then place a copy or a spill of the accumulator straight behind it -- wrong sums, silently (rounds 4 and 6)."""
+    out, func = [], "?"
+    recent = []                                            # (slots left, kind, lo, hi, text)
+    for line in lines:
+        m = re.match(r"^[0-9a-f]+ <(.+)>:", line)
+        if m:
+            func, recent = m.group(1), []
+            continue
+        text = line.split("//")[0]
+        if ":" in text[:24]:
+            text = text.split(":", 1)[1] if re.match(r"^\s*[0-9a-f]+:", text) else text
+        t = text.strip()
+        if not t:
+            continue
+        if re.search(r"\b(s_branch|s_cbranch\w*|s_endpgm|s_setpc_b64|s_barrier)\b", t):
+            recent = []                                    # (what follows in the listing is not what follows in time; a barrier is long enough)
+            continue
+        mn = re.match(r"s_nop\s+(\d+)", t)
+        md = MFMA_DST.match(t)
+        step = int(mn.group(1)) + 1 if mn else 4 if md else 1
+        if not md and not mn:
+            for kind, a, b, one in REGS.findall(t.split(None, 1)[1] if len(t.split(None, 1)) > 1 else ""):
+                lo, hi = (int(a), int(b)) if a else (int(one), int(one))
+                for left, k2, l2, h2, txt in recent:
+                    if k2 == kind and lo <= h2 and l2 <= hi:
+                        out.append((func, txt, t))
+                        break
+        recent = [(left - step, k, l, h, x) for left, k, l, h, x in recent if left - step > 0]
+        if md:
+            recent.append((7 if "16x16" in t else EARLY_SLOTS, md.group(1), int(md.group(2)), int(md.group(3)), t))
+    return out
+
+
 def scan(obj):
     bad, total = [], 0
     with tempfile.TemporaryDirectory() as td:
@@ -102,12 +144,12 @@ def scan(obj):
             bad.append((func, line.strip().split("//")[0].strip()))
     nst = [0]
     sth = store_hazards(dis.splitlines(), nst)
-    return total, bad, sth, nst[0]
+    return total, bad, sth, nst[0], early_result_uses(dis.splitlines())
 
 
 # objects whose kernels are built on MFMAs and 16-byte stores: the scan must FIND both in them -- a disassembler whose text no longer matches the
 # patterns above (or an empty build directory) must fail the check, not pass it vacuously
-MFMA_OBJECTS = ("gemm.o", "gemm16.o", "ffn.o", "rowgemm.o", "attention.o", "attn64.o", "tleg.o", "gnconv.o")
+MFMA_OBJECTS = ("gemm.o", "gemm16.o", "ffn.o", "rowgemm.o", "attention.o", "attn64.o", "tleg.o", "gnconv.o", "rconv.o")
 NO_WIDE_STORES = ("attn64.o",)          # (its outputs leave as 8-byte stores)
 
 
@@ -120,8 +162,12 @@ def main():
             print(f"check_mfma_overlap: objects not built: {missing} (run make -C mmgt_amd/csrc first)")
             return 2
     for o in objs:
-        total, bad, sth, nst = scan(o)
-        print(f"{os.path.basename(o):24s} {total:6d} MFMAs, {len(bad)} with vDst partially overlapping SrcC; {nst} wide stores, {len(sth)} whose data is rewritten at once")
+        total, bad, sth, nst, early = scan(o)
+        print(f"{os.path.basename(o):24s} {total:6d} MFMAs, {len(bad)} with vDst partially overlapping SrcC; {nst} wide stores, {len(sth)} whose data is rewritten at once; "
+              f"{len(early)} MFMA results touched within {EARLY_SLOTS} wait states")
+        for f, mf, us in early[:20]:
+            print(f"    {f[:60]}: {mf}   ->   {us}")
+            rc = 1
         base = os.path.basename(o).replace("abl_", "")
         if base in MFMA_OBJECTS and (total == 0 or (nst == 0 and base not in NO_WIDE_STORES)):
             print(f"    PARSED NOTHING: {total} MFMAs / {nst} wide stores in an object that is built on them -- the disassembly no longer matches this tool's patterns")

@@ -59,6 +59,13 @@ def key_of(name, args, kw):
         pro = "LN" if kw.get("ln_gamma") is not None else "GN" if kw.get("pre_scale") is not None else "-"
         return (f"rowgemm320 M={x.shape[0]} N={N} ({pro} prologue{', V^T' if n1 not in (None, N) else ''}{', +res' if kw.get('residual') is not None else ''})",
                 2 * x.shape[0] * N * 320)
+    if name == "gn_silu_conv3x3_unet":
+        x, cout = args[0], args[4]
+        x1 = kw.get("x1")
+        cin = x.shape[3] + (0 if x1 is None else x1.shape[3])
+        res = kw.get("residual") is not None or (len(args) > 8 and args[8] is not None)
+        return (f"gn_silu_conv3x3_unet nb={x.shape[0]} h={x.shape[1]} cin={cin} cout={cout} (GroupNorm apply + SiLU + conv{' + res' if res else ''}, one launch)",
+                2 * x.shape[0] * x.shape[1] * x.shape[2] * cout * 9 * cin)
     if name == "groupnorm_affine":
         x = args[0]
         return f"groupnorm_affine nb={x.shape[0]} hw={x.shape[1]} c={x.shape[2]} (statistics only)", 0
@@ -102,7 +109,7 @@ def main():
     if len(sys.argv) > 2:                                       # window length (the reference ships context_frames = 12)
         bench.FRAMES = int(sys.argv[2])
         bench.build_inputs.__defaults__ = (bench.FRAMES,) + bench.build_inputs.__defaults__[1:]
-    for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "ff_fused", "ff_fused_po", "temporal_leg320", "rowgemm320", "groupnorm_affine", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
+    for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "ff_fused", "ff_fused_po", "temporal_leg320", "rowgemm320", "groupnorm_affine", "gn_silu_conv3x3_unet", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
               "ncfhw_to_nhwc", "nhwc_to_ncfhw", "timestep_features", "silu", "cfg_ddim_step", "accumulate_window"]:
         wrap(n)
     sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-calib"]
