@@ -934,6 +934,7 @@ void mmgt_tleg_set_abl(int v);
 void mmgt_gnconv_set_abl(int v);
 void mmgt_rconv_set_abl(int v);
 void mmgt_rconv_set_stagger(int v);
+void mmgt_rconv_set_cb(int v);
 // Switches of the HOST side of the operator (mmgt_amd/unet3d.py, pipeline.py, smga.py read them through mmgt_tune_get): they live here,
 // beside the kernel knobs, so that ONE state -- this table -- describes what a run executed (MMGT_TUNE="twin_attention=0,splitk=0").
 namespace {
@@ -974,6 +975,7 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "splitk")) { g_splitk = value; return 0; }
   if (key && !strcmp(key, "bm192")) { g_bm192 = value; return 0; }
   if (key && !strcmp(key, "tailsplit")) { g_tailsplit = value; return 0; }
+  if (key && !strcmp(key, "rconv_cb") && (value == 0 || value == 320 || value == 256 || value == 160)) { mmgt_rconv_set_cb(value); return 0; }
   if (key && !strcmp(key, "rconv_stagger") && value >= 0 && value <= 8192) { mmgt_rconv_set_stagger(value); return 0; }
 #ifdef MMGT_ABLATE   // libmmgt_hip_abl.so (`make abl`): timing ablations whose RESULTS ARE GARBAGE -- the instruments under tools/ load that library explicitly
   if (key && !strcmp(key, "ffn_dbg") && value >= 0 && value <= 2) { mmgt_ffn_set_dbg(value); return 0; }

@@ -373,7 +373,10 @@ __global__ __launch_bounds__(256) void gn_affine_kernel(const T* __restrict__ x0
 template <typename T, int GPW>
 __global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       T* __restrict__ out, int HW, int G, float eps, int silu) {
+                                                       T* __restrict__ out, int HW, int G, float eps, int silu,
+                                                       float* __restrict__ tscale = nullptr, float* __restrict__ tshift = nullptr) {
+  // tscale / tshift (mmgt_groupnorm_affine2 on small images): the two statistics passes only, the per-(image, channel) tables out instead of the
+  // normalised tensor -- for a consumer that applies x * scale + shift itself (csrc/rconv.hip).
   constexpr int VEC = VecIO<T>::VEC;
   __shared__ float part[256 * VEC];
   __shared__ float chan[320];               // per-channel sums of the slab (the dispatch guard admits cw = GPW * C / G <= 320 channels)
@@ -442,6 +445,13 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x0,
       const float rstd = rsqrtf(gstat[1][gid[e]] / cnt + eps);
       sc[e] = rstd * gamma[c + e];
       sh[e] = beta[c + e] - mean[e] * sc[e];
+    }
+    if (tscale) {
+      if (r0 == 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { tscale[(long)n * C + c + e] = sc[e]; tshift[(long)n * C + c + e] = sh[e]; }
+      }
+      return;
     }
     T* dst = out + (long)n * HW * C + c;
 #pragma unroll 4
@@ -628,6 +638,22 @@ extern "C" int mmgt_groupnorm_affine2(const void* x, int C0, const void* x1, int
   MMGT_CHECK(C <= GN_MAXC && C % G == 0 && G <= 64 && C0 % vec == 0 && C1 % vec == 0, "groupnorm_affine: unsupported channels C=%d + %d G=%d", C0, C1, G);
   MMGT_CHECK(NB > 0 && HW > 0 && NB <= 65535, "groupnorm_affine: bad NB=%d HW=%d", NB, HW);
   hipStream_t s = (hipStream_t)stream;
+  {
+    // small images (the 16 x 16 and 8 x 8 levels): the single-launch kernel's two statistics passes, tables out (see mmgt_groupnorm_nhwc)
+    const int cg = C / G;
+    const int gpw = (HW > 64 && G % 2 == 0 && (2 * cg) % vec == 0) ? 2 : 4;
+    const int cw = gpw * cg;
+    if (HW <= 256 && G % gpw == 0 && cw % vec == 0 && cw <= 320 && cw / vec <= 256 && C0 % vec == 0) {
+      dim3 grid(G / gpw, NB);
+#define GN_SMALL_T(T_, GPW_) hipLaunchKernelGGL((gn_small_kernel<T_, GPW_>), grid, dim3(256), 0, s, (const T_*)x, C0, (const T_*)x1, C1, gamma, beta, \
+                                                (T_*)nullptr, HW, G, eps, 0, scale, shift)
+      if (dtype == MMGT_BF16) { if (gpw == 2) GN_SMALL_T(bf16_t, 2); else GN_SMALL_T(bf16_t, 4); }
+      else { if (gpw == 2) GN_SMALL_T(float, 2); else GN_SMALL_T(float, 4); }
+#undef GN_SMALL_T
+      MMGT_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   const int nvec = C / vec, maxs = GN_MAXC / (vec * 64);
   if (!x1 && gn_narrow_fits(nvec, 0, HW)) {
     const int chunks = gn_narrow_chunks(HW, NB, nvec);

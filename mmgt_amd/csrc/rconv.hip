@@ -44,7 +44,7 @@ constexpr int RC_HPIECES = (RC_NPIX * (RC_PC / 8) + 63) / 64;               // 1
 constexpr int RC_HALO = RC_HPIECES * 1024;                                  // bytes per halo buffer
 constexpr int RC_NHV = (RC_HPIECES + 7) / 8;                                // pieces (= 16-byte vectors per lane) per wave and phase: 6
 constexpr int RC_NSTEP = 18;                                                // k-steps (tap, 32-channel half) per phase
-constexpr int RC_FWD = 4;                                                   // W fragments in flight per wave
+constexpr int RC_FWD = 3;                                                   // W fragments in flight per wave (4: 4 registers more -- the 320-wide cut then spills inside its k-steps)
 
 struct RcArgs {
   const bf16_t* x0; const bf16_t* x1;   // (nb, H, W, C0) [, (nb, H, W, C1)]
@@ -58,6 +58,7 @@ struct RcArgs {
   bf16_t* out;                          // (nb, H, W, Cout)
   int nb, H, W, tiles_x, tiles_per_img, ncb, nunits, nph, cout;
   unsigned long long* trace;            // debug: [workgroup][512] 100-MHz stamps of wave 0 (k-step starts; 2 per epilogue), or null
+  int trace_fine;                       // debug: four stamps per k-step (start, in front of the counted wait, in front of / behind the barrier)
   int stagger;                          // start delay of workgroup group (blockIdx.x >> 3) & 7, in units of 64 cycles per group index
   int abl;                              // -DMMGT_ABLATE builds only (timing ablations, results are garbage): 1 no weight data, 2 no halo data, 4 no normalisation, 8 no barriers, 16 no stores
 };
@@ -95,27 +96,37 @@ __device__ __forceinline__ const void* rc_uni(const void* ptr) {
   return reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
 }
 
+// the lane id, read afresh (a free function: see rc_uni)
+__device__ __forceinline__ int rc_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
 template <int LO, int... I, typename F>
 __device__ __forceinline__ void rc_for_impl(std::integer_sequence<int, I...>, F&& fn) { (fn(std::integral_constant<int, LO + I>{}), ...); }
 template <int LO, int HI, typename F>
 __device__ __forceinline__ void rc_for(F&& fn) { rc_for_impl<LO>(std::make_integer_sequence<int, (HI > LO ? HI - LO : 0)>{}, static_cast<F&&>(fn)); }
 
-template <int NT> struct RcCfg {
-  static constexpr int CB = 32 * NT, SLOT = CB * 64, NPC = 2 * NT, PPW = (NPC + 7) / 8;   // output block; bytes and pieces per k-step; pieces per wave
-  static constexpr int NSLOT = NT >= 10 ? 3 : 4;
+// Three cuts of a workgroup's 8 waves (rows x columns) over its unit of 256 pixels x CB output channels:
+//   NT = 10, RT = 4 (4 x 2 waves, CB = 320): the 320-wide level (768 units = 3 rounds of 256 CUs at 48 x 64 x 64);
+//   NT =  8, RT = 4 (4 x 2 waves, CB = 256): the 1280-wide level (48 tiles x 5 blocks = 240 units instead of 192);
+//   NT = 10, RT = 2 (8 x 1 waves, CB = 160): the 640-wide level (192 tiles x 4 blocks = 768 units instead of 384 = 1.5 rounds) and 24-image launches.
+template <int NT, int RT> struct RcCfg {
+  static constexpr int WN = RT / 2, CB = 16 * NT * WN, SLOT = CB * 64, NPC = NT * WN;   // wave columns; output block; bytes and 1-KiB pieces per k-step
+  // the weight pieces of a k-step are issued by the first NW waves, PPW each (NW = the largest divisor of NPC <= 8: 5 x 4, 8 x 2, 5 x 2): a wave's
+  // in-order vmcnt queue then holds either exactly PPW weight pieces per k-step or none, and the counted waits below are exact for both kinds
+  static constexpr int NW = NPC % 8 == 0 ? 8 : NPC % 7 == 0 ? 7 : NPC % 6 == 0 ? 6 : NPC % 5 == 0 ? 5 : 4, PPW = NPC / NW;
+  static constexpr int NSLOT_FIT = (160 * 1024 - 2 * RC_HALO - 6144) / SLOT, NSLOT = NSLOT_FIT > 5 ? 5 : NSLOT_FIT;   // (<= 5: the late waves' normalisation must end in front of k-step 17)
   static constexpr int L_RING = 2 * RC_HALO, L_BIAS = L_RING + NSLOT * SLOT, L_TAB = L_BIAS + 4096, L_DUMMY = L_TAB + 1024, LDS = L_DUMMY + 1024;
-  static_assert(LDS <= 160 * 1024 && NT % 2 == 0 && NPC >= RC_FWD && (RC_NSTEP * NT) % RC_FWD == 0, "LDS / shape");
+  static_assert(LDS <= 160 * 1024 && NSLOT >= 3 && NW * PPW == NPC && NT % 2 == 0 && NT >= RC_FWD + 2 && (RC_NSTEP * NT) % RC_FWD == 0 && (RT == 2 || RT == 4), "LDS / shape");
 };
 
-template <int NT, bool RES>
+template <int NT, int RT, bool RES>
 __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
-  using Cfg = RcCfg<NT>;
-  constexpr int CB = Cfg::CB, SLOT = Cfg::SLOT, NPC = Cfg::NPC, PPW = Cfg::PPW, NSLOT = Cfg::NSLOT;
-  constexpr int RT = 4, NPAIR = NT / 2, NST = RT * NPAIR;                   // image rows per wave; tile pairs; 16-byte stores per wave and unit
+  using Cfg = RcCfg<NT, RT>;
+  constexpr int CB = Cfg::CB, SLOT = Cfg::SLOT, NW = Cfg::NW, PPW = Cfg::PPW, NSLOT = Cfg::NSLOT, WN = Cfg::WN;
+  constexpr int NPAIR = NT / 2, NST = RT * NPAIR;                           // tile pairs; 16-byte stores per wave and unit
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lm = lane & 15, lq = lane >> 4;
-  const int wm = wid >> 1, wn = wid & 1;                   // image rows 4 wm .. + 3 of the tile, output channels (CB / 2) wn .. of the block
+  const int wm = wid / WN, wn = wid % WN;                  // image rows RT wm .. of the tile, output channels 16 NT wn .. of the block
 #ifdef MMGT_ABLATE
   const int abl = a.abl;
 #else
@@ -150,21 +161,22 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
   // ---- weight stream: k-step wg (counted over the workgroup's units) lives in ring slot wg % NSLOT
   const __amdgpu_buffer_rsrc_t rW = dma_rsrc(a.wimg);
   int wg = 0, w_vt = blockIdx.x, w_ch = 0, w_cboff = 0, w_slot = 0;
+  const int w_row = a.cout * 64;                           // bytes of a k-step's weights over ALL output channels (the image is [k-step][cout / 16][1 KiB])
   {
     int n, ty, tx, cb;
     decode(w_vt < a.nunits ? w_vt : 0, n, ty, tx, cb);
-    w_cboff = cb * ksteps_per_unit * SLOT;
+    w_cboff = cb * SLOT;
   }
-  // Beyond the last k-step the pieces still go out against the poison offset (zeros into a slot nobody reads), and the pieces a wave has too
-  // many (PPW 8 > NPC) into a dummy KiB: every wait count below is a compile-time constant on every path.
+  // Beyond the last k-step the pieces still go out against the poison offset (zeros into a slot nobody reads): every wait count below is a
+  // compile-time constant on every path.
   auto issue_w = [&]() {
-    const int soff = w_cboff + w_ch * SLOT;
+    const int soff = w_cboff + w_ch * w_row;
+    if (wid < NW) {
 #pragma unroll
-    for (int u = 0; u < PPW; ++u) {
-      const int q = wid * PPW + u;
-      const bool real = q < NPC;
-      blds16(rW, (real && wg < total && !(abl & 1)) ? (unsigned)(lane * 16 + q * 1024) : DMA_POISON, soff,
-             smem + (real ? Cfg::L_RING + w_slot * SLOT + q * 1024 : Cfg::L_DUMMY));
+      for (int u = 0; u < PPW; ++u) {
+        const int q = wid * PPW + u;
+        blds16(rW, (wg < total && !(abl & 1)) ? (unsigned)(rc_lane() * 16 + q * 1024) : DMA_POISON, soff, smem + Cfg::L_RING + w_slot * SLOT + q * 1024);
+      }
     }
     ++wg;
     w_slot = w_slot == NSLOT - 1 ? 0 : w_slot + 1;
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
       if (w_vt < a.nunits) {
         int n, ty, tx, cb;
         decode(w_vt, n, ty, tx, cb);
-        w_cboff = cb * ksteps_per_unit * SLOT;
+        w_cboff = cb * SLOT;
       }
     }
   };
@@ -183,9 +195,8 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
   // (lane & 7) ^ (R & 7) = (lane & 7) ^ (lane >> 3).  The thread that issues a vector normalises it (same buffer position), so `hmask` (bit i:
   // vector i lies inside the image) is the only state that crosses from the issue to the normalisation.
   unsigned hmask = 0;
-  const int hl_chunk = (lane & 7) ^ (lane >> 3);
-  const int hl_R = 8 * wid + (lane >> 3);                                  // pixel of vector 0 (vector i: + 64 i)
-  const int hl_pos = hl_R * 128 + (lane & 7) * 16;                         // its byte position inside a halo buffer (vector i: + 8192 i)
+  // (everything per lane below is derived from a lane id read AFRESH where it is used: values kept live across the k-steps were spilled, and a
+  //  scratch reload inside the loop costs an s_waitcnt vmcnt(0) -- i.e. the latency of the weight and halo pieces just issued: 1 us per reload)
   // One vector (= one piece per wave) of the halo of phase (h_n, h_ty, h_tx; source h_src, h_cs channels per pixel, channel offset h_choff) per
   // hand-over of k-steps 0 .. 5: ~15 full-rate VALU (24-bit multiplies) and one DMA each, instead of ~150 instructions in one k-step of every
   // wave at once (stamps, tools/trace_rconv.py: k-step 0 of a phase took 3.2 us against 1.05).
@@ -205,8 +216,8 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
   auto issue_halo_vec = [&](auto Ic, int buf) {
     constexpr int i = decltype(Ic)::value;
     const __amdgpu_buffer_rsrc_t rX = dma_rsrc(rc_uni(h_src));
-    int R = hl_R + 64 * i;
-    asm volatile("" : "+v"(R));                             // opaque: recomputed here, not kept across the phase
+    const int ln = rc_lane(), hl_chunk = (ln & 7) ^ (ln >> 3);
+    const int R = 8 * wid + (ln >> 3) + 64 * i;             // pixel of the lane's vector i
     const int hy = (int)__umul24(R, 3641) >> 16, hx = R - RC_HP * hy;           // R / 18, exact for R < 3 000
     const int y = h_ty * RC_T - 1 + hy, x = h_tx * RC_T - 1 + hx;
     const bool ok = R < RC_NPIX && y >= 0 && y < a.H && x >= 0 && x < a.W;
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
     // with the first vector: the phase's 64 scales (lanes 0 .. 15) | 64 shifts (lanes 16 .. 31), one piece of wave 0
     if constexpr (i == 0) {
       if (wid == 0)
-        blds16(dma_rsrc(a.scale), lane < 32 ? (unsigned)((((lane >> 4) * a.nb + h_n) * cin + h_c0 + (lane & 15) * 4) * 4) : DMA_POISON, 0,
+        blds16(dma_rsrc(a.scale), ln < 32 ? (unsigned)((((ln >> 4) * a.nb + h_n) * cin + h_c0 + (ln & 15) * 4) * 4) : DMA_POISON, 0,
                smem + Cfg::L_TAB);
     }
   };
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
     if (wid < 4) {
       int n, ty, tx, cb;
       decode(v, n, ty, tx, cb);
-      const int arr = wid >> 1, pc = wid & 1, col = pc * 256 + lane * 4;
+      const int arr = wid >> 1, pc = wid & 1, col = pc * 256 + rc_lane() * 4;
       const float* src = arr == 0 ? a.bias : a.bias2 ? a.bias2 + (long)(n / a.b2_imgs) * a.cout : nullptr;
       blds16(dma_rsrc(rc_uni(src ? src : a.scale)), (src && col < CB) ? (unsigned)((cb * CB + col) * 4) : DMA_POISON, 0, smem + Cfg::L_BIAS + arr * 2048 + pc * 1024);
     }
@@ -238,7 +249,6 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
   // exp -> rcp -> convert -> LDS write, ~300 cycles of latency) stood in front of the wave's next MFMAs (stamps: +0.15 us on a 0.9-us k-step).
   // Branch-free, scalar f32 arithmetic (csrc/gnconv.hip: packed f32 instructions cost ~25 cycles beside MFMAs); every stage's results are pinned
   // where the stage stands.
-  const int tab_ofs = Cfg::L_TAB + hl_chunk * 32;
   u32x2 n_raw;
   f32x4 n_sc, n_sh, n_t, n_x;
   int n_pos = 0;
@@ -246,9 +256,9 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
     constexpr int K = decltype(Kc)::value, I = decltype(Ic)::value, J = decltype(Jc)::value;
     if ((I == RC_NHV - 1 && wid != 0) || (abl & 4)) return;  // (only wave 0 has a sixth vector)
     if constexpr (K == 0) {
-      n_pos = buf * RC_HALO + hl_pos + I * 8192 + 4 * J;
-      int tofs = tab_ofs + 8 * J;
-      asm volatile("" : "+v"(n_pos), "+v"(tofs));           // (opaque: no common subexpressions across calls)
+      const int ln = rc_lane();
+      n_pos = buf * RC_HALO + (8 * wid + (ln >> 3)) * 128 + (ln & 7) * 16 + I * 8192 + 4 * J;   // vector I of this lane, dword J
+      const int tofs = Cfg::L_TAB + ((ln & 7) ^ (ln >> 3)) * 32 + 8 * J;                          // its channel octet's scales
       n_raw = *reinterpret_cast<const u32x2*>(smem + n_pos);
       n_sc = *reinterpret_cast<const f32x4*>(smem + tofs);
       n_sh = *reinterpret_cast<const f32x4*>(smem + tofs + RC_PC * 4);
@@ -276,15 +286,15 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
 
   // ---- fragment addressing.  A: pixel R = rl + K with rl = 18 (4 wm) + lm and K = 18 (i + ky) + kx a compile-time constant: row R of the
   // buffer, slot (4 ks + lq) ^ (R & 7); R & 7 = (rl + (K & 7)) & 7, so eight per-lane offsets (one per K & 7) serve every tap.
-  const int rl = RC_HP * RT * wm + lm;
-  int aofs[8];
-#pragma unroll
-  for (int k7 = 0; k7 < 8; ++k7) aofs[k7] = rl * 128 + ((lq ^ ((rl + k7) & 7)) << 4);
+  // computed where it is used from two registers (rl16: bits 6:4 = rl & 7; lq16) in three instructions per fragment -- eight offsets kept live cost
+  // the 320-wide cut spills inside its k-steps.
+  const int rl16 = (RC_HP * RT * wm + lm) * 16, lq16 = lq * 16;
   const int w_lane = Cfg::L_RING + wn * NT * 1024 + lane * 16;             // + slot SLOT + j 1 KiB
   s16x8 fa[RT], fw[RC_FWD];
   auto read_a1 = [&](int buf, auto Sc, auto Ic) {             // A fragment of image row i of the wave for k-step S
     constexpr int S = decltype(Sc)::value, i = decltype(Ic)::value, tap = S >> 1, ks = S & 1, ky = tap / 3, kx = tap % 3, K = RC_HP * (i + ky) + kx;
-    return *reinterpret_cast<const s16x8*>(smem + buf * RC_HALO + ((aofs[K & 7] ^ (ks ? 64 : 0)) + K * 128));
+    const int sw = (rl16 + (K & 7) * 16) & 0x70;              // ((rl + K) & 7) << 4
+    return *reinterpret_cast<const s16x8*>(smem + buf * RC_HALO + ((sw ^ (lq16 ^ (ks ? 64 : 0))) + (rl16 << 3) + K * 128));
   };
   auto read_w = [&](int slot, int j) { return *reinterpret_cast<const s16x8*>(smem + w_lane + slot * SLOT + j * 1024); };
 
@@ -293,6 +303,13 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
   // behind its stores.  Eight groups of workgroups start a few microseconds apart so that the bursts are spread over that time.
   for (int d = ((blockIdx.x >> 3) & 7) * a.stagger; d > 0; d -= 64) __builtin_amdgcn_s_sleep(64);
 
+  // s_waitcnt vmcnt(W PPW + X): W k-steps of weight pieces (the waves that issue them) + X other operations may stay in flight
+  auto wait_wx = [&](auto Wc, auto Xc) {
+    constexpr int W = decltype(Wc)::value, X = decltype(Xc)::value;
+    if (NW == 8 || wid < NW) wait_vmcnt<W * PPW + X>(); else wait_vmcnt<X>();
+  };
+#define RC_WAIT(W_, X_) wait_wx(std::integral_constant<int, (W_)>{}, std::integral_constant<int, (X_)>{})
+
   // ---- prologue: bias of the first unit, its first halo (normalised here), the first NSLOT - 1 k-steps of weights
   int vt = blockIdx.x, ph = 0, fp = 0;                      // current unit, its phase, phases done (buffer parity)
   if (my_units > 0) {
@@ -300,10 +317,10 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
     halo_target(vt, 0);
     rc_for<0, RC_NHV>([&](auto ic) { issue_halo_vec(ic, 0); });
     for (int g = 0; g < NSLOT - 1; ++g) issue_w();
-    wait_vmcnt<(NSLOT - 1) * PPW>();                        // bias, table, halo have landed (this wave's pieces)
+    RC_WAIT(NSLOT - 1, 0);                                  // bias, table, halo have landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();                           // ... everybody's: the table is complete
     rc_for<0, RC_NHV>([&](auto ic) { norm_dword(0, ic, std::integral_constant<int, 0>{}); norm_dword(0, ic, std::integral_constant<int, 2>{}); });
-    wait_vmcnt<(NSLOT - 2) * PPW>();                        // k-step 0 has landed
+    RC_WAIT(NSLOT - 2, 0);                                  // k-step 0 has landed
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0): the LDS stores above
   __builtin_amdgcn_s_barrier();
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
     if (has_next) halo_target(nvt, nph);
 
     if (first_ph) {
-      const acc4* lb = reinterpret_cast<const acc4*>(smem + Cfg::L_BIAS) + wn * (CB / 8) + lq;   // the lane's columns 16 j + 4 lq + r
+      const acc4* lb = reinterpret_cast<const acc4*>(smem + Cfg::L_BIAS) + wn * NT * 4 + lq;   // the lane's columns 16 j + 4 lq + r
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const acc4 b = lb[4 * j] + lb[128 + 4 * j];               // bias + temb row (2 KiB apart)
@@ -339,45 +356,54 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
       constexpr int S = decltype(sc_)::value;
       stamp();
       const int n_slot = c_slot == NSLOT - 1 ? 0 : c_slot + 1;
-      // two dwords of the next phase's halo per k-step, S = 3 .. 14 (its pieces and table have landed behind the barrier of k-step 2)
-      constexpr bool NORM = S >= 3 && S < 3 + 2 * RC_NHV;
-      constexpr int NV = NORM ? (S - 3) >> 1 : 0, NJ = NORM ? 2 * ((S - 3) & 1) : 0;
+      // Two dwords of the next phase's halo per k-step, S = NSLOT .. NSLOT + 11.  The counted waits of the hand-overs leave NSLOT - 3 k-steps of
+      // weight pieces and the halo pieces issued among them in flight, so the piece of hand-over h (vector h) -- and the table, issued with
+      // vector 0 by wave 0 -- is only known to have landed behind hand-over h + NSLOT - 1: vector i is normalised in k-steps NSLOT + 2 i, + 1.
+      // (With a six-deep ring a start at k-step 3 read LDS the DMA had not written yet: wrong rows, now and then.)
+      constexpr bool NORM = S >= NSLOT && S < NSLOT + 2 * RC_NHV;
+      constexpr int NV = NORM ? (S - NSLOT) >> 1 : 0, NJ = NORM ? 2 * ((S - NSLOT) & 1) : 0;
+      static_assert(NSLOT + 2 * RC_NHV <= RC_NSTEP - 1, "the normalisation must end in front of the phase's last k-step (whose barrier the late waves take first)");
       auto fwi = [](int j) constexpr { return (S * NT + j) % RC_FWD; };      // the rolling window's register of W tile j of this k-step
+      // ---- hand-over of k-step g: k-step g + 1 has landed (this wave's pieces; the barrier collects the others').  vmcnt retires in order, so
+      // the count is the operations YOUNGER than those pieces: the pieces of the k-steps behind it, the halo pieces of the earlier hand-overs
+      // (waves that issued a table / bias piece too wait for one operation more than they must), the stores of an epilogue in front of k-step 0.
+      auto handover = [&]() {
+        if (a.trace_fine) stamp();
+        constexpr int HLO = S + 2 - NSLOT > 0 ? S + 2 - NSLOT : 0, HHI = S - 1 < RC_NHV - 1 ? S - 1 : RC_NHV - 1;
+        constexpr int NH = HHI >= HLO ? HHI - HLO + 1 : 0;            // halo pieces issued behind the pieces waited for (one per hand-over 0 .. 5)
+        constexpr bool EPI = S <= NSLOT - 3;                          // ... and the stores of an epilogue in front of k-step 0
+        if constexpr (NH > 0 && EPI) {
+          if (stored) { if (has_next) RC_WAIT(NSLOT - 3, NH + NST); else RC_WAIT(NSLOT - 3, NST); }
+          else { if (has_next) RC_WAIT(NSLOT - 3, NH); else RC_WAIT(NSLOT - 3, 0); }
+        } else if constexpr (NH > 0) {
+          if (has_next) RC_WAIT(NSLOT - 3, NH); else RC_WAIT(NSLOT - 3, 0);
+        } else if constexpr (EPI) {
+          if (stored) RC_WAIT(NSLOT - 3, NST); else RC_WAIT(NSLOT - 3, 0);
+        } else {
+          RC_WAIT(NSLOT - 3, 0);
+        }
+        if constexpr (S == RC_NSTEP - 1) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this thread's normalised dwords are in LDS
+        if (a.trace_fine) stamp();
+        if (!(abl & 8)) __builtin_amdgcn_s_barrier();
+        if (a.trace_fine) stamp();
+        issue_w();                                          // into the slot k-step g - 1 left
+        if constexpr (S < RC_NHV) {
+          if (has_next) {
+            issue_halo_vec(std::integral_constant<int, S>{}, nbuf);
+            if constexpr (S == 0) { if (last_ph) issue_bias(nvt); }
+          }
+        }
+      };
       // ---- W tiles 0 .. NT - 3: tile-major (a W fragment serves the wave's four image rows, then its register takes the tile four ahead)
       rc_for<0, NT - 2>([&](auto jc_) {
         constexpr int j = decltype(jc_)::value;
         rc_for<0, RT>([&](auto ic) { rc_mma<(j < 8)>(acc[decltype(ic)::value][j], fw[fwi(j)], fa[decltype(ic)::value]); });
         if constexpr (NORM && j < 5) norm_stage(std::integral_constant<int, j>{}, nbuf, std::integral_constant<int, NV>{}, std::integral_constant<int, NJ>{});
         if constexpr (j + RC_FWD < NT) fw[fwi(j)] = read_w(c_slot, j + RC_FWD);
-        if constexpr (j + RC_FWD == NT) {
-          // ---- hand-over, behind the last read of the current slot: k-step g + 1 has landed (this wave's pieces; the barrier collects the
-          // others').  vmcnt retires in order, so the count is the operations YOUNGER than those pieces: the pieces of the k-steps behind
-          // it, the halo pieces of the earlier hand-overs (waves that issued a table / bias piece too wait for one operation more than they
-          // must), the stores of an epilogue in front of k-step 0.
-          constexpr int BASE = (NSLOT - 3) * PPW;
-          constexpr int HLO = S + 2 - NSLOT > 0 ? S + 2 - NSLOT : 0, HHI = S - 1 < RC_NHV - 1 ? S - 1 : RC_NHV - 1;
-          constexpr int NH = HHI >= HLO ? HHI - HLO + 1 : 0;            // halo pieces issued behind the pieces waited for (one per hand-over 0 .. 5)
-          constexpr bool EPI = S <= NSLOT - 3;                          // ... and the stores of an epilogue in front of k-step 0
-          if constexpr (NH > 0 && EPI) {
-            if (stored) { if (has_next) wait_vmcnt<BASE + NH + NST>(); else wait_vmcnt<BASE + NST>(); }
-            else { if (has_next) wait_vmcnt<BASE + NH>(); else wait_vmcnt<BASE>(); }
-          } else if constexpr (NH > 0) {
-            if (has_next) wait_vmcnt<BASE + NH>(); else wait_vmcnt<BASE>();
-          } else if constexpr (EPI) {
-            if (stored) wait_vmcnt<BASE + NST>(); else wait_vmcnt<BASE>();
-          } else {
-            wait_vmcnt<BASE>();
-          }
-          if constexpr (S == RC_NSTEP - 1) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this thread's normalised dwords are in LDS
-          if (!(abl & 8)) __builtin_amdgcn_s_barrier();
-          issue_w();                                          // into the slot k-step g - 1 left
-          if constexpr (S < RC_NHV) {
-            if (has_next) {
-              issue_halo_vec(std::integral_constant<int, S>{}, nbuf);
-              if constexpr (S == 0) { if (last_ph) issue_bias(nvt); }
-            }
-          }
-        }
+        // ---- hand-over (see `handover` above), behind the last read of the current slot.  (Measured and dropped: waves 4 - 7 -- the SIMD partners
+        // of waves 0 - 3 -- taking theirs five tile groups earlier, i.e. running half a k-step behind, MI355X_MICROARCH.md's stagger for "two waves
+        // that run the same program with one barrier per block": 0 ... +3 % on the four in-step shapes, profiles/r6/bench_rconv_wstagger_r6.txt.)
+        if constexpr (j + RC_FWD == NT) handover();
         if constexpr (j + RC_FWD >= NT) {
           // (no fragments are carried across an epilogue: it needs their 32 registers, and the unit's first reads cost one LDS round trip per ~100 000 cycles)
           if (S + 1 < RC_NSTEP || !last_ph) fw[fwi(j)] = read_w(n_slot, j + RC_FWD - NT);
@@ -408,9 +434,8 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
       stamp();
       int n, ty, tx, cb;
       decode(vt, n, ty, tx, cb);
-      int lme = lm, lqe = lq;
-      asm volatile("" : "+v"(lme), "+v"(lqe));               // (nothing of this is hoisted above the main loop)
-      const int cofs = cb * CB + wn * (CB / 2) + 16 * (lqe & 1) + 8 * (lqe >> 1);
+      const int lne = rc_lane(), lme = lne & 15, lqe = lne >> 4;   // (nothing of this is hoisted above the main loop or kept live across it)
+      const int cofs = cb * CB + wn * NT * 16 + 16 * (lqe & 1) + 8 * (lqe >> 1);
       const unsigned eoff = (unsigned)((((n * a.H + ty * RC_T + RT * wm) * a.W + tx * RC_T + lme) * a.cout + cofs) * 2);   // byte offset of (row 0, pair 0)
       const int erow = a.W * a.cout * 2;                      // bytes per image row
       u32x4 rv[2][RES ? NPAIR : 1];                           // residual vectors, one image row ahead of their use (one at a time: 0.8 us of latency each, 16 us per unit)
@@ -462,28 +487,31 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
     ph = nph;
     ++fp;
   }
+#undef RC_WAIT
   wait_vmcnt<0>();                                           // (the poison pieces write LDS: none may be in flight when the workgroup's LDS is released)
 }
 
-int g_rconv_abl = 0, g_rconv_stagger = 0;
+int g_rconv_abl = 0, g_rconv_stagger = 0, g_rconv_cb = 0;
 unsigned long long* g_rconv_trace = nullptr;
+int g_rconv_fine = 0;                  // (mmgt_rconv_set_trace(buf | 1): four stamps per k-step)
 
 }  // namespace
 
 void mmgt_rconv_set_abl(int v) { g_rconv_abl = v; }
 void mmgt_rconv_set_stagger(int v) { g_rconv_stagger = v; }
-extern "C" void mmgt_rconv_set_trace(void* p) { g_rconv_trace = reinterpret_cast<unsigned long long*>(p); }
+void mmgt_rconv_set_cb(int v) { g_rconv_cb = v; }
+extern "C" void mmgt_rconv_set_trace(void* p) { g_rconv_trace = reinterpret_cast<unsigned long long*>((uintptr_t)p & ~(uintptr_t)1); g_rconv_fine = (int)((uintptr_t)p & 1); }
 
 // x0 (nb, H, W, C0) [+ x1 (nb, H, W, C1)] bf16 channels-last, H and W multiples of 16; scale | shift (2, nb, C0 + C1) fp32 in one allocation;
 // wimg = pack_rconv image of the (Cout, C0 + C1, 3, 3) weight; bias (Cout) / bias2 (rows, Cout) fp32 or null, image n takes row n / b2_imgs;
-// residual / out (nb, H, W, Cout) bf16.  C0, C1 multiples of 64, Cout a multiple of 320.
+// residual / out (nb, H, W, Cout) bf16.  C0, C1 multiples of 64, Cout a multiple of 160.
 extern "C" int mmgt_gn_silu_conv3x3_unet(const void* x0, int C0, const void* x1, int C1, const float* scale_shift, const void* wimg, const float* bias,
                                          const float* bias2, int b2_imgs, const void* residual, void* out, int nb, int H, int W, int cout, int dtype,
                                          void* stream) {
   MMGT_CHECK(x0 && scale_shift && wimg && out && nb > 0 && H > 0 && W > 0, "gn_silu_conv3x3_unet: bad arguments");
   MMGT_CHECK(dtype == MMGT_BF16, "gn_silu_conv3x3_unet: bf16 only (the fp32-I/O mode runs GroupNorm / conv)");
   MMGT_CHECK((x1 != nullptr) == (C1 > 0) && C0 > 0 && C0 % RC_PC == 0 && C1 % RC_PC == 0, "gn_silu_conv3x3_unet: C0 = %d, C1 = %d must be multiples of %d", C0, C1, RC_PC);
-  MMGT_CHECK(cout > 0 && cout % 320 == 0, "gn_silu_conv3x3_unet: Cout = %d must be a multiple of 320", cout);
+  MMGT_CHECK(cout > 0 && cout % 160 == 0, "gn_silu_conv3x3_unet: Cout = %d must be a multiple of 160", cout);
   MMGT_CHECK(H % RC_T == 0 && W % RC_T == 0, "gn_silu_conv3x3_unet: H and W must be multiples of 16 (got %d x %d)", H, W);
   MMGT_CHECK(!bias2 || b2_imgs > 0, "gn_silu_conv3x3_unet: bias2 needs b2_imgs > 0");
   const long cin = (long)C0 + C1;
@@ -492,7 +520,7 @@ extern "C" int mmgt_gn_silu_conv3x3_unet(const void* x0, int C0, const void* x1,
              "gn_silu_conv3x3_unet: every operand must be smaller than 2 GiB");
   MMGT_CHECK((((uintptr_t)x0 | (uintptr_t)x1 | (uintptr_t)scale_shift | (uintptr_t)wimg | (uintptr_t)bias | (uintptr_t)bias2 | (uintptr_t)residual | (uintptr_t)out) & 15) == 0,
              "gn_silu_conv3x3_unet: pointers must be 16-byte aligned");
-  RcArgs a;
+  RcArgs a{};
   a.x0 = reinterpret_cast<const bf16_t*>(x0);
   a.x1 = reinterpret_cast<const bf16_t*>(x1);
   a.C0 = C0;
@@ -509,13 +537,12 @@ extern "C" int mmgt_gn_silu_conv3x3_unet(const void* x0, int C0, const void* x1,
   a.W = W;
   a.tiles_x = W / RC_T;
   a.tiles_per_img = (H / RC_T) * (W / RC_T);
-  a.ncb = cout / 320;
-  a.nunits = nb * a.tiles_per_img * a.ncb;
   a.nph = (int)(cin / RC_PC);
   a.cout = cout;
   a.abl = g_rconv_abl;
   a.stagger = g_rconv_stagger;
   a.trace = g_rconv_trace;
+  a.trace_fine = g_rconv_fine;
   int dev = 0;
   static int ncu[16] = {};
   MMGT_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "gn_silu_conv3x3_unet: device query failed");
@@ -524,11 +551,23 @@ extern "C" int mmgt_gn_silu_conv3x3_unet(const void* x0, int C0, const void* x1,
     MMGT_CHECK(hipGetDeviceProperties(&prop, dev) == hipSuccess, "gn_silu_conv3x3_unet: device query failed");
     ncu[dev] = prop.multiProcessorCount;
   }
-  int gx = ncu[dev] / 8 * 8;
+  // The cut (block width) that needs the fewest rounds of the persistent grid, weighted by what a unit costs: its MFMA work grows with CB, its halo
+  // traffic, normalisation and epilogue hand-over do not (the 40).  mmgt_tune("rconv_cb", 320 | 256 | 160) forces one.
+  const int tiles = nb * (H / RC_T) * (W / RC_T), cus = ncu[dev] / 8 * 8;
+  int cb = 0;
+  long best = 0;
+  for (int c : {320, 256, 160}) {
+    if (cout % c || (g_rconv_cb && g_rconv_cb != c)) continue;
+    const long units = (long)tiles * (cout / c), score = (units + cus - 1) / cus * (c + 40);
+    if (!cb || score < best) { cb = c; best = score; }
+  }
+  MMGT_CHECK(cb, "gn_silu_conv3x3_unet: no block width for Cout = %d (rconv_cb = %d)", cout, g_rconv_cb);
+  a.ncb = cout / cb;
+  a.nunits = tiles * a.ncb;
+  int gx = cus;
   if (gx > a.nunits) gx = a.nunits;
-  static bool ready[16][2] = {};
-  auto go = [&](void (*kern)(const RcArgs), int slot) -> int {
-    constexpr int lds = RcCfg<10>::LDS;
+  static bool ready[16][6] = {};
+  auto go = [&](void (*kern)(const RcArgs), int lds, int slot) -> int {
     if (!ready[dev][slot]) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
         mmgt_set_error("gn_silu_conv3x3_unet: cannot reserve %d bytes of LDS", lds);
@@ -539,12 +578,15 @@ extern "C" int mmgt_gn_silu_conv3x3_unet(const void* x0, int C0, const void* x1,
     hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, (hipStream_t)stream, a);
     return 0;
   };
-  const int rc = residual ? go(rconv_kernel<10, true>, 1) : go(rconv_kernel<10, false>, 0);
+  int rc;
+  if (cb == 320) rc = residual ? go(rconv_kernel<10, 4, true>, RcCfg<10, 4>::LDS, 1) : go(rconv_kernel<10, 4, false>, RcCfg<10, 4>::LDS, 0);
+  else if (cb == 256) rc = residual ? go(rconv_kernel<8, 4, true>, RcCfg<8, 4>::LDS, 3) : go(rconv_kernel<8, 4, false>, RcCfg<8, 4>::LDS, 2);
+  else rc = residual ? go(rconv_kernel<10, 2, true>, RcCfg<10, 2>::LDS, 5) : go(rconv_kernel<10, 2, false>, RcCfg<10, 2>::LDS, 4);
   if (rc) return rc;
   MMGT_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" long mmgt_gn_silu_conv3x3_unet_image_bytes(int cin, int cout) {
-  return (cin > 0 && cin % RC_PC == 0 && cout > 0 && cout % 320 == 0) ? (long)cin * 9 * cout * 2 : -1;
+  return (cin > 0 && cin % RC_PC == 0 && cout > 0 && cout % 160 == 0) ? (long)cin * 9 * cout * 2 : -1;
 }

@@ -339,11 +339,11 @@ def groupnorm(x, gamma, beta, groups, eps, silu=False, x1=None, out=None):
 
 
 def groupnorm_affine(x, gamma, beta, groups, eps, x1=None):
-    """x (NB, HW, C) [+ x1 (NB, HW, C1): the channel concatenation], HW > 256 -> (scale, shift), fp32 (NB, C + C1) each:
+    """x (NB, HW, C) [+ x1 (NB, HW, C1): the channel concatenation] -> (scale, shift), fp32 (NB, C + C1) each:
     GroupNorm(x | x1)[n, p, c] = (x | x1)[n, p, c] * scale[n, c] + shift[n, c].
     The statistics pass of `groupnorm` alone; `rowgemm320(pre_scale=, pre_shift=)` / `gn_silu_conv3x3_unet` apply the tables while they load x."""
     _dev(x, gamma, beta, x1)
-    assert x.dim() == 3 and x.is_contiguous() and x.shape[1] > 256
+    assert x.dim() == 3 and x.is_contiguous()
     NB, HW, C = x.shape
     C1 = 0
     if x1 is not None:
@@ -359,8 +359,8 @@ def groupnorm_affine(x, gamma, beta, groups, eps, x1=None):
 
 
 def gn_silu_conv3x3_unet_supported(dtype, c0, c1, cout, H, W):
-    """csrc/rconv.hip: bf16, 16 x 16 pixel tiles, 64-channel phases, 320-wide output blocks"""
-    return dtype == torch.bfloat16 and c0 % 64 == 0 and c1 % 64 == 0 and c0 > 0 and cout % 320 == 0 and H % 16 == 0 and W % 16 == 0
+    """csrc/rconv.hip: bf16, 16 x 16 pixel tiles, 64-channel phases, output blocks of 320 / 256 / 160 channels"""
+    return dtype == torch.bfloat16 and c0 % 64 == 0 and c1 % 64 == 0 and c0 > 0 and cout % 160 == 0 and H % 16 == 0 and W % 16 == 0
 
 
 def gn_silu_conv3x3_unet(x, scale, shift, wimg, cout, bias=None, bias2=None, b2_imgs=0, residual=None, x1=None, out=None):

@@ -190,15 +190,14 @@ def pack_gnconv(w):
     return img.contiguous().view(torch.uint8).reshape(-1)
 
 
-def pack_rconv(w, cb=320):
-    """A (Cout, Cin, 3, 3) conv weight, Cin % 64 == 0, Cout % cb == 0 -> the fragment-major image of csrc/rconv.hip (mmgt_gn_silu_conv3x3_unet), a
-    uint8 tensor: per block of cb output channels, Cin / 64 phases x 9 taps x 2 k-steps of 32 channels, each cb / 16 pieces of 1 KiB:
-    [blk][ph][tap = 3 ky + kx][ks][ct][lane][8 bf16] = W[cb blk + 16 ct + (lane & 15)][64 ph + 32 ks + 8 (lane >> 4) + j][ky][kx] -- fragments of
+def pack_rconv(w):
+    """A (Cout, Cin, 3, 3) conv weight, Cin % 64 == 0, Cout % 16 == 0 -> the fragment-major image of csrc/rconv.hip (mmgt_gn_silu_conv3x3_unet), a
+    uint8 tensor: Cin / 64 phases x 9 taps x 2 k-steps of 32 channels, each Cout / 16 pieces of 1 KiB (a workgroup's block of output channels is a
+    contiguous run of pieces of every k-step, whatever its width):
+    [ph][tap = 3 ky + kx][ks][ct][lane][8 bf16] = W[16 ct + (lane & 15)][64 ph + 32 ks + 8 (lane >> 4) + j][ky][kx] -- fragments of
     v_mfma_f32_16x16x32_bf16 (lane (lm, lq) owns row lm of the 16-channel tile, reduction slots 8 lq .. 8 lq + 7 of the k-step)."""
     cout, cin = w.shape[0], w.shape[1]
-    assert tuple(w.shape) == (cout, cin, 3, 3) and cin % 64 == 0 and cout % cb == 0 and cb % 16 == 0
-    dev = w.device
-    lane = torch.arange(64, device=dev)
-    wt = w.to(torch.bfloat16).permute(2, 3, 0, 1).reshape(9, cout // cb, cb // 16, 16, cin // 64, 2, 4, 8)   # (tap, blk, ct, lm, ph, ks, lq, j)
-    img = wt.permute(1, 4, 0, 5, 2, 6, 3, 7)                                                                  # (blk, ph, tap, ks, ct, lq, lm, j)
+    assert tuple(w.shape) == (cout, cin, 3, 3) and cin % 64 == 0 and cout % 16 == 0
+    wt = w.to(torch.bfloat16).permute(2, 3, 0, 1).reshape(9, cout // 16, 16, cin // 64, 2, 4, 8)   # (tap, ct, lm, ph, ks, lq, j)
+    img = wt.permute(3, 0, 4, 1, 5, 2, 6)                                                            # (ph, tap, ks, ct, lq, lm, j)
     return img.contiguous().view(torch.uint8).reshape(-1)

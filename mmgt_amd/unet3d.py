@@ -516,7 +516,7 @@ class UNet3DConditionModel:
         cout = self.spec[p + ".conv1.weight"][0]
         c1 = 0 if skip is None else skip.shape[3]
         # GroupNorm-apply + SiLU + conv3x3 as ONE launch behind the statistics pass (csrc/rconv.hip): the normalised tensor is never written
-        fused = hw > 256 and (p + ".conv1.rimg") in self.w and (p + ".conv2.rimg") in self.w and \
+        fused = (p + ".conv1.rimg") in self.w and (p + ".conv2.rimg") in self.w and \
             hip.gn_silu_conv3x3_unet_supported(self._dtype, c0, c1, cout, h, ww) and hip.gn_silu_conv3x3_unet_supported(self._dtype, cout, 0, cout, h, ww)
         if fused:
             eps = self.config.norm_eps

@@ -149,6 +149,25 @@ def test_product_library_refuses_the_timing_ablations():
     assert r.returncode != 0 and "garbage" in r.stderr
 
 
+def test_pack_rconv_fragment_image():
+    """The weight image of csrc/rconv.hip: [64-channel phase][tap][k-step of 32][16-channel tile][lane][8] with lane (lm, lq) = row lm of the tile,
+    reduction slots 8 lq .. 8 lq + 7 -- checked entry by entry against the definition; its size is what the library expects."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_rconv
+    g = torch.Generator().manual_seed(4)
+    for cout, cin in ((320, 320), (640, 384), (160, 64)):
+        w = torch.randn((cout, cin, 3, 3), generator=g)
+        raw = pack_rconv(w)
+        assert raw.numel() == hip.lib().mmgt_gn_silu_conv3x3_unet_image_bytes(cin, cout)
+        img = raw.view(torch.bfloat16).view(cin // 64, 9, 2, cout // 16, 64, 8)
+        wb = w.to(torch.bfloat16)
+        gi = torch.Generator().manual_seed(5)
+        for _ in range(200):
+            ph, tap, ks, ct, lane, j = (int(torch.randint(0, n, (1,), generator=gi)) for n in (cin // 64, 9, 2, cout // 16, 64, 8))
+            assert img[ph, tap, ks, ct, lane, j] == wb[16 * ct + (lane & 15), 64 * ph + 32 * ks + 8 * (lane >> 4) + j, tap // 3, tap % 3]
+    assert hip.lib().mmgt_gn_silu_conv3x3_unet_image_bytes(320, 300) == -1
+
+
 def test_pack_gnconv_fragment_image():
     """The weight image of csrc/gnconv.hip: [block of <= 128 output channels][128-channel phase][tap][k-step of 32][16-channel tile][lane][8] with
     lane (lm, lq) = row lm of the tile, reduction slots 8 lq .. 8 lq + 7 -- checked entry by entry against the definition."""

@@ -59,12 +59,23 @@ def _check(out, ref, cin):
     (300, 16, 16, 320, 0, 320, True, 0, 0),            # more units than workgroups: many units per workgroup, epilogue -> next unit hand-over
 ])
 def test_rconv_tables_vs_fp64(nb, H, W, c0, c1, cout, res, temb_rows, b2):
+    """... in every cut of the workgroup (mmgt_tune "rconv_cb": blocks of 320 / 256 / 160 output channels = 4 x 2 waves of 10 or 8 column tiles, 8 x 1
+    waves of 10) and in the one the dispatcher picks"""
     from mmgt_amd import hip
     from mmgt_amd.packing import pack_rconv
     x0, x1, w, b, temb, r, scale, shift = _case(nb, H, W, c0, c1, cout, 100 + nb + c0 + c1, res=res, temb_rows=temb_rows)
-    out = hip.gn_silu_conv3x3_unet(x0, scale, shift, pack_rconv(w), cout, b, temb, b2, r, x1=x1)
-    torch.cuda.synchronize()
-    _check(out, _ref(x0, x1, w, b, temb, max(b2, 1), r, scale, shift), c0 + c1)
+    ref = _ref(x0, x1, w, b, temb, max(b2, 1), r, scale, shift)
+    wimg = pack_rconv(w)
+    try:
+        for cb in (0, 320, 256, 160):
+            if cb and cout % cb:
+                continue
+            hip.tune("rconv_cb", cb)
+            out = hip.gn_silu_conv3x3_unet(x0, scale, shift, wimg, cout, b, temb, b2, r, x1=x1)
+            torch.cuda.synchronize()
+            _check(out, ref, c0 + c1)
+    finally:
+        hip.tune("rconv_cb", 0)
 
 
 def test_rconv_routing_closed_form():
@@ -112,7 +123,7 @@ def test_rconv_zero_padding_after_the_activation():
     torch.testing.assert_close(out, ref.bfloat16().float(), rtol=2.0 ** -7, atol=0)
 
 
-@pytest.mark.parametrize("c0,c1,cout,H", [(320, 0, 320, 64), (640, 320, 320, 64), (640, 640, 640, 32)])
+@pytest.mark.parametrize("c0,c1,cout,H", [(320, 0, 320, 64), (640, 320, 320, 64), (640, 640, 640, 32), (1280, 0, 1280, 16)])
 def test_rconv_in_step_shapes_vs_two_launches_and_fp64(c0, c1, cout, H):
     """The in-step shapes (48 images) against fp64 AND against hip.groupnorm(silu) -> hip.conv3x3, the pair it replaces (the pair rounds the
     normalised tensor to bf16 at the same point; the table form x * scale + shift differs from ((x - mean) rstd) gamma + beta in the last
@@ -144,10 +155,12 @@ def test_rconv_in_step_shapes_vs_two_launches_and_fp64(c0, c1, cout, H):
         assert torch.equal(o2, out)
 
 
-def test_groupnorm_affine_two_sources():
-    """The statistics pass over a channel concatenation whose groups straddle the seam (1280 | 640 in 32 groups of 60) against fp64."""
+@pytest.mark.parametrize("HW", [1024, 256, 64])
+def test_groupnorm_affine_two_sources(HW):
+    """The statistics pass over a channel concatenation whose groups straddle the seam (1280 | 640 in 32 groups of 60) against fp64; 256 and 64
+    pixels: the small-image kernel's two passes with tables out."""
     from mmgt_amd import hip
-    nb, HW, c0, c1 = 3, 1024, 1280, 640
+    nb, c0, c1 = 3, 1280, 640
     g = torch.Generator(device="cpu").manual_seed(3)
     x0 = (torch.randn((nb, HW, c0), generator=g) * 1.3 + 4.0).to(dev()).bfloat16()
     x1 = (torch.randn((nb, HW, c1), generator=g) * 0.4 - 2.0).to(dev()).bfloat16()

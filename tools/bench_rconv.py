@@ -56,14 +56,19 @@ for nb, H, c0, c1, cout in SHAPES:
     out = torch.empty((nb, H, H, cout), device=dev, dtype=torch.bfloat16)
     t_gn = t_us(lambda: hip.groupnorm(v0, gamma, beta, 32, 1e-5, silu=True, x1=v1, out=hdn))
     t_cv = t_us(lambda: hip.conv3x3(hdn.view(nb, H, H, cin), wp, b, bias2=temb, bias2_rows=nb // 2 * H * H, residual=r, out=out))
-    if H * H > 256:
-        sc, sh = hip.groupnorm_affine(v0, gamma, beta, 32, 1e-5, x1=v1)
-        t_st = t_us(lambda: hip.groupnorm_affine(v0, gamma, beta, 32, 1e-5, x1=v1))
-    else:
-        tab = torch.rand((2, nb, cin), device=dev)
-        sc, sh, t_st = tab[0], tab[1], float("nan")
+    sc, sh = hip.groupnorm_affine(v0, gamma, beta, 32, 1e-5, x1=v1)
+    t_st = t_us(lambda: hip.groupnorm_affine(v0, gamma, beta, 32, 1e-5, x1=v1))
     t_f = t_us(lambda: hip.gn_silu_conv3x3_unet(x0, sc, sh, wimg, cout, b, temb, nb // 2, r, x1=x1, out=out))
     fl = 2.0 * nb * H * H * cout * 9 * cin
+    if os.environ.get("CB"):
+        row = []
+        for v in [int(x) for x in os.environ["CB"].split(",")]:
+            if v and cout % v:
+                continue
+            hip.tune("rconv_cb", v)
+            row.append(f"cb {v}: {t_us(lambda: hip.gn_silu_conv3x3_unet(x0, sc, sh, wimg, cout, b, temb, nb // 2, r, x1=x1, out=out)):7.1f}")
+        hip.tune("rconv_cb", 0)
+        print("    " + "  ".join(row))
     if os.environ.get("STAGGER"):
         row = []
         for v in [int(x) for x in os.environ["STAGGER"].split(",")]:

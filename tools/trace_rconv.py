@@ -24,6 +24,8 @@ tab = torch.rand((2, nb, cin), device=dev)
 r = torch.randn((nb, H, H, cout), device=dev).bfloat16()
 wimg = pack_rconv(w)
 out = torch.empty((nb, H, H, cout), device=dev, dtype=torch.bfloat16)
+if os.environ.get("CB"):
+    hip.tune("rconv_cb", int(os.environ["CB"]))
 run = lambda: hip.gn_silu_conv3x3_unet(x0, tab[0], tab[1], wimg, cout, None, None, 0, r, x1=x1, out=out)
 for _ in range(3):
     run()
@@ -51,3 +53,20 @@ for u in range(4):
     print("   k-step durations by index (first phase):", [round(float(x), 2) for x in m[:18]])
     print("   k-step durations by index (second phase):", [round(float(x), 2) for x in m[18:36]])
 print(" end spread:", float(t.max() - t0), "us")
+if os.environ.get("FINE"):
+    # four stamps per k-step: start | in front of the counted wait | in front of the barrier | behind the barrier
+    buf.zero_()
+    lib.mmgt_rconv_set_trace(ctypes.c_void_p(buf.data_ptr() | 1))
+    run()
+    torch.cuda.synchronize()
+    lib.mmgt_rconv_set_trace(None)
+    t = buf.cpu().double() * 0.01
+    nk = min(126, nph * 18)
+    q = t[:, :4 * nk].view(256, nk, 4)
+    nxt = t[:, 4:4 * nk + 4:4]
+    head, wait, barr, tail = q[:, :, 1] - q[:, :, 0], q[:, :, 2] - q[:, :, 1], q[:, :, 3] - q[:, :, 2], nxt - q[:, :, 3]
+    print(" fine stamps of the first", nk, "k-steps of unit 0, mean over workgroups, by k-step index inside the phase (phases 1.. averaged):")
+    for name, v in (("MFMA groups in front of the hand-over", head), ("counted wait", wait), ("barrier", barr), ("hand-over issue + rest of the k-step", tail)):
+        m = v.mean(0)[18:18 * (nk // 18)].view(-1, 18).mean(0)
+        print(f"   {name:40s}", [round(float(x), 2) for x in m], " sum", round(float(m.sum()), 2))
+
