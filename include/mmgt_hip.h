@@ -311,6 +311,17 @@ int mmgt_gn_stats_finalize(const float* stats, const float* gamma, const float* 
  * null (the time-embedding projection: image n takes row n / b2_imgs); residual / out (nb, H, W, Cout) bf16.  bf16 only; everything else runs
  * mmgt_groupnorm_nhwc -> mmgt_conv3x3_nhwc. */
 long mmgt_gn_silu_conv3x3_unet_image_bytes(int cin, int cout);
+/* ... with the statistics of the GroupNorm that reads `out` from the launch's epilogue (the next leg's norm2, resnet.py:231): `stats` (or NULL) receives
+ * [3][nb (H / 16) (W / 16) (16 / rows)][Cout] floats = (pivot, sum, sum of squares of the deviations from the pivot) of the bf16 values stored, per partial
+ * of rows x 16 pixels and channel; rows = mmgt_gn_silu_conv3x3_unet_stats_rows(nb, H, W, Cout) (4 or 2: the cut the launch takes for this shape).
+ * mmgt_gn_stats_finalize_unet combines the partials (Chan's pairwise update: no cancellation whatever the mean) into scale | shift (2, nb, C) of
+ * GroupNorm(G, gamma, beta, eps) over the stored tensor (count = 16 rows values per partial and channel): no statistics pass over the tensor. */
+int mmgt_gn_silu_conv3x3_unet_stats_rows(int nb, int H, int W, int cout);
+int mmgt_gn_silu_conv3x3_unet_stats(const void* x0, int C0, const void* x1, int C1, const float* scale_shift, const void* wimg, const float* bias,
+                                    const float* bias2, int b2_imgs, const void* residual, void* out, float* stats, int nb, int H, int W, int cout, int dtype,
+                                    void* stream);
+int mmgt_gn_stats_finalize_unet(const float* stats, const float* gamma, const float* beta, float* scale_shift, int nb, int parts_per_img, int count, int C,
+                                int G, float eps, void* stream);
 /* Debug (tools/trace_rconv.py): a device buffer of [workgroups][512] u64 receives 100-MHz stamps of the launches that follow; NULL = off. */
 void mmgt_rconv_set_trace(void* buf);
 int mmgt_gn_silu_conv3x3_unet(const void* x0, int C0, const void* x1, int C1, const float* scale_shift, const void* wimg, const float* bias,

@@ -57,6 +57,7 @@ struct RcArgs {
   const bf16_t* res;                    // (nb, H, W, Cout) or null
   bf16_t* out;                          // (nb, H, W, Cout)
   int nb, H, W, tiles_x, tiles_per_img, ncb, nunits, nph, cout;
+  float* stats;                         // or null: per (tile, wave row group, channel) the triple (pivot, sum, sum of squares of deviations) of the STORED values: [3][partials][cout]
   unsigned long long* trace;            // debug: [workgroup][512] 100-MHz stamps of wave 0 (k-step starts; 2 per epilogue), or null
   int trace_fine;                       // debug: four stamps per k-step (start, in front of the counted wait, in front of / behind the barrier)
   int stagger;                          // start delay of workgroup group (blockIdx.x >> 3) & 7, in units of 64 cycles per group index
@@ -118,11 +119,15 @@ template <int NT, int RT> struct RcCfg {
   static_assert(LDS <= 160 * 1024 && NSLOT >= 3 && NW * PPW == NPC && NT % 2 == 0 && NT >= RC_FWD + 2 && (RC_NSTEP * NT) % RC_FWD == 0 && (RT == 2 || RT == 4), "LDS / shape");
 };
 
-template <int NT, int RT, bool RES>
+// ST: the epilogue also emits the statistics of the GroupNorm that reads this launch's output (the next leg's norm2, resnet.py:231): per partial
+// = (tile, wave row group: RT image rows x 16 pixels) and channel the pivot-shifted sums of the bf16 values it stores, folded over the partial's
+// pixels in a fixed order; mmgt_gn_stats_finalize_unet combines the partials (Chan's update: no cancellation whatever the mean) into the
+// (scale, shift) tables -- the statistics pass over the tensor is not needed.
+template <int NT, int RT, bool RES, bool ST = false>
 __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
   using Cfg = RcCfg<NT, RT>;
   constexpr int CB = Cfg::CB, SLOT = Cfg::SLOT, NW = Cfg::NW, PPW = Cfg::PPW, NSLOT = Cfg::NSLOT, WN = Cfg::WN;
-  constexpr int NPAIR = NT / 2, NST = RT * NPAIR;                           // tile pairs; 16-byte stores per wave and unit
+  constexpr int NPAIR = NT / 2, NST = RT * NPAIR + (ST ? 6 * NPAIR : 0);      // tile pairs; 16-byte stores per wave and unit (ST: + 6 per pair)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lm = lane & 15, lq = lane >> 4;
@@ -438,6 +443,87 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
       const int cofs = cb * CB + wn * NT * 16 + 16 * (lqe & 1) + 8 * (lqe >> 1);
       const unsigned eoff = (unsigned)((((n * a.H + ty * RC_T + RT * wm) * a.W + tx * RC_T + lme) * a.cout + cofs) * 2);   // byte offset of (row 0, pair 0)
       const int erow = a.W * a.cout * 2;                      // bytes per image row
+      auto out8 = [&](auto ic, auto jpc, const u32x4& rvv) {   // the lane's 8 output channels of image row i, tile pair jp, rounded and packed
+        constexpr int i = decltype(ic)::value, jp = decltype(jpc)::value;
+        const acc4 x = rc_get<(2 * jp < 8)>(acc[i][2 * jp]), y = rc_get<(2 * jp + 1 < 8)>(acc[i][2 * jp + 1]);
+        if constexpr (!RES) {
+          const auto s01 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[0], x[1]), pack_bf16x2(y[0], y[1]), false, false);
+          const auto s23 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[2], x[3]), pack_bf16x2(y[2], y[3]), false, false);
+          return (u32x4){s01[0], s23[0], s01[1], s23[1]};
+        } else {
+          float o8[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[r]), __float_as_uint(y[r]), false, false);
+            o8[r] = __uint_as_float(sw[0]);
+            o8[4 + r] = __uint_as_float(sw[1]);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o8[2 * e] += rc_lo(rvv[e]);
+            o8[2 * e + 1] += rc_hi(rvv[e]);
+          }
+          return (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])};
+        }
+      };
+      if constexpr (ST) {
+        // pair-major: a tile pair's 8 channels x RT rows are tallied in 16 registers, folded over the 16 pixels of the row tiles by four DPP steps
+        // (fixed order) and written by lane lm = 0 of each lq; the pivot of a channel is the value of (row 0, pixel 0) of the partial
+        const __amdgpu_buffer_rsrc_t rS = dma_rsrc(a.stats);
+        const int part = ((n * a.tiles_per_img + ty * a.tiles_x + tx) * (RC_T / RT) + wm);
+        const int nparts = a.nb * a.tiles_per_img * (RC_T / RT);
+        u32x4 rv[2][RES ? RT : 1];
+        if constexpr (RES) {
+#pragma unroll
+          for (int i = 0; i < RT; ++i) rv[0][i] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)eoff + i * erow, 0, 0);
+        }
+        rc_for<0, NPAIR>([&](auto jpc) {
+          constexpr int jp = decltype(jpc)::value;
+          if constexpr (RES && jp + 1 < NPAIR) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) rv[(jp + 1) & 1][i] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)eoff + i * erow + 64 * (jp + 1), 0, 0);
+          }
+          float piv[8], s1[8], s2[8];
+          rc_for<0, RT>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            const u32x4 pk = out8(ic, jpc, rv[jp & 1][RES ? i : 0]);
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rO, (int)eoff + i * erow + 64 * jp, 0, 0);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] = rc_lo(pk[e]); v[2 * e + 1] = rc_hi(pk[e]); }
+            if constexpr (i == 0) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                piv[e] = __uint_as_float((unsigned)__builtin_amdgcn_ds_bpermute((lne & 48) << 2, (int)__float_as_uint(v[e])));   // pixel 0 of the row tile
+                s1[e] = 0.f;
+                s2[e] = 0.f;
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[e] - piv[e]; s1[e] += d; s2[e] = fmaf(d, d, s2[e]); }
+          });
+          auto fold16 = [](float v) {                        // sum over the 16 lanes of a DPP row, fixed order (quad, quad pairs, halves, row)
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+            return v;
+          };
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s1[e] = fold16(s1[e]); s2[e] = fold16(s2[e]); }
+          // lane lm = 0 of each lq: [3][partials][cout] floats, 8 consecutive channels of each array = two 16-byte stores
+          // (the array offset rides in the VECTOR offset too: no register in soffset -- the store-data hazard of csrc/gnconv.hip)
+          const unsigned soff = (unsigned)((part * a.cout + cofs + 32 * jp) * 4), arr = (unsigned)(nparts * a.cout * 4);
+          const unsigned vo0 = lme == 0 ? soff : DMA_POISON, vo1 = lme == 0 ? soff + arr : DMA_POISON, vo2 = lme == 0 ? soff + 2 * arr : DMA_POISON;   // (out of range: dropped)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(piv[4 * h]), __float_as_uint(piv[4 * h + 1]), __float_as_uint(piv[4 * h + 2]), __float_as_uint(piv[4 * h + 3])}, rS, (int)vo0 + 16 * h, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(s1[4 * h]), __float_as_uint(s1[4 * h + 1]), __float_as_uint(s1[4 * h + 2]), __float_as_uint(s1[4 * h + 3])}, rS, (int)vo1 + 16 * h, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(s2[4 * h]), __float_as_uint(s2[4 * h + 1]), __float_as_uint(s2[4 * h + 2]), __float_as_uint(s2[4 * h + 3])}, rS, (int)vo2 + 16 * h, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      } else {
       u32x4 rv[2][RES ? NPAIR : 1];                           // residual vectors, one image row ahead of their use (one at a time: 0.8 us of latency each, 16 us per unit)
       if constexpr (RES) {
 #pragma unroll
@@ -449,31 +535,12 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
 #pragma unroll
           for (int j2 = 0; j2 < NPAIR; ++j2) rv[(i + 1) & 1][j2] = __builtin_amdgcn_raw_buffer_load_b128(rR, (int)eoff + (i + 1) * erow + 64 * j2, 0, 0);
         }
-        const acc4 x = rc_get<(2 * jp < 8)>(acc[i][2 * jp]), y = rc_get<(2 * jp + 1 < 8)>(acc[i][2 * jp + 1]);
-        u32x4 pk;
-        if constexpr (!RES) {
-          const auto s01 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[0], x[1]), pack_bf16x2(y[0], y[1]), false, false);
-          const auto s23 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[2], x[3]), pack_bf16x2(y[2], y[3]), false, false);
-          pk = (u32x4){s01[0], s23[0], s01[1], s23[1]};
-        } else {
-          float o8[8];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[r]), __float_as_uint(y[r]), false, false);
-            o8[r] = __uint_as_float(sw[0]);
-            o8[4 + r] = __uint_as_float(sw[1]);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o8[2 * e] += rc_lo(rv[i & 1][jp][e]);
-            o8[2 * e + 1] += rc_hi(rv[i & 1][jp][e]);
-          }
-          pk = (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])};
-        }
+        const u32x4 pk = out8(std::integral_constant<int, i>{}, std::integral_constant<int, jp>{}, rv[i & 1][RES ? jp : 0]);
         // (the row offset rides in the VECTOR offset, not in soffset: see csrc/gnconv.hip -- the store-data hazard tools/check_mfma_overlap.py scans for)
         if (!(abl & 16) || pk[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(pk, rO, (int)eoff + i * erow + 64 * jp, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       });
+      }
       // the next unit's first fragments (its halo and its first k-step are in LDS behind the barrier of k-step 17)
       if (has_next) {
         rc_for<0, RT>([&](auto ic) { fa[decltype(ic)::value] = read_a1(nbuf, std::integral_constant<int, 0>{}, ic); });
@@ -491,6 +558,51 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
   wait_vmcnt<0>();                                           // (the poison pieces write LDS: none may be in flight when the workgroup's LDS is released)
 }
 
+// The tables of a GroupNorm from the partials of the launch that produced its input: stats [3][parts][C] = (pivot, sum, sum of squares) of the
+// deviations from the pivot over `cnt` values per (partial, channel).  One workgroup per image; thread (group g, run r of 256 / G) folds the partials
+// r, r + runs, ... of its group's channels with Chan's pairwise update -- mean and M2 of a union from the means and M2s of its parts, every term of
+// the order of the variance --, then the runs are folded in a fixed order.  Bitwise reproducible.
+__global__ __launch_bounds__(256) void rconv_stats_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float* __restrict__ scale, float* __restrict__ shift, int nb, int ppi, int C, int G, float cnt,
+                                                                   float eps) {
+  __shared__ float pn[8][64], pm[8][64], pq[8][64];
+  const int n = blockIdx.x, g = threadIdx.x % G, run = threadIdx.x / G, nrun = 256 / G, cpg = C / G;
+  const long arr = (long)nb * ppi * C;
+  float cn = 0.f, cm = 0.f, cq = 0.f;                      // count, mean, sum of squared deviations from the mean
+  const float icnt = 1.f / cnt;
+  for (int p = run; p < ppi; p += nrun) {
+    const float* b = stats + ((long)n * ppi + p) * C + g * cpg;
+    for (int k = 0; k < cpg; ++k) {
+      const float s1 = b[arr + k], mb = b[k] + s1 * icnt, qb = fmaxf(b[2 * arr + k] - s1 * s1 * icnt, 0.f);
+      const float tot = cn + cnt, d = mb - cm, f = cnt / tot;
+      cm = fmaf(d, f, cm);
+      cq += qb + d * d * cn * f;
+      cn = tot;
+    }
+  }
+  pn[run][g] = cn;
+  pm[run][g] = cm;
+  pq[run][g] = cq;
+  __syncthreads();
+  if (run == 0) {
+    for (int r = 1; r < nrun; ++r) {
+      const float nb_ = pn[r][g];
+      if (nb_ > 0.f) {
+        const float tot = cn + nb_, d = pm[r][g] - cm, f = nb_ / tot;
+        cm = fmaf(d, f, cm);
+        cq += pq[r][g] + d * d * cn * f;
+        cn = tot;
+      }
+    }
+    const float rstd = rsqrtf(cq / cn + eps);
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      const float sc = gamma[c] * rstd;
+      scale[(long)n * C + c] = sc;
+      shift[(long)n * C + c] = fmaf(-cm, sc, beta[c]);
+    }
+  }
+}
+
 int g_rconv_abl = 0, g_rconv_stagger = 0, g_rconv_cb = 0;
 unsigned long long* g_rconv_trace = nullptr;
 int g_rconv_fine = 0;                  // (mmgt_rconv_set_trace(buf | 1): four stamps per k-step)
@@ -505,9 +617,46 @@ extern "C" void mmgt_rconv_set_trace(void* p) { g_rconv_trace = reinterpret_cast
 // x0 (nb, H, W, C0) [+ x1 (nb, H, W, C1)] bf16 channels-last, H and W multiples of 16; scale | shift (2, nb, C0 + C1) fp32 in one allocation;
 // wimg = pack_rconv image of the (Cout, C0 + C1, 3, 3) weight; bias (Cout) / bias2 (rows, Cout) fp32 or null, image n takes row n / b2_imgs;
 // residual / out (nb, H, W, Cout) bf16.  C0, C1 multiples of 64, Cout a multiple of 160.
-extern "C" int mmgt_gn_silu_conv3x3_unet(const void* x0, int C0, const void* x1, int C1, const float* scale_shift, const void* wimg, const float* bias,
-                                         const float* bias2, int b2_imgs, const void* residual, void* out, int nb, int H, int W, int cout, int dtype,
-                                         void* stream) {
+namespace {
+// the cut (block width) of a launch: the one that needs the fewest rounds of the persistent grid, weighted by what a unit costs -- its MFMA work grows
+// with CB, its halo traffic, normalisation and epilogue hand-over do not (the 40).  mmgt_tune("rconv_cb", 320 | 256 | 160) forces one.
+int rconv_cut(int nb, int H, int W, int cout, int cus) {
+  const int tiles = nb * (H / RC_T) * (W / RC_T);
+  int cb = 0;
+  long best = 0;
+  for (int c : {320, 256, 160}) {
+    if (cout % c || (g_rconv_cb && g_rconv_cb != c)) continue;
+    const long units = (long)tiles * (cout / c), score = (units + cus - 1) / cus * (c + 40);
+    if (!cb || score < best) { cb = c; best = score; }
+  }
+  return cb;
+}
+int rconv_cus(int* out) {
+  int dev = 0;
+  static int ncu[16] = {};
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -1;
+  if (!ncu[dev]) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+    ncu[dev] = prop.multiProcessorCount;
+  }
+  *out = ncu[dev] / 8 * 8;
+  return dev;
+}
+}  // namespace
+
+// The image rows per statistics partial (4 or 2) of the cut mmgt_gn_silu_conv3x3_unet_stats will take for this shape: its `stats` buffer holds
+// 3 * nb * (H / 16) * (W / 16) * (16 / rows) * Cout floats.
+extern "C" int mmgt_gn_silu_conv3x3_unet_stats_rows(int nb, int H, int W, int cout) {
+  int cus = 0;
+  if (rconv_cus(&cus) < 0 || nb <= 0 || H <= 0 || W <= 0 || H % RC_T || W % RC_T) return -1;
+  const int cb = rconv_cut(nb, H, W, cout, cus);
+  return cb == 0 ? -1 : cb == 160 ? 2 : 4;
+}
+
+extern "C" int mmgt_gn_silu_conv3x3_unet_stats(const void* x0, int C0, const void* x1, int C1, const float* scale_shift, const void* wimg, const float* bias,
+                                               const float* bias2, int b2_imgs, const void* residual, void* out, float* stats, int nb, int H, int W, int cout,
+                                               int dtype, void* stream) {
   MMGT_CHECK(x0 && scale_shift && wimg && out && nb > 0 && H > 0 && W > 0, "gn_silu_conv3x3_unet: bad arguments");
   MMGT_CHECK(dtype == MMGT_BF16, "gn_silu_conv3x3_unet: bf16 only (the fp32-I/O mode runs GroupNorm / conv)");
   MMGT_CHECK((x1 != nullptr) == (C1 > 0) && C0 > 0 && C0 % RC_PC == 0 && C1 % RC_PC == 0, "gn_silu_conv3x3_unet: C0 = %d, C1 = %d must be multiples of %d", C0, C1, RC_PC);
@@ -543,30 +692,19 @@ extern "C" int mmgt_gn_silu_conv3x3_unet(const void* x0, int C0, const void* x1,
   a.stagger = g_rconv_stagger;
   a.trace = g_rconv_trace;
   a.trace_fine = g_rconv_fine;
-  int dev = 0;
-  static int ncu[16] = {};
-  MMGT_CHECK(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16, "gn_silu_conv3x3_unet: device query failed");
-  if (!ncu[dev]) {
-    hipDeviceProp_t prop;
-    MMGT_CHECK(hipGetDeviceProperties(&prop, dev) == hipSuccess, "gn_silu_conv3x3_unet: device query failed");
-    ncu[dev] = prop.multiProcessorCount;
-  }
-  // The cut (block width) that needs the fewest rounds of the persistent grid, weighted by what a unit costs: its MFMA work grows with CB, its halo
-  // traffic, normalisation and epilogue hand-over do not (the 40).  mmgt_tune("rconv_cb", 320 | 256 | 160) forces one.
-  const int tiles = nb * (H / RC_T) * (W / RC_T), cus = ncu[dev] / 8 * 8;
-  int cb = 0;
-  long best = 0;
-  for (int c : {320, 256, 160}) {
-    if (cout % c || (g_rconv_cb && g_rconv_cb != c)) continue;
-    const long units = (long)tiles * (cout / c), score = (units + cus - 1) / cus * (c + 40);
-    if (!cb || score < best) { cb = c; best = score; }
-  }
+  int cus = 0;
+  const int dev = rconv_cus(&cus);
+  MMGT_CHECK(dev >= 0, "gn_silu_conv3x3_unet: device query failed");
+  MMGT_CHECK(!stats || ((uintptr_t)stats % 16) == 0, "gn_silu_conv3x3_unet: stats must be 16-byte aligned");
+  a.stats = stats;
+  const int tiles = nb * (H / RC_T) * (W / RC_T);
+  const int cb = rconv_cut(nb, H, W, cout, cus);
   MMGT_CHECK(cb, "gn_silu_conv3x3_unet: no block width for Cout = %d (rconv_cb = %d)", cout, g_rconv_cb);
   a.ncb = cout / cb;
   a.nunits = tiles * a.ncb;
   int gx = cus;
   if (gx > a.nunits) gx = a.nunits;
-  static bool ready[16][6] = {};
+  static bool ready[16][12] = {};
   auto go = [&](void (*kern)(const RcArgs), int lds, int slot) -> int {
     if (!ready[dev][slot]) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -578,11 +716,34 @@ extern "C" int mmgt_gn_silu_conv3x3_unet(const void* x0, int C0, const void* x1,
     hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, (hipStream_t)stream, a);
     return 0;
   };
+  MMGT_CHECK(!stats || 3l * tiles * (RC_T / (cb == 160 ? 2 : 4)) * cout * 4 < (1l << 31), "gn_silu_conv3x3_unet: statistics buffer beyond 2 GiB");
   int rc;
-  if (cb == 320) rc = residual ? go(rconv_kernel<10, 4, true>, RcCfg<10, 4>::LDS, 1) : go(rconv_kernel<10, 4, false>, RcCfg<10, 4>::LDS, 0);
+  if (stats) {
+    if (cb == 320) rc = residual ? go(rconv_kernel<10, 4, true, true>, RcCfg<10, 4>::LDS, 7) : go(rconv_kernel<10, 4, false, true>, RcCfg<10, 4>::LDS, 6);
+    else if (cb == 256) rc = residual ? go(rconv_kernel<8, 4, true, true>, RcCfg<8, 4>::LDS, 9) : go(rconv_kernel<8, 4, false, true>, RcCfg<8, 4>::LDS, 8);
+    else rc = residual ? go(rconv_kernel<10, 2, true, true>, RcCfg<10, 2>::LDS, 11) : go(rconv_kernel<10, 2, false, true>, RcCfg<10, 2>::LDS, 10);
+  } else if (cb == 320) rc = residual ? go(rconv_kernel<10, 4, true>, RcCfg<10, 4>::LDS, 1) : go(rconv_kernel<10, 4, false>, RcCfg<10, 4>::LDS, 0);
   else if (cb == 256) rc = residual ? go(rconv_kernel<8, 4, true>, RcCfg<8, 4>::LDS, 3) : go(rconv_kernel<8, 4, false>, RcCfg<8, 4>::LDS, 2);
   else rc = residual ? go(rconv_kernel<10, 2, true>, RcCfg<10, 2>::LDS, 5) : go(rconv_kernel<10, 2, false>, RcCfg<10, 2>::LDS, 4);
   if (rc) return rc;
+  MMGT_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmgt_gn_silu_conv3x3_unet(const void* x0, int C0, const void* x1, int C1, const float* scale_shift, const void* wimg, const float* bias,
+                                         const float* bias2, int b2_imgs, const void* residual, void* out, int nb, int H, int W, int cout, int dtype,
+                                         void* stream) {
+  return mmgt_gn_silu_conv3x3_unet_stats(x0, C0, x1, C1, scale_shift, wimg, bias, bias2, b2_imgs, residual, out, nullptr, nb, H, W, cout, dtype, stream);
+}
+
+// stats [3][nb * parts_per_img][C] as written by mmgt_gn_silu_conv3x3_unet_stats (parts_per_img = (H / 16) (W / 16) (16 / rows), `count` = 16 rows values
+// per partial and channel) -> scale | shift (2, nb, C) of GroupNorm(G groups, gamma, beta, eps) over the stored tensor.  G <= 64 and a divisor of 256.
+extern "C" int mmgt_gn_stats_finalize_unet(const float* stats, const float* gamma, const float* beta, float* scale_shift, int nb, int parts_per_img, int count,
+                                           int C, int G, float eps, void* stream) {
+  MMGT_CHECK(stats && gamma && beta && scale_shift && nb > 0 && parts_per_img > 0 && count > 0, "gn_stats_finalize_unet: bad arguments");
+  MMGT_CHECK(G > 0 && G <= 64 && 256 % G == 0 && C % G == 0, "gn_stats_finalize_unet: unsupported C = %d, G = %d", C, G);
+  hipLaunchKernelGGL(rconv_stats_finalize_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta, scale_shift, scale_shift + (long)nb * C, nb,
+                     parts_per_img, C, G, (float)count, eps);
   MMGT_LAUNCH_CHECK();
   return 0;
 }

@@ -73,6 +73,10 @@ _SIGS = {
     "mmgt_gn_silu_conv3x3_unet_image_bytes": (c_long, [c_int, c_int]),
     "mmgt_gn_silu_conv3x3_unet": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                           c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_gn_silu_conv3x3_unet_stats_rows": (c_int, [c_int, c_int, c_int, c_int]),
+    "mmgt_gn_silu_conv3x3_unet_stats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                                c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmgt_gn_stats_finalize_unet": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "mmgt_groupnorm_affine2": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                        c_float, c_int, c_void_p]),
     "mmgt_gn_stats_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
@@ -363,9 +367,11 @@ def gn_silu_conv3x3_unet_supported(dtype, c0, c1, cout, H, W):
     return dtype == torch.bfloat16 and c0 % 64 == 0 and c1 % 64 == 0 and c0 > 0 and cout % 160 == 0 and H % 16 == 0 and W % 16 == 0
 
 
-def gn_silu_conv3x3_unet(x, scale, shift, wimg, cout, bias=None, bias2=None, b2_imgs=0, residual=None, x1=None, out=None):
+def gn_silu_conv3x3_unet(x, scale, shift, wimg, cout, bias=None, bias2=None, b2_imgs=0, residual=None, x1=None, out=None, next_norm=None):
     """bias + bias2[n // b2_imgs] + conv3x3(silu((x | x1) * scale[n, c] + shift[n, c])) (+ residual) in one launch (csrc/rconv.hip): x (NB, H, W, C0)
-    [, x1 (NB, H, W, C1)] bf16 channels-last, (scale, shift) the tables of `groupnorm_affine` (one allocation), wimg = packing.pack_rconv(weight)."""
+    [, x1 (NB, H, W, C1)] bf16 channels-last, (scale, shift) the tables of `groupnorm_affine` (one allocation), wimg = packing.pack_rconv(weight).
+    next_norm = (gamma, beta, groups, eps) of the GroupNorm that reads the result: returns (out, (scale, shift) of THAT norm) -- its statistics
+    come from the launch's epilogue and a small fold (mmgt_gn_stats_finalize_unet), the pass over the tensor is not needed."""
     _dev(x, scale, shift, wimg, bias, bias2, residual, x1, out)
     assert x.dim() == 4 and x.is_contiguous()
     NB, H, W, C0 = x.shape
@@ -385,10 +391,22 @@ def gn_silu_conv3x3_unet(x, scale, shift, wimg, cout, bias=None, bias2=None, b2_
         assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x.dtype
     if bias2 is not None:
         assert bias2.dim() == 2 and bias2.shape[1] == cout and bias2.is_contiguous() and b2_imgs > 0 and (NB + b2_imgs - 1) // b2_imgs <= bias2.shape[0]
-    _check(lib().mmgt_gn_silu_conv3x3_unet(_ptr(x), C0, _ptr(x1), C1, _ptr(scale), _ptr(wimg), _ptr(_f32(bias, "bias")), _ptr(_f32(bias2, "bias2")),
-                                           b2_imgs, _ptr(residual), _ptr(out), NB, H, W, cout, dtype_code(x.dtype), _stream()),
+    stats = None
+    if next_norm is not None:
+        rows = lib().mmgt_gn_silu_conv3x3_unet_stats_rows(NB, H, W, cout)
+        assert rows in (2, 4)
+        ppi = (H // 16) * (W // 16) * (16 // rows)
+        stats = torch.empty((3, NB * ppi, cout), device=x.device, dtype=torch.float32)
+    _check(lib().mmgt_gn_silu_conv3x3_unet_stats(_ptr(x), C0, _ptr(x1), C1, _ptr(scale), _ptr(wimg), _ptr(_f32(bias, "bias")), _ptr(_f32(bias2, "bias2")),
+                                                 b2_imgs, _ptr(residual), _ptr(out), _ptr(stats), NB, H, W, cout, dtype_code(x.dtype), _stream()),
            "mmgt_gn_silu_conv3x3_unet")
-    return out
+    if next_norm is None:
+        return out
+    gamma, beta, groups, eps = next_norm
+    tab = torch.empty((2, NB, cout), device=x.device, dtype=torch.float32)
+    _check(lib().mmgt_gn_stats_finalize_unet(_ptr(stats), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")), _ptr(tab), NB, ppi, 16 * rows, cout, groups,
+                                             eps, _stream()), "mmgt_gn_stats_finalize_unet")
+    return out, (tab[0], tab[1])
 
 
 def gn_silu_conv3x3_supported(dtype, cin, cout, H, W, residual=False):

@@ -121,6 +121,7 @@ class UNet3DConditionModel:
         self._fuse_oz = bool(hip.tune_get("oz3"))                 # 0: the three masked audio out-projections as separate launches
         self._fuse_ln = bool(hip.tune_get("rowgemm"))             # 0: LayerNorm and q / k / v GEMMs as separate launches
         self._fuse_tleg = bool(hip.tune_get("tleg"))              # 0: a level-0 temporal-attention leg as three launches
+        self._rconv_stats = bool(hip.tune_get("rconv_stats"))     # a fused leg's output statistics from its epilogue instead of a pass over the tensor
         self._rconv = hip.tune_get("rconv")                        # resnets whose GroupNorm -> SiLU -> conv3x3 legs run as one launch (csrc/rconv.hip): 0 none,
                                                                    # 1 the 320-wide level, 2 + the 640-wide level, 3 every level with 16 x 16 tiles
         self.spec = unet3d_spec(boc, cfg["cross_attention_dim"], cfg["audio_attention_dim"], self.in_channels,
@@ -522,8 +523,12 @@ class UNet3DConditionModel:
             eps = self.config.norm_eps
             sc, sh = hip.groupnorm_affine(x.view(nb, hw, c0), self.w[p + ".norm1.g"], self.w[p + ".norm1.b"], 32, eps,
                                           x1=None if skip is None else skip.view(nb, hw, c1))
-            hdn = hip.gn_silu_conv3x3_unet(x, sc, sh, self.w[p + ".conv1.rimg"], cout, self.w[p + ".conv1.bias"], temb[p], nb // temb[p].shape[0], x1=skip)
-            sc, sh = hip.groupnorm_affine(hdn.view(nb, hw, cout), self.w[p + ".norm2.g"], self.w[p + ".norm2.b"], 32, eps)
+            if self._rconv_stats:       # norm2's statistics from conv1's epilogue (resnet.py:231): no pass over the tensor
+                hdn, (sc, sh) = hip.gn_silu_conv3x3_unet(x, sc, sh, self.w[p + ".conv1.rimg"], cout, self.w[p + ".conv1.bias"], temb[p], nb // temb[p].shape[0],
+                                                         x1=skip, next_norm=(self.w[p + ".norm2.g"], self.w[p + ".norm2.b"], 32, eps))
+            else:
+                hdn = hip.gn_silu_conv3x3_unet(x, sc, sh, self.w[p + ".conv1.rimg"], cout, self.w[p + ".conv1.bias"], temb[p], nb // temb[p].shape[0], x1=skip)
+                sc, sh = hip.groupnorm_affine(hdn.view(nb, hw, cout), self.w[p + ".norm2.g"], self.w[p + ".norm2.b"], 32, eps)
         else:
             hdn = self._gn(p + ".norm1", x, self.config.norm_eps, silu=True, x1=skip)
             b2rows = (nb // temb[p].shape[0]) * hw

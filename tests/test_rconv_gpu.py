@@ -174,6 +174,46 @@ def test_groupnorm_affine_two_sources(HW):
     torch.testing.assert_close(sh.double().view(nb, 32, -1), want_sh, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("nb,H,c0,c1,cout,res,mean", [(48, 64, 320, 0, 320, False, 0.0), (48, 32, 640, 320, 640, True, 2.0), (48, 16, 1280, 0, 1280, False, 0.5),
+                                                      (24, 64, 320, 0, 320, True, 40.0), (4, 32, 320, 0, 320, False, -3.0)])
+def test_rconv_statistics_of_the_output(nb, H, c0, c1, cout, res, mean):
+    """The next GroupNorm's tables from the launch's epilogue (pivot-shifted partials per tile / wave row group / channel, folded by
+    mmgt_gn_stats_finalize_unet with Chan's update) against the statistics pass over the stored tensor and against fp64 -- also for an output whose
+    mean is 40 sigma (a conv bias of 40: an unshifted E[x^2] - mean^2 in fp32 would keep ~3 digits); bitwise repeatable; the output itself is the
+    launch's without statistics; every cut of the workgroup."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_rconv
+    W = H
+    x0, x1, w, b, temb, r, scale, shift = _case(nb, H, W, c0, c1, cout, 500 + nb + cout, res=res, temb_rows=2)
+    b = b + mean
+    g = torch.Generator(device="cpu").manual_seed(9)
+    gamma, beta = (0.5 + torch.rand(cout, generator=g)).to(dev()), (torch.rand(cout, generator=g) - 0.5).to(dev())
+    wimg = pack_rconv(w)
+    try:
+        for cb in (0, 320, 256, 160):
+            if cb and cout % cb:
+                continue
+            hip.tune("rconv_cb", cb)
+            out, (sc, sh) = hip.gn_silu_conv3x3_unet(x0, scale, shift, wimg, cout, b, temb, nb // 2, r, x1=x1, next_norm=(gamma, beta, 32, 1e-5))
+            assert torch.equal(out, hip.gn_silu_conv3x3_unet(x0, scale, shift, wimg, cout, b, temb, nb // 2, r, x1=x1))
+            sc2, sh2 = hip.groupnorm_affine(out.view(nb, H * W, cout), gamma, beta, 32, 1e-5)
+            o = out.double().view(nb, H * W, 32, cout // 32)
+            mu, var = o.mean(dim=(1, 3)), o.var(dim=(1, 3), unbiased=False)
+            want_sc = gamma.double().view(1, 32, -1) * (var + 1e-5).rsqrt()[:, :, None]
+            want_sh = beta.double().view(1, 32, -1) - mu[:, :, None] * want_sc
+            # the error a consumer sees on a normalised value at |x - mean| = sigma, in units of sigma (its own bf16 rounding: 4e-3)
+            xs = mu[:, :, None] + var.sqrt()[:, :, None]
+            for name, (a_, b_) in (("epilogue", (sc, sh)), ("pass", (sc2, sh2))):
+                e_sc = ((a_.double().view(nb, 32, -1) - want_sc) / want_sc).abs().max().item()
+                ey = ((xs * a_.double().view(nb, 32, -1) + b_.double().view(nb, 32, -1) - (xs * want_sc + want_sh)).abs() / gamma.double().view(1, 32, -1)).max().item()
+                print(f"cb {cb} |mean| / sigma {(mu.abs() / var.sqrt()).mean().item():.1f}: tables from the {name}: relative scale error {e_sc:.2e}, normalised-value error {ey:.2e} sigma")
+                assert e_sc < 1e-4 and ey < 2e-4, (name, e_sc, ey)
+            out2, (sc3, sh3) = hip.gn_silu_conv3x3_unet(x0, scale, shift, wimg, cout, b, temb, nb // 2, r, x1=x1, next_norm=(gamma, beta, 32, 1e-5))
+            assert torch.equal(sc, sc3) and torch.equal(sh, sh3) and torch.equal(out, out2)
+    finally:
+        hip.tune("rconv_cb", 0)
+
+
 def test_rconv_rejects_unsupported():
     from mmgt_amd import hip
     assert not hip.gn_silu_conv3x3_unet_supported(torch.float32, 320, 0, 320, 64, 64)

@@ -60,6 +60,12 @@ for nb, H, c0, c1, cout in SHAPES:
     t_st = t_us(lambda: hip.groupnorm_affine(v0, gamma, beta, 32, 1e-5, x1=v1))
     t_f = t_us(lambda: hip.gn_silu_conv3x3_unet(x0, sc, sh, wimg, cout, b, temb, nb // 2, r, x1=x1, out=out))
     fl = 2.0 * nb * H * H * cout * 9 * cin
+    if os.environ.get("ST"):
+        g2, b2 = torch.rand(cout).to(dev) + 0.5, torch.rand(cout).to(dev) - 0.5
+        t_a = t_us(lambda: hip.gn_silu_conv3x3_unet(x0, sc, sh, wimg, cout, b, temb, nb // 2, r, x1=x1, out=out))
+        t_p = t_us(lambda: hip.groupnorm_affine(out.view(nb, H * H, cout), g2, b2, 32, 1e-5))
+        t_s = t_us(lambda: hip.gn_silu_conv3x3_unet(x0, sc, sh, wimg, cout, b, temb, nb // 2, r, x1=x1, out=out, next_norm=(g2, b2, 32, 1e-5)))
+        print(f"    launch {t_a:7.1f} + statistics pass over its output {t_p:6.1f} = {t_a + t_p:7.1f}   |   launch with epilogue statistics + fold {t_s:7.1f}")
     if os.environ.get("CB"):
         row = []
         for v in [int(x) for x in os.environ["CB"].split(",")]:
