@@ -43,6 +43,8 @@ const char* mmgt_last_error(void);
  *                20 = its 256 x 128 tile: measured slower than the 128 x 128 tile everywhere, kept for the record);
  *   "bm192"    = 1 (default) / 0: the 192-row gemm16 tile for shapes whose 256-row tile count leaves the last round of the grid half empty;
  *   "attn64"   = 1 (default) / 0: the 64-queries-per-wave spatial attention kernel at head_dim 40;
+ *   "attn_nomax" = 1 (default) / 0: that kernel without the running maximum (the softmax reference stays what a row's first 32 keys set it to; a
+ *                workgroup in which a denominator ends beyond 2^100 runs its tile loop again with the running maximum: csrc/attn64.hip);
  *   "gn_rows"  = 0 (default: measured choice) or the GroupNorm rows per workgroup;
  *   "splitk"   = 1 (default) / 0: split-K of long reductions on grids of at most half a tile per CU (the 8x8-level convs);
  *   "ffn_dbg", "tleg_abl", "gnconv_abl", "rowgemm_dbg" 1 .. 4: timing ablations whose RESULTS ARE GARBAGE.  The product library does not

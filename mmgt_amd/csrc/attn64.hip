@@ -7,6 +7,8 @@
 // are independent (one block's exponentials issue beside the other's MFMAs).  The price is two waves per SIMD instead of three (o and
 // s for two blocks: 128 registers).  Dispatched for whole-tile key sets with nq % 256 == 0.  The phased (round 2) and software-
 // pipelined register-staged (round 4) predecessors are kept as records in tools/micro/attn64_variants.hip.
+#include <type_traits>
+
 #include "common.h"
 #include "gemm_common.h"
 #include "attn_common.h"
@@ -36,9 +38,16 @@ constexpr int SLOT_K = KT * HD * 2, SLOT_V = HD * KT * 2, SLOT_CONST = SLOT_K + 
 
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 #define PIN(x) asm volatile("" : "+v"(x))
+// FAST: no running maximum.  The softmax reference of a query row stays what the first 32 keys set it to: any reference gives the same quotient
+// sum(p v) / sum(p) as long as no p = 2^(s - reference) overflows (fp32 and bf16 share the exponent range, so a large p loses no relative
+// precision), and the per-tile maxima, the lazy-rescale test and the reference update -- 22 of the ~74 vector instructions of a 32 x 64 block in a
+// kernel that is bound by vector issue -- are not computed at all.  The guard: when a row's denominator ends beyond 2^100 (or not finite),
+// the WORKGROUP runs the tile loop again with the running maximum (uniform decision through LDS): results are then bitwise those of FAST = false.
+template <bool FAST>
 __global__ __launch_bounds__(NT, 2) void attn64d_kernel(AttnParams p) {
   typedef bf16_t T;
   __shared__ __attribute__((aligned(1024))) char smem[NSLOT * SLOT_BYTES + 1024];
+  __shared__ int redo_flag;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   int pair, qblk;
@@ -224,34 +233,13 @@ __global__ __launch_bounds__(NT, 2) void attn64d_kernel(AttnParams p) {
     frag_load(f, reinterpret_cast<const T*>(slot + off));
   };
 
-  // ---- prologue: tiles 0, 1, 2 on their way, tiles 0 and 1 landed; the scores of half tile 0 ----
-  issue_tile(0);
-  if (ntiles > 1) issue_tile(1);
-  if (ntiles > 2) issue_tile(2);
-  if (ntiles > 2) { if (npieces == 3) wait_vmcnt<3>(); else wait_vmcnt<2>(); } else wait_vmcnt<0>();
-  __syncthreads();
-  f32x16 sA[QB], sB[QB];
-  {
-    Frag<T> kf[KSQ];
-#pragma unroll
-    for (int ks = 0; ks < KSQ; ++ks) kfrag(kf[ks], smem, 0, ks);
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) sA[qb] = (f32x16)(0.f);
-#pragma unroll
-    for (int ks = 0; ks < KSQ; ++ks)
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) mma32(sA[qb], kf[ks], qf[qb][ks]);
-    float mt[QB];
-    tile_max(sA, mt);
-    rescale(sA, mt, true);
-  }
-
   // Fragment registers are double-buffered across bodies: a body multiplies with the K / first-V^T fragments its predecessor read for it and
   // reads its successor's behind its last score MFMA (the LDS round trip of five ds_read_b128 is off the wave's critical path; the
   // ablation that removed the fragment reads altogether ran 15 % faster).
   union VF { u32x4 u; Frag<T> f; };
-  auto body = [&](f32x16 (&sp)[QB], f32x16 (&sn)[QB], Frag<T> (&kf)[KSQ], VF (&vf0)[DT], Frag<T> (&kfn)[KSQ], VF (&vf0n)[DT], const char* vslot, int vhf,
+  auto body = [&](auto fastc, f32x16 (&sp)[QB], f32x16 (&sn)[QB], Frag<T> (&kf)[KSQ], VF (&vf0)[DT], Frag<T> (&kfn)[KSQ], VF (&vf0n)[DT], const char* vslot, int vhf,
                   const char* kslot_n, int khf_n, const char* vslot_n, int vhf_n, bool decide, bool twin) __attribute__((always_inline)) {
+    constexpr bool fast = decltype(fastc)::value;
     VF vf1[DT];
     float ex[2][16];
     Frag<T> pf[2][QB];
@@ -307,7 +295,7 @@ __global__ __launch_bounds__(NT, 2) void attn64d_kernel(AttnParams p) {
       const int dt = c >> 1, qb = c & 1;
       mma32(o[qb][dt], vf1[dt].f, pf[1][qb]);
       PIN(o[qb][dt]);
-      if (c < 2) {
+      if (!fast && c < 2) {
         PIN(sn[c]);
         float m1 = fmaxf(fmaxf(sn[c][0], sn[c][1]), sn[c][2]);
 #pragma unroll
@@ -320,38 +308,101 @@ __global__ __launch_bounds__(NT, 2) void attn64d_kernel(AttnParams p) {
       FENCE();
     }
     if (twin) store_out(ob_twin);
-    if (decide && __any(fmaxf(mt[0], mt[1]) > RESCALE_LAG)) rescale(sn, mt, false);
+    if constexpr (!fast) {
+      if (decide && __any(fmaxf(mt[0], mt[1]) > RESCALE_LAG)) rescale(sn, mt, false);
+    }
   };
 
-  Frag<T> kfA[KSQ], kfB[KSQ];
-  VF vfA[DT], vfB[DT];
-#pragma unroll
-  for (int ks = 0; ks < KSQ; ++ks) kfrag(kfA[ks], smem, 1, ks);                                        // S(0, 1)
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt) vfA[dt].u = *reinterpret_cast<const u32x4*>(smem + vofs[0][0][dt]);   // P.V(0, 0)
-  for (int it = 0; it < ntiles; ++it) {
-    if (it > 0) {
-      // tile it + 1 (issued two iterations ago) has landed -- this wave's pieces: only those of tile it + 2 may still be in flight --
-      // and, behind the barrier, everybody's; the barrier also frees slot (it + 3) % 4 = (it - 1) % 4, last read in iteration it - 1
-      // (the fragments read ahead at the end of iteration it - 1 come from tile it's slot)
-      if (it + 2 < ntiles) { if (npieces == 3) wait_vmcnt<3>(); else wait_vmcnt<2>(); } else wait_vmcnt<0>();
-      __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's fragment reads have returned
-      __builtin_amdgcn_s_barrier();
+  // One pass over the key tiles: prologue (tiles 0, 1, 2 on their way; the scores of half tile 0 set the softmax reference) + the tile loop.
+  auto attend = [&](auto fastc) __attribute__((always_inline)) {
+    issue_tile(0);
+    if (ntiles > 1) issue_tile(1);
+    if (ntiles > 2) issue_tile(2);
+    if (ntiles > 2) { if (npieces == 3) wait_vmcnt<3>(); else wait_vmcnt<2>(); } else wait_vmcnt<0>();
+    __syncthreads();
+    f32x16 sA[QB], sB[QB];
+    {
+      Frag<T> kf[KSQ];
+  #pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) kfrag(kf[ks], smem, 0, ks);
+  #pragma unroll
+      for (int qb = 0; qb < QB; ++qb) sA[qb] = (f32x16)(0.f);
+  #pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks)
+  #pragma unroll
+        for (int qb = 0; qb < QB; ++qb) mma32(sA[qb], kf[ks], qf[qb][ks]);
+      float mt[QB];
+      tile_max(sA, mt);
+      rescale(sA, mt, true);
     }
-    if (it + 3 < ntiles) issue_tile(it + 3);
-    const char* cur = smem + (it & (NSLOT - 1)) * SLOT_BYTES;
-    const char* nxt = smem + ((it + 1) & (NSLOT - 1)) * SLOT_BYTES;
-    // S(it, 1) || P.V(it, 0); reads ahead: K(it + 1, 0), V(it, 1)
-    body(sA, sB, kfA, vfA, kfB, vfB, cur, 0, nxt, 0, cur, 1, true, false);
-    // S(it + 1, 0) || P.V(it, 1); reads ahead: K(it + 1, 1), V(it + 1, 0)
-    body(sB, sA, kfB, vfB, kfA, vfA, cur, 1, nxt, 1, nxt, 0, it + 1 < ntiles, ob_twin && it == nt0 - 1);
+
+    Frag<T> kfA[KSQ], kfB[KSQ];
+    VF vfA[DT], vfB[DT];
+  #pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) kfrag(kfA[ks], smem, 1, ks);                                        // S(0, 1)
+  #pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vfA[dt].u = *reinterpret_cast<const u32x4*>(smem + vofs[0][0][dt]);   // P.V(0, 0)
+    for (int it = 0; it < ntiles; ++it) {
+      if (it > 0) {
+        // tile it + 1 (issued two iterations ago) has landed -- this wave's pieces: only those of tile it + 2 may still be in flight --
+        // and, behind the barrier, everybody's; the barrier also frees slot (it + 3) % 4 = (it - 1) % 4, last read in iteration it - 1
+        // (the fragments read ahead at the end of iteration it - 1 come from tile it's slot)
+        if (it + 2 < ntiles) { if (npieces == 3) wait_vmcnt<3>(); else wait_vmcnt<2>(); } else wait_vmcnt<0>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's fragment reads have returned
+        __builtin_amdgcn_s_barrier();
+      }
+      if (it + 3 < ntiles) issue_tile(it + 3);
+      const char* cur = smem + (it & (NSLOT - 1)) * SLOT_BYTES;
+      const char* nxt = smem + ((it + 1) & (NSLOT - 1)) * SLOT_BYTES;
+      // S(it, 1) || P.V(it, 0); reads ahead: K(it + 1, 0), V(it, 1)
+      body(fastc, sA, sB, kfA, vfA, kfB, vfB, cur, 0, nxt, 0, cur, 1, true, false);
+      // S(it + 1, 0) || P.V(it, 1); reads ahead: K(it + 1, 1), V(it + 1, 0)
+      body(fastc, sB, sA, kfB, vfB, kfA, vfA, cur, 1, nxt, 1, nxt, 0, it + 1 < ntiles, ob_twin && it == nt0 - 1);
+    }
+  };
+  if constexpr (!FAST) {
+    attend(std::false_type{});
+  } else {
+    if (tid == 0) redo_flag = 0;                           // (published by the first barrier of the pass)
+    attend(std::true_type{});
+    // the guard: a denominator beyond 2^100 (or inf / NaN: an exponent overflowed) in any row of the workgroup
+    bool bad = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      constexpr int R = HD % 32, REG = (R & 3) + 4 * (R >> 3);
+      bad |= !(fabsf(o[qb][HD / 32][REG]) < 1.2676506e30f);   // (lanes of the half that holds no denominator read a V^T row: finite too)
+    }
+    wait_vmcnt<0>();
+    if (__any(bad) && lane == 0) redo_flag = 1;
+    __syncthreads();
+    if (redo_flag) {                                       // uniform over the workgroup: every wave has left the tile loop, no DMA is in flight
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = 0.f;
+        if (lh == 1) {                                     // (the reference the first pass folded into the padding of the third K-step)
+          qf[qb][KSQ - 1].set(0, 0.f);
+          qf[qb][KSQ - 1].set(1, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < DT; ++i) o[qb][i] = (f32x16)(0.f);
+      }
+      kseg = uni(kb0);
+      vseg = uni(vb0);
+      kts2 = __builtin_amdgcn_readfirstlane((int)p.k_ts * 2);
+      seg_offsets(false);
+      attend(std::false_type{});
+    }
   }
   store_out(ob);
 }
 #undef PIN
 #undef FENCE
 
+int g_attn_nomax = 1;   // mmgt_tune("attn_nomax", 0 / 1): the kernel without the running maximum (guarded), A/B switch
+
 }  // namespace
+
+void mmgt_attn_set_nomax(int v) { g_attn_nomax = v; }
 
 // attention.hip's dispatcher: bf16, head_dim 40, V transposed, nq % 256 == 0, nk % 64 == 0, nk2 % 64 == 0
 int mmgt_attn64_launch(const void* params, int batch, int heads, void* stream) {
@@ -359,7 +410,8 @@ int mmgt_attn64_launch(const void* params, int batch, int heads, void* stream) {
   p.heads = heads;
   p.npairs = batch * heads;
   p.nqb = p.nq / (32 * QB * NW);
-  hipLaunchKernelGGL(attn64d_kernel, dim3((unsigned)((long)p.nqb * batch * heads)), dim3(NT), 0, (hipStream_t)stream, p);
+  if (g_attn_nomax) hipLaunchKernelGGL(attn64d_kernel<true>, dim3((unsigned)((long)p.nqb * batch * heads)), dim3(NT), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(attn64d_kernel<false>, dim3((unsigned)((long)p.nqb * batch * heads)), dim3(NT), 0, (hipStream_t)stream, p);
   MMGT_LAUNCH_CHECK();
   return 0;
 }

@@ -503,6 +503,61 @@ def test_attention_online_softmax_rescale_branch_is_forced(hd, a64):
     torch.testing.assert_close(out.double(), ref, **tol(dt))
 
 
+def test_attention_without_running_maximum_and_its_overflow_guard():
+    """attn64d_kernel<FAST> (mmgt_tune "attn_nomax", the default): the softmax reference of a row stays what its first 32 keys set it to.  (1) On
+    ordinary rows -- including rows whose maximum jumps mid-sequence by a few octaves -- the result meets the same fp64 gate as the kernel with the
+    running maximum.  (2) A key whose score lies 2^130 above the reference overflows p = 2^(s - reference): the workgroup's guard (a denominator
+    beyond 2^100) must send it through the tile loop again WITH the running maximum -- its rows are then bitwise those of attn_nomax = 0 --, no
+    inf / NaN may reach the output, and workgroups without such a key keep their fast results."""
+    from mmgt_amd import hip
+    dt = torch.bfloat16
+    heads, hd, B, nq, nk2 = 2, 40, 4, 512, 256
+    inner = heads * hd
+    q = rnd("qf", (B, nq, inner), 1.0, dt)
+    k = rnd("kf", (B, nq, inner), 1.0, dt)
+    v = rnd("vf", (B, nq, inner), 1.0, dt)
+    kb = rnd("kbf", (2, nk2, inner), 1.0, dt)
+    vb = rnd("vbf", (2, nk2, inner), 1.0, dt)
+    for tile, qrow in ((1, 5), (3, 77), (6, 300)):          # moderate spikes: the reference of these rows ends ~2^15 below their maximum
+        k[:, 64 * tile + 9] = (q[:, qrow].float() * 6).to(dt)
+    k[1, 64 * 5 + 17] = (q[1, 130].float() * 60).to(dt)     # batch 1, query 130 (workgroup of queries 0 .. 255): 2^(~180) above the reference
+    kb[1, 200] = (q[3, 411].float() * 70).to(dt)            # a bank key against batch 3, query 411 (bank row 3 // 2 = 1)
+    scale = hd ** -0.5
+    split = lambda t: t.double().reshape(t.shape[0], t.shape[1], heads, hd).permute(0, 2, 1, 3)
+    refs = []
+    for b in range(B):
+        kk, vv = k[b:b + 1], v[b:b + 1]
+        if b >= 2:
+            kk = torch.cat([kk, kb[b // 2][None]], 1)
+            vv = torch.cat([vv, vb[b // 2][None]], 1)
+        refs.append(_ref_attn(split(q[b:b + 1]), split(kk), split(vv), scale))
+    ref = torch.cat(refs).permute(0, 2, 1, 3).reshape(B, nq, inner)
+    vT, vbT = v.transpose(1, 2).contiguous(), vb.transpose(1, 2).contiguous()
+
+    def run(nomax):
+        out = torch.full_like(q, float("nan"))
+        hip.tune("attn_nomax", nomax)
+        hip.attention(q, k, vT, out, batch=B, heads=heads, hd=hd, nq=nq, nk=nq, scale=scale, q_str=(nq * inner, 0, inner),
+                      k_str=(nq * inner, 0, inner), v_str=(vT.stride(0), 0, vT.stride(1)), o_str=(nq * inner, 0, inner),
+                      v_transposed=True, k2=kb, v2=vbT, k2_str=(kb.stride(0), inner), v2_str=(vbT.stride(0), vbT.stride(1)),
+                      k2_bdiv=2, nk2=nk2, seg2_first_batch=2)
+        return out
+    try:
+        exact, fast = run(0), run(1)
+    finally:
+        hip.tune("attn_nomax", 1)
+    assert torch.isfinite(fast.float()).all()
+    # (nearly one-hot rows of |v| <= 1 values: P and the output are bf16, 2^-9 relative each -- the same gate for both kernels)
+    torch.testing.assert_close(exact.double(), ref, rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(fast.double(), ref, rtol=2e-2, atol=3e-2)
+    # the two workgroups that overflowed (256 queries x both heads... a workgroup = one (batch, head) pair x 256 queries) went through the guarded pass
+    assert torch.equal(fast[1, :256], exact[1, :256]) and torch.equal(fast[3, 256:], exact[3, 256:])
+    # ... the others did not: somewhere their rounding differs (another reference), far inside the gate
+    assert not torch.equal(fast[0], exact[0])
+    assert (fast[0].float() - exact[0].float()).abs().max() <= 2.0 ** -7
+    assert torch.equal(run(1), fast)                        # repeatable
+
+
 @pytest.mark.parametrize("a64", [0, 1])
 def test_attention_run_to_run_deterministic(a64):
     """Identical launches give bitwise identical results (a data race between the staging writes and the fragment reads of the

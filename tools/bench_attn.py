@@ -52,3 +52,15 @@ if __name__ == "__main__":
             print(f"{name:32s} attn64={a64} | {min(ts):8.1f}/{statistics.median(ts):8.1f} us {fl / min(ts) / 1e6:5.0f} TF", flush=True)
         print(f"    max|attn64 - base| = {(outs[1] - outs[0]).abs().max().item():.3e}", flush=True)
     hip.tune("attn64", 1)
+    # the head_dim-40 kernel with (attn_nomax = 0) and without (1, the default) the running maximum, alternating
+    for name, run, fl, o in [case(4096, 320, 4096), case(4096, 320, 0)]:
+        outs = {}
+        for rnd_ in range(3):
+            for nm in (0, 1):
+                hip.tune("attn_nomax", nm)
+                t_us(run)
+                ts = [t_us(run) for _ in range(3)]
+                outs[nm] = o.float().clone()
+                print(f"{name:32s} attn_nomax={nm} | {min(ts):8.1f}/{statistics.median(ts):8.1f} us {fl / min(ts) / 1e6:5.0f} TF", flush=True)
+        print(f"    max|nomax - running max| = {(outs[1] - outs[0]).abs().max().item():.3e}", flush=True)
+    hip.tune("attn_nomax", 1)
