@@ -98,7 +98,12 @@ __device__ __forceinline__ const void* rc_uni(const void* ptr) {
 }
 
 // the lane id, read afresh (a free function: see rc_uni)
-__device__ __forceinline__ int rc_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// (volatile: the builtin is loop-invariant, hipcc hoists it out of the phase loop and keeps what is derived from it in registers -- which it then spills)
+__device__ __forceinline__ int rc_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 
 template <int LO, int... I, typename F>
 __device__ __forceinline__ void rc_for_impl(std::integer_sequence<int, I...>, F&& fn) { (fn(std::integral_constant<int, LO + I>{}), ...); }
@@ -111,12 +116,12 @@ __device__ __forceinline__ void rc_for(F&& fn) { rc_for_impl<LO>(std::make_integ
 //   NT = 10, RT = 2 (8 x 1 waves, CB = 160): the 640-wide level (192 tiles x 4 blocks = 768 units instead of 384 = 1.5 rounds) and 24-image launches.
 template <int NT, int RT> struct RcCfg {
   static constexpr int WN = RT / 2, CB = 16 * NT * WN, SLOT = CB * 64, NPC = NT * WN;   // wave columns; output block; bytes and 1-KiB pieces per k-step
-  // the weight pieces of a k-step are issued by the first NW waves, PPW each (NW = the largest divisor of NPC <= 8: 5 x 4, 8 x 2, 5 x 2): a wave's
-  // in-order vmcnt queue then holds either exactly PPW weight pieces per k-step or none, and the counted waits below are exact for both kinds
-  static constexpr int NW = NPC % 8 == 0 ? 8 : NPC % 7 == 0 ? 7 : NPC % 6 == 0 ? 6 : NPC % 5 == 0 ? 5 : 4, PPW = NPC / NW;
+  // piece q of a k-step is issued by wave q % 8: every wave has at least PPW = NPC / 8 weight pieces per k-step in its in-order vmcnt queue, and the
+  // counted waits below, written for PPW, only wait longer (never shorter) on the waves that have one more
+  static constexpr int PPW = NPC / 8;
   static constexpr int NSLOT_FIT = (160 * 1024 - 2 * RC_HALO - 6144) / SLOT, NSLOT = NSLOT_FIT > 5 ? 5 : NSLOT_FIT;   // (<= 5: the late waves' normalisation must end in front of k-step 17)
   static constexpr int L_RING = 2 * RC_HALO, L_BIAS = L_RING + NSLOT * SLOT, L_TAB = L_BIAS + 4096, L_DUMMY = L_TAB + 1024, LDS = L_DUMMY + 1024;
-  static_assert(LDS <= 160 * 1024 && NSLOT >= 3 && NW * PPW == NPC && NT % 2 == 0 && NT >= RC_FWD + 2 && (RC_NSTEP * NT) % RC_FWD == 0 && (RT == 2 || RT == 4), "LDS / shape");
+  static_assert(LDS <= 160 * 1024 && NSLOT >= 3 && PPW >= 1 && NT % 2 == 0 && NT >= RC_FWD + 2 && (RC_NSTEP * NT) % RC_FWD == 0 && (RT == 2 || RT == 4), "LDS / shape");
 };
 
 // ST: the epilogue also emits the statistics of the GroupNorm that reads this launch's output (the next leg's norm2, resnet.py:231): per partial
@@ -126,7 +131,7 @@ template <int NT, int RT> struct RcCfg {
 template <int NT, int RT, bool RES, bool ST = false>
 __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
   using Cfg = RcCfg<NT, RT>;
-  constexpr int CB = Cfg::CB, SLOT = Cfg::SLOT, NW = Cfg::NW, PPW = Cfg::PPW, NSLOT = Cfg::NSLOT, WN = Cfg::WN;
+  constexpr int CB = Cfg::CB, SLOT = Cfg::SLOT, NPC = Cfg::NPC, PPW = Cfg::PPW, NSLOT = Cfg::NSLOT, WN = Cfg::WN;
   constexpr int NPAIR = NT / 2, NST = RT * NPAIR + (ST ? 6 * NPAIR : 0);      // tile pairs; 16-byte stores per wave and unit (ST: + 6 per pair)
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,13 +142,21 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
 #else
   constexpr int abl = 0;
 #endif
-  int trace_n = 0;                                         // debug (tools/trace_rconv.py, as gemm16's): 100-MHz stamps of wave 0; a.trace == NULL: off
+  // debug (tools/trace_rconv.py): 100-MHz stamps of wave 0 -- in the -DMMGT_ABLATE library only: the four null-pointer tests per k-step, each a taken
+  // scalar branch, were a tenth of the k-step's instruction stream
+#ifdef MMGT_ABLATE
+  int trace_n = 0;
   auto stamp = [&]() {
     if (a.trace) {
       if (tid == 0 && trace_n < 512) a.trace[(long)blockIdx.x * 512 + trace_n] = wall_clock64();
       ++trace_n;
     }
   };
+  const bool trace_fine = a.trace_fine != 0;
+#else
+  auto stamp = [&]() {};
+  constexpr bool trace_fine = false;
+#endif
   const int G = gridDim.x;
   const int cin = a.C0 + a.C1;
   const int my_units = (a.nunits - (int)blockIdx.x + G - 1) / G;
@@ -163,37 +176,31 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
     tx = rem - ty * a.tiles_x;
   };
 
-  // ---- weight stream: k-step wg (counted over the workgroup's units) lives in ring slot wg % NSLOT
+  // ---- weight stream: k-step wg (counted over the workgroup's units) lives in ring slot wg % NSLOT.  Scalar state only, advanced without
+  // branches: the image offset of the k-step (w_soff: + one k-step's row of the image; at a unit's end the next unit's block offset, decoded once per
+  // unit at its first phase), the LDS offset of the slot, the k-steps left.  Piece q of a k-step is issued by wave q % 8.
   const __amdgpu_buffer_rsrc_t rW = dma_rsrc(a.wimg);
-  int wg = 0, w_vt = blockIdx.x, w_ch = 0, w_cboff = 0, w_slot = 0;
   const int w_row = a.cout * 64;                           // bytes of a k-step's weights over ALL output channels (the image is [k-step][cout / 16][1 KiB])
+  int w_left = total, w_ch = 0, w_soff = 0, w_next = 0, w_lds = Cfg::L_RING;
   {
     int n, ty, tx, cb;
-    decode(w_vt < a.nunits ? w_vt : 0, n, ty, tx, cb);
-    w_cboff = cb * SLOT;
+    decode(blockIdx.x < (unsigned)a.nunits ? (int)blockIdx.x : 0, n, ty, tx, cb);
+    w_soff = cb * SLOT;
   }
   // Beyond the last k-step the pieces still go out against the poison offset (zeros into a slot nobody reads): every wait count below is a
   // compile-time constant on every path.
   auto issue_w = [&]() {
-    const int soff = w_cboff + w_ch * w_row;
-    if (wid < NW) {
+    const unsigned vo = (w_left > 0 && !(abl & 1)) ? (unsigned)(rc_lane() * 16 + wid * 1024) : DMA_POISON;
 #pragma unroll
-      for (int u = 0; u < PPW; ++u) {
-        const int q = wid * PPW + u;
-        blds16(rW, (wg < total && !(abl & 1)) ? (unsigned)(rc_lane() * 16 + q * 1024) : DMA_POISON, soff, smem + Cfg::L_RING + w_slot * SLOT + q * 1024);
-      }
+    for (int u = 0; u < (NPC + 7) / 8; ++u) {
+      if (8 * u + 7 < NPC || wid + 8 * u < NPC) blds16(rW, vo, w_soff + u * 8192, smem + w_lds + (wid + 8 * u) * 1024);
     }
-    ++wg;
-    w_slot = w_slot == NSLOT - 1 ? 0 : w_slot + 1;
-    if (++w_ch == ksteps_per_unit) {
-      w_ch = 0;
-      w_vt += G;
-      if (w_vt < a.nunits) {
-        int n, ty, tx, cb;
-        decode(w_vt, n, ty, tx, cb);
-        w_cboff = cb * SLOT;
-      }
-    }
+    --w_left;
+    w_lds = w_lds == Cfg::L_RING + (NSLOT - 1) * SLOT ? Cfg::L_RING : w_lds + SLOT;
+    ++w_ch;
+    const bool wrap = w_ch == ksteps_per_unit;
+    w_soff = wrap ? w_next : w_soff + w_row;
+    w_ch = wrap ? 0 : w_ch;
   };
 
   // ---- halo stream: piece q = wid + 8 i of a phase holds vectors 64 q + lane = pixel R = 8 q + (lane >> 3), slot lane & 7, i.e. the source chunk
@@ -294,26 +301,28 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
   // computed where it is used from two registers (rl16: bits 6:4 = rl & 7; lq16) in three instructions per fragment -- eight offsets kept live cost
   // the 320-wide cut spills inside its k-steps.
   const int rl16 = (RC_HP * RT * wm + lm) * 16, lq16 = lq * 16;
-  const int w_lane = Cfg::L_RING + wn * NT * 1024 + lane * 16;             // + slot SLOT + j 1 KiB
+  const int w_lane = wn * NT * 1024 + lane * 16;                           // + LDS offset of the slot + j 1 KiB
   s16x8 fa[RT], fw[RC_FWD];
-  auto read_a1 = [&](int buf, auto Sc, auto Ic) {             // A fragment of image row i of the wave for k-step S
-    constexpr int S = decltype(Sc)::value, i = decltype(Ic)::value, tap = S >> 1, ks = S & 1, ky = tap / 3, kx = tap % 3, K = RC_HP * (i + ky) + kx;
-    const int sw = (rl16 + (K & 7) * 16) & 0x70;              // ((rl + K) & 7) << 4
-    return *reinterpret_cast<const s16x8*>(smem + buf * RC_HALO + ((sw ^ (lq16 ^ (ks ? 64 : 0))) + (rl16 << 3) + K * 128));
+  int a_rl = 0, a_base = 0;                                  // per k-step: an opaque copy of rl and the byte offset of the lane's row 0 in the halo buffer
+  auto read_a_begin = [&](int buf) {                         // (opaque: the eight loop-invariant swizzles are not hoisted out of the phase loop and kept live)
+    a_rl = rl16 >> 4;
+    asm volatile("" : "+v"(a_rl));
+    a_base = buf * RC_HALO + a_rl * 128;
   };
-  auto read_w = [&](int slot, int j) { return *reinterpret_cast<const s16x8*>(smem + w_lane + slot * SLOT + j * 1024); };
+  auto read_a1 = [&](int buf, auto Sc, auto Ic) {             // A fragment of image row i of the wave for k-step S (after read_a_begin(buf))
+    constexpr int S = decltype(Sc)::value, i = decltype(Ic)::value, tap = S >> 1, ks = S & 1, ky = tap / 3, kx = tap % 3, K = RC_HP * (i + ky) + kx;
+    const int sw = ((a_rl + (K & 7)) & 7) * 16;               // ((rl + K) & 7) << 4: a multiple of 16, like everything below (one ds_read_b128)
+    return *reinterpret_cast<const s16x8*>(smem + ((sw ^ (lq16 ^ (ks ? 64 : 0))) + a_base + K * 128));
+  };
+  auto read_w = [&](int slot_off, int j) { return *reinterpret_cast<const s16x8*>(smem + w_lane + slot_off + j * 1024); };
 
   // Start stagger.  Every unit of a launch is the same length, so the persistent workgroups of the whole chip reach their epilogues together: a
   // burst of nunits-per-round x 160 KB that HBM takes ~10 - 18 us to absorb while every wave's in-order vmcnt queue holds its next weight pieces
   // behind its stores.  Eight groups of workgroups start a few microseconds apart so that the bursts are spread over that time.
   for (int d = ((blockIdx.x >> 3) & 7) * a.stagger; d > 0; d -= 64) __builtin_amdgcn_s_sleep(64);
 
-  // s_waitcnt vmcnt(W PPW + X): W k-steps of weight pieces (the waves that issue them) + X other operations may stay in flight
-  auto wait_wx = [&](auto Wc, auto Xc) {
-    constexpr int W = decltype(Wc)::value, X = decltype(Xc)::value;
-    if (NW == 8 || wid < NW) wait_vmcnt<W * PPW + X>(); else wait_vmcnt<X>();
-  };
-#define RC_WAIT(W_, X_) wait_wx(std::integral_constant<int, (W_)>{}, std::integral_constant<int, (X_)>{})
+  // s_waitcnt vmcnt(W PPW + X): W k-steps of weight pieces + X other operations may stay in flight
+#define RC_WAIT(W_, X_) wait_vmcnt<(W_) * PPW + (X_)>()
 
   // ---- prologue: bias of the first unit, its first halo (normalised here), the first NSLOT - 1 k-steps of weights
   int vt = blockIdx.x, ph = 0, fp = 0;                      // current unit, its phase, phases done (buffer parity)
@@ -329,11 +338,12 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0): the LDS stores above
   __builtin_amdgcn_s_barrier();
-  int c_slot = 0;                                           // ring slot of the k-step being multiplied
+  int c_slot = Cfg::L_RING;                                 // LDS offset of the ring slot of the k-step being multiplied
   if (my_units > 0) {
+    read_a_begin(0);
     rc_for<0, RT>([&](auto ic) { fa[decltype(ic)::value] = read_a1(0, std::integral_constant<int, 0>{}, ic); });
 #pragma unroll
-    for (int j = 0; j < RC_FWD; ++j) fw[j] = read_w(0, j);
+    for (int j = 0; j < RC_FWD; ++j) fw[j] = read_w(c_slot, j);
   }
 
   const __amdgpu_buffer_rsrc_t rO = dma_rsrc(a.out), rR = dma_rsrc(a.res ? a.res : a.out);
@@ -345,6 +355,11 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
     const bool has_next = nvt < a.nunits;
     const int buf = fp & 1, nbuf = buf ^ 1;
     if (has_next) halo_target(nvt, nph);
+    if (first_ph && vt + G < a.nunits) {                    // the block offset of the weight stream's next unit (it enters that unit NSLOT - 1 k-steps early)
+      int n, ty, tx, cb;
+      decode(vt + G, n, ty, tx, cb);
+      w_next = cb * SLOT;
+    }
 
     if (first_ph) {
       const acc4* lb = reinterpret_cast<const acc4*>(smem + Cfg::L_BIAS) + wn * NT * 4 + lq;   // the lane's columns 16 j + 4 lq + r
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
     rc_for<0, RC_NSTEP>([&](auto sc_) {
       constexpr int S = decltype(sc_)::value;
       stamp();
-      const int n_slot = c_slot == NSLOT - 1 ? 0 : c_slot + 1;
+      const int n_slot = c_slot == Cfg::L_RING + (NSLOT - 1) * SLOT ? Cfg::L_RING : c_slot + SLOT;
       // Two dwords of the next phase's halo per k-step, S = NSLOT .. NSLOT + 11.  The counted waits of the hand-overs leave NSLOT - 3 k-steps of
       // weight pieces and the halo pieces issued among them in flight, so the piece of hand-over h (vector h) -- and the table, issued with
       // vector 0 by wave 0 -- is only known to have landed behind hand-over h + NSLOT - 1: vector i is normalised in k-steps NSLOT + 2 i, + 1.
@@ -373,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
       // the count is the operations YOUNGER than those pieces: the pieces of the k-steps behind it, the halo pieces of the earlier hand-overs
       // (waves that issued a table / bias piece too wait for one operation more than they must), the stores of an epilogue in front of k-step 0.
       auto handover = [&]() {
-        if (a.trace_fine) stamp();
+        if (trace_fine) stamp();
         constexpr int HLO = S + 2 - NSLOT > 0 ? S + 2 - NSLOT : 0, HHI = S - 1 < RC_NHV - 1 ? S - 1 : RC_NHV - 1;
         constexpr int NH = HHI >= HLO ? HHI - HLO + 1 : 0;            // halo pieces issued behind the pieces waited for (one per hand-over 0 .. 5)
         constexpr bool EPI = S <= NSLOT - 3;                          // ... and the stores of an epilogue in front of k-step 0
@@ -388,9 +403,9 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
           RC_WAIT(NSLOT - 3, 0);
         }
         if constexpr (S == RC_NSTEP - 1) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this thread's normalised dwords are in LDS
-        if (a.trace_fine) stamp();
+        if (trace_fine) stamp();
         if (!(abl & 8)) __builtin_amdgcn_s_barrier();
-        if (a.trace_fine) stamp();
+        if (trace_fine) stamp();
         issue_w();                                          // into the slot k-step g - 1 left
         if constexpr (S < RC_NHV) {
           if (has_next) {
@@ -416,6 +431,7 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
       });
       // ---- the last two W tiles row-major: an A fragment's register takes the next k-step's fragment as soon as its two MFMAs have issued
       // (k-step 17: from the next phase's halo, complete behind the barrier above)
+      read_a_begin(S + 1 < RC_NSTEP ? buf : nbuf);
       rc_for<0, RT>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         rc_mma<(NT - 2 < 8)>(acc[i][NT - 2], fw[fwi(NT - 2)], fa[i]);
@@ -543,6 +559,7 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
       }
       // the next unit's first fragments (its halo and its first k-step are in LDS behind the barrier of k-step 17)
       if (has_next) {
+        read_a_begin(nbuf);
         rc_for<0, RT>([&](auto ic) { fa[decltype(ic)::value] = read_a1(nbuf, std::integral_constant<int, 0>{}, ic); });
 #pragma unroll
         for (int j = 0; j < RC_FWD; ++j) fw[j] = read_w(c_slot, j);

@@ -210,6 +210,26 @@ def _(x, ln_gamma, beta_pe, wimg, bias_o, batch, frames, heads):
     return torch.empty_like(x)
 
 
+@_lib.custom_op("mmgt_hip::gn_silu_conv3x3", mutates_args=(), device_types="cuda")
+def gn_silu_conv3x3(x: torch.Tensor, skip: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, wimg: torch.Tensor,
+                    cout: int, bias: Optional[torch.Tensor], temb: Optional[torch.Tensor], residual: Optional[torch.Tensor]) -> torch.Tensor:
+    """conv3x3(silu(GroupNorm(cat(x, skip)))) + bias + temb[n] (+ residual) of a ResnetBlock3D leg (resnet.py:217-247: norm -> nonlinearity -> conv, + temb
+    behind conv1, + shortcut behind conv2) on channels-last (N, H, W, C) bf16 frames: the statistics pass + ONE fused launch (csrc/rconv.hip); wimg =
+    packing.pack_rconv(conv.weight); temb (rows, cout) fp32 with N % rows == 0 (one row per batch entry)."""
+    nb, h, w, c0 = x.shape
+    c1 = 0 if skip is None else skip.shape[3]
+    if not hip.gn_silu_conv3x3_unet_supported(x.dtype, c0, c1, cout, h, w):
+        raise RuntimeError(f"mmgt_hip::gn_silu_conv3x3: built for bf16, H and W multiples of 16, channel counts multiples of 64, Cout a multiple of 160 "
+                           f"(got {x.dtype}, {h} x {w}, {c0} + {c1} -> {cout})")
+    sc, sh = hip.groupnorm_affine(x.view(nb, h * w, c0), gamma, beta, groups, eps, x1=None if skip is None else skip.view(nb, h * w, c1))
+    return hip.gn_silu_conv3x3_unet(x, sc, sh, wimg, cout, bias, temb, 0 if temb is None else nb // temb.shape[0], residual, x1=skip)
+
+
+@gn_silu_conv3x3.register_fake
+def _(x, skip, gamma, beta, groups, eps, wimg, cout, bias, temb, residual):
+    return x.new_empty(tuple(x.shape[:3]) + (cout,))
+
+
 _VAES = {}
 
 
@@ -235,4 +255,4 @@ def _(z, weights):
 
 
 OPS = ("gemm", "conv3x3_nhwc", "attention", "groupnorm_silu", "layernorm", "cfg_ddim_step", "attn_bank_fwd", "temporal_attn", "mmhaa_cross",
-       "ff_fused", "rowgemm320", "temporal_leg", "vae_decode")
+       "ff_fused", "rowgemm320", "temporal_leg", "gn_silu_conv3x3", "vae_decode")

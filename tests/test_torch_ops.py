@@ -64,6 +64,8 @@ def test_fake_kernels_of_the_fused_ops_give_shapes():
         assert torch.ops.mmgt_hip.vae_decode(e(2, 4, 8, 8), [e(3)]).shape == (2, 3, 64, 64)
         assert torch.ops.mmgt_hip.temporal_leg(e(2 * 24 * 8, 320), e(320, dt=torch.float32), e(32, 320, dt=torch.float32), e(10, dt=torch.uint8),
                                                e(320, dt=torch.float32), 2, 24, 8).shape == (384, 320)
+        assert torch.ops.mmgt_hip.gn_silu_conv3x3(e(2, 32, 32, 640), e(2, 32, 32, 320), e(960, dt=torch.float32), e(960, dt=torch.float32), 32, 1e-5,
+                                                  e(10, dt=torch.uint8), 640, None, e(2, 640, dt=torch.float32), None).shape == (2, 32, 32, 640)
 
 
 @pytest.mark.gpu
@@ -150,6 +152,18 @@ def test_fused_projection_ops_match_torch_math_bf16():
     got_t = torch.ops.mmgt_hip.temporal_leg(xt, w["g"], w["bpe"], pack_tleg(w["q"], w["k"], w["v"], w["o"]), w["bo"], B, Fr, 8)
     want_t = TT._ref(xt, w, B, Fr, n, 40 ** -0.5)
     assert ((got_t.double() - want_t).abs() <= 2.0 ** -8 * want_t.abs() + 8e-3).all()
+    # gn_silu_conv3x3: GroupNorm -> SiLU -> conv3x3 (+ temb, + residual) over a two-source input, against fp64 with the bf16 rounding of the normalised tensor
+    from mmgt_amd.packing import pack_rconv
+    nb, hh, c0, c1, co = 2, 32, 320, 64, 320
+    xa, xb = r("rc.x", (nb, hh, hh, c0), 1.5).bfloat16(), r("rc.s", (nb, hh, hh, c1)).bfloat16()
+    gg, bb = 1 + 0.2 * r("rc.g", (c0 + c1,)), 0.1 * r("rc.b", (c0 + c1,))
+    wc = r("rc.w", (co, c0 + c1, 3, 3)) * (9 * (c0 + c1)) ** -0.5
+    bc, te, rs = 0.1 * r("rc.bc", (co,)), 0.3 * r("rc.te", (nb, co)), r("rc.r", (nb, hh, hh, co)).bfloat16()
+    got_c = torch.ops.mmgt_hip.gn_silu_conv3x3(xa, xb, gg, bb, 32, 1e-5, pack_rconv(wc), co, bc, te, rs)
+    xc = torch.cat([xa, xb], 3).double().permute(0, 3, 1, 2)
+    nrm = F.silu(F.group_norm(xc, 32, gg.double(), bb.double(), 1e-5)).bfloat16().double()
+    want_c = F.conv2d(nrm, wc.bfloat16().double(), bc.double(), padding=1).permute(0, 2, 3, 1) + te.double()[:, None, None, :] + rs.double()
+    assert ((got_c.double() - want_c).abs() <= 2.0 ** -7 * want_c.abs() + 2e-2).all()
 
 
 @pytest.mark.gpu

@@ -34,6 +34,17 @@ elif kind == "conv":
     w = pack_conv3x3((rnd(cout, cin, 3, 3) / math.sqrt(9 * cin)).bfloat16())
     b = rnd(cout)
     fn = lambda: hip.conv3x3(x, w, b)
+elif kind == "rconv":
+    from mmgt_amd.packing import pack_rconv
+    nb, h, cin, cout = (int(v) for v in sys.argv[2:6])
+    res = len(sys.argv) > 6 and sys.argv[6] == "res"
+    x = rnd(nb, h, h, cin).bfloat16()
+    wimg = pack_rconv(rnd(cout, cin, 3, 3) / math.sqrt(9 * cin))
+    b, temb = rnd(cout), rnd(2, cout)
+    tab = torch.rand((2, nb, cin), device=dev)
+    r = rnd(nb, h, h, cout).bfloat16() if res else None
+    out = torch.empty((nb, h, h, cout), device=dev, dtype=torch.bfloat16)
+    fn = lambda: hip.gn_silu_conv3x3_unet(x, tab[0], tab[1], wimg, cout, b, temb, nb // 2, r, out=out)
 elif kind == "ffn":
     M, C, INNER = 48 * 4096, 320, 1280
     x = rnd(M, C).bfloat16()

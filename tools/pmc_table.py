@@ -30,7 +30,7 @@ def counters(db):
 
 def main_kernel(ctrs, dur):
     # the operator's own kernel = the one with the largest total time among mmgt kernels
-    own = {k: v for k, v in dur.items() if any(s in k for s in ("gemm", "attn", "ff_fused"))}
+    own = {k: v for k, v in dur.items() if any(s in k for s in ("gemm", "attn", "ff_fused", "rconv"))}
     return max(own, key=lambda k: own[k][0] * own[k][1])
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Debug: 100-MHz stamps of wave 0 of every persistent workgroup of csrc/rconv.hip (mmgt_rconv_set_trace): k-step starts and the epilogue."""
+"""Debug: 100-MHz stamps of wave 0 of every persistent workgroup of csrc/rconv.hip (mmgt_rconv_set_trace of the -DMMGT_ABLATE library): k-step starts and the epilogue."""
 import ctypes
 import os
 import sys
@@ -8,8 +8,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tools import abl_lib  # noqa: E402
+path = abl_lib.use()             # the stamps are compiled into the ablation library only
 from mmgt_amd import hip  # noqa: E402
-path = hip.LIB_PATH
 from mmgt_amd.packing import pack_rconv  # noqa: E402
 
 lib = ctypes.CDLL(path)
