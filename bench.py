@@ -281,9 +281,22 @@ def kernel_rooflines(unet, dev):
     fl = 2.0 * M * C * 9 * C
     out.append({"kernel": "conv3x3 48x64x64 320->320", "bound": "mfma", "ms": ms, "achieved": fl / ms / 1e9,
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS})
-    # GroupNorm + SiLU at L0 (HBM: 2 reads + 1 write of the tensor)
+    # ... the same leg as the step runs it since round 6: GroupNorm apply + SiLU + conv3x3 + residual as ONE launch behind the statistics pass (csrc/rconv.hip)
     g, b = unet.w["down_blocks.0.resnets.0.norm1.g"], unet.w["down_blocks.0.resnets.0.norm1.b"]
     x3 = xi.view(48, 4096, C)
+    if "down_blocks.0.resnets.0.conv2.rimg" in unet.w:
+        rimg = unet.w["down_blocks.0.resnets.0.conv2.rimg"]
+        sc_, sh_ = hip.groupnorm_affine(x3, g, b, 32, 1e-5)
+        oc = torch.empty_like(xi)
+        ms = _time_ms(lambda: hip.gn_silu_conv3x3_unet(xi, sc_, sh_, rimg, C, bc, residual=xi, out=oc))
+        out.append({"kernel": "gn_silu_conv3x3_unet 48x64x64 320->320 (GroupNorm apply + SiLU + conv + residual, one launch)", "bound": "mfma", "ms": ms,
+                    "achieved": fl / ms / 1e9, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS})
+        ms = _time_ms(lambda: hip.groupnorm_affine(x3, g, b, 32, 1e-5))
+        by = 1.0 * M * C * 2
+        out.append({"kernel": "groupnorm statistics pass 48x4096x320 (tables for the fused launch)", "bound": "hbm", "ms": ms, "achieved": by / ms / 1e6,
+                    "peak": 8000.0, "unit": "GB/s", "frac": by / ms / 1e6 / 8000.0})
+        del oc
+    # GroupNorm + SiLU at L0 (HBM: 2 reads + 1 write of the tensor): the unfused pass (fp32-I/O mode, the 8 x 8 level)
     ms = _time_ms(lambda: hip.groupnorm(x3, g, b, 32, 1e-5, silu=True))
     by = 3.0 * M * C * 2
     out.append({"kernel": "groupnorm+silu 48x4096x320", "bound": "hbm", "ms": ms, "achieved": by / ms / 1e6, "peak": 8000.0,

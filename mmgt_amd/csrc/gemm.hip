@@ -947,7 +947,7 @@ HostSwitch g_host[] = {
     {"oz3", 1},              // the three masked audio out-projections as one GEMM
     {"rowgemm", 1},          // row-stationary LayerNorm / GroupNorm -> projection launches
     {"tleg", 1},             // a level-0 temporal-attention leg as one launch (csrc/tleg.hip)
-    {"rconv", 3},            // the UNet resnets' GroupNorm + SiLU + conv3x3 legs as one launch (csrc/rconv.hip): 1 the 320-wide level, 2 + 640, 3 every level, 0 off
+    {"rconv", 5},            // the UNet resnets' GroupNorm + SiLU + conv3x3 legs as one launch (csrc/rconv.hip): a mask of 1 the 320-wide level, 2 the 640-wide, 4 the 1280-wide; 0 off
     {"rconv_stats", 1},      // ... with the next GroupNorm's statistics from the launch's epilogue (0: a statistics pass over the tensor)
     {"gnconv", 2},           // the VAE's GroupNorm + SiLU + conv3x3 as one launch (csrc/gnconv.hip): 1 with a statistics pass, 2 statistics from the producing launch
     {"zero_audio_skip", 1},  // skip the audio cross-attention of an all-zero (unconditional) audio row

@@ -122,8 +122,8 @@ class UNet3DConditionModel:
         self._fuse_ln = bool(hip.tune_get("rowgemm"))             # 0: LayerNorm and q / k / v GEMMs as separate launches
         self._fuse_tleg = bool(hip.tune_get("tleg"))              # 0: a level-0 temporal-attention leg as three launches
         self._rconv_stats = bool(hip.tune_get("rconv_stats"))     # a fused leg's output statistics from its epilogue instead of a pass over the tensor
-        self._rconv = hip.tune_get("rconv")                        # resnets whose GroupNorm -> SiLU -> conv3x3 legs run as one launch (csrc/rconv.hip): 0 none,
-                                                                   # 1 the 320-wide level, 2 + the 640-wide level, 3 every level with 16 x 16 tiles
+        self._rconv = hip.tune_get("rconv")                        # resnets whose GroupNorm -> SiLU -> conv3x3 legs run as one launch (csrc/rconv.hip): a mask of
+                                                                   # 1 the 320-wide level, 2 the 640-wide level, 4 the 1280-wide level (16 x 16 pixel tiles)
         self.spec = unet3d_spec(boc, cfg["cross_attention_dim"], cfg["audio_attention_dim"], self.in_channels,
                                 self.out_channels, cfg["layers_per_block"],
                                 cfg["motion_module_kwargs"].get("temporal_position_encoding_max_len", 32))
@@ -313,7 +313,7 @@ class UNet3DConditionModel:
             conv(p + ".conv1")
             conv(p + ".conv2")
             cout = self.spec[p + ".conv1.weight"][0]
-            if self._rconv and self._dtype == torch.bfloat16 and cout <= (320, 640, 1280)[min(self._rconv, 3) - 1] and \
+            if self._dtype == torch.bfloat16 and (self._rconv & {320: 1, 640: 2, 1280: 4}.get(cout, 0)) and \
                     has(p + ".conv1.weight") and has(p + ".conv2.weight"):
                 for cv in (".conv1", ".conv2"):                        # fragment-major images of the fused GroupNorm + SiLU + conv launch
                     wt = sd[p + cv + ".weight"]
