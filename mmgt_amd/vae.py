@@ -13,7 +13,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
-from .packing import pack_conv3x3, pack_gnconv, pad_cols, pad_rows, round_up
+from .packing import pack_conv3x3, pack_gnconv, pack_rconv, pad_cols, pad_rows, round_up
 
 _UP_CH = ((512, 512), (512, 512), (512, 256), (256, 128))     # (in, out) of decoder.up_blocks.0..3
 
@@ -170,6 +170,9 @@ class AutoencoderKL:
                     wpad = torch.zeros((cout_pad, wt.shape[1], 3, 3), device=self._device, dtype=torch.float32)
                     wpad[:wt.shape[0]] = wt.to(self._device, torch.float32)
                     w[p + ".gimg"] = pack_gnconv(wpad)
+                elif self._dtype == torch.bfloat16 and wt.shape[1] % 64 == 0 and wt.shape[0] % 256 == 0:
+                    # the 512-channel levels (and 512 -> 256): GroupNorm + SiLU + conv fused in 64-channel phases over 256-wide output blocks (csrc/rconv.hip)
+                    w[p + ".rimg"] = pack_rconv(wt.to(self._device, torch.float32))
             elif wt.dim() == 4:                                      # 1x1 conv as GEMM
                 m = wt.reshape(wt.shape[0], -1)
                 w[p + ".w"] = self._t(pad_rows(pad_cols(m, round_up(m.shape[1], 64)), round_up(m.shape[0], 64)))
@@ -206,32 +209,41 @@ class AutoencoderKL:
         nb, h, ww, c = x.shape
         return hip.groupnorm(x.view(nb, h * ww, c), self.w[p + ".g"], self.w[p + ".b"], 32, 1e-6, silu=silu).view(nb, h, ww, c)
 
-    def _gn_silu_conv(self, pn, pc, x, residual=None, stats=None):
+    def _gn_silu_conv(self, pn, pc, x, residual=None, stats=None, next_pn=None):
         """conv3x3(silu(GroupNorm(x))) (+ residual): diffusers `ResnetBlock2D.forward`'s norm -> nonlinearity -> conv.  In a bf16 model the convs
         of the 512 x 512 and 256 x 256 levels (128 / 256 input channels; conv_out padded to 64 outputs) run as ONE fused launch per 128 output
-        channels (the normalised tensor is never written); the GroupNorm statistics come from `stats` -- the per-tile partial sums the launch that
-        PRODUCED x wrote beside it -- or from one pass over x.  Everything else runs GroupNorm and conv as two launches.
-        Returns (out, stats of out or None)."""
+        channels (csrc/gnconv.hip) and those of the 512-channel levels as one launch in 64-channel phases (csrc/rconv.hip, round 6): the normalised
+        tensor is never written.  The GroupNorm statistics come from `stats` -- what the launch that PRODUCED x left beside it: ("tiles", per-tile
+        partial sums) of a gnconv launch, ("tables", (scale, shift)) of an rconv launch that was told the norm (`next_pn`) -- or from one pass over x.
+        Everything else runs GroupNorm and conv as two launches.  Returns (out, stats of out or None)."""
         nb, h, ww, c = x.shape
         cout = self.w[pc + ".bias"].numel()
-        if (hip.tune_get("gnconv") and (pc + ".gimg") in self.w and hip.gn_silu_conv3x3_supported(x.dtype, c, cout, h, ww, residual is not None)
-                and h * ww > 256):
-            g, b = self.w[pn + ".g"], self.w[pn + ".b"]
-            chain = hip.tune_get("gnconv") >= 2                  # (1: every fused launch behind its own statistics pass)
-            tables = hip.gn_tables_from_stats(stats, g, b, 32, 1e-6, nb, c) if stats is not None and chain else None
+        mode = hip.tune_get("gnconv")
+        chain = mode >= 2                                        # (1: every fused launch behind its own statistics pass)
+        g, b = self.w[pn + ".g"], self.w[pn + ".b"]
+        tables = None
+        if stats is not None and chain:
+            tables = stats[1] if stats[0] == "tables" else hip.gn_tables_from_stats(stats[1], g, b, 32, 1e-6, nb, c)
+        if mode and (pc + ".gimg") in self.w and hip.gn_silu_conv3x3_supported(x.dtype, c, cout, h, ww, residual is not None) and h * ww > 256:
             r = hip.gn_silu_conv3x3(x, g, b, 32, 1e-6, self.w[pc + ".gimg"], cout, self.w[pc + ".bias"], residual, tables=tables, want_stats=chain)
-            return r if chain else (r, None)
+            return (r[0], None if r[1] is None else ("tiles", r[1])) if chain else (r, None)
+        if mode and (pc + ".rimg") in self.w and hip.gn_silu_conv3x3_unet_supported(x.dtype, c, 0, cout, h, ww) and \
+                x.numel() * 2 <= hip.DMA_LIMIT and nb * h * ww * cout * 2 <= hip.DMA_LIMIT:
+            sc, sh = tables if tables is not None else hip.groupnorm_affine(x.view(nb, h * ww, c), g, b, 32, 1e-6)
+            nn = (self.w[next_pn + ".g"], self.w[next_pn + ".b"], 32, 1e-6) if next_pn and chain else None
+            r = hip.gn_silu_conv3x3_unet(x, sc, sh, self.w[pc + ".rimg"], cout, self.w[pc + ".bias"], residual=residual, next_norm=nn)
+            return (r[0], ("tables", r[1])) if nn else (r, None)
         return hip.conv3x3(self._gn(pn, x, True), self.w[pc + ".w"], self.w[pc + ".bias"], residual=residual), None
 
-    def _resnet(self, p, x, stats=None):
-        """-> (out, per-tile statistics of out or None); `stats`: those of x, from the launch that produced it"""
+    def _resnet(self, p, x, stats=None, next_pn=None):
+        """-> (out, statistics of out or None); `stats`: those of x, from the launch that produced it; next_pn: the GroupNorm that reads the result"""
         nb, h, ww, cin = x.shape
-        hdn, st = self._gn_silu_conv(p + ".norm1", p + ".conv1", x, stats=stats)
+        hdn, st = self._gn_silu_conv(p + ".norm1", p + ".conv1", x, stats=stats, next_pn=p + ".norm2")
         res = x
         if (p + ".conv_shortcut.w") in self.w:
             res = hip.gemm(x.view(nb * h * ww, cin), self.w[p + ".conv_shortcut.w"], self.w[p + ".conv_shortcut.bias"])
             res = res.view(nb, h, ww, -1)
-        return self._gn_silu_conv(p + ".norm2", p + ".conv2", hdn, residual=res, stats=st)
+        return self._gn_silu_conv(p + ".norm2", p + ".conv2", hdn, residual=res, stats=st, next_pn=next_pn)
 
     def _mid_attention(self, x, a="decoder.mid_block.attentions.0"):
         if self._split_attention and self._dtype == torch.bfloat16 and x.shape[1] * x.shape[2] % 256 == 0 and x.shape[1] * x.shape[2] <= 8192:
@@ -291,7 +303,8 @@ class AutoencoderKL:
         st = None                                            # statistics of x written by the launch that produced it (the fused launches only)
         for i in range(4):
             for j in range(3):
-                x, st = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", x, st)
+                nxt = f"decoder.up_blocks.{i}.resnets.{j + 1}.norm1" if j < 2 else "decoder.conv_norm_out" if i == 3 else None
+                x, st = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", x, st, next_pn=nxt)
             if i != 3:
                 p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
                 x, st = hip.conv3x3(x, self.w[p + ".w"], self.w[p + ".bias"], upsample=True), None
