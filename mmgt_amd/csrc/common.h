@@ -6,6 +6,11 @@
 // Both use one fragment convention: lane (r = lane & 31, h = lane >> 5) holds 8 consecutive k values k = 8h .. 8h+7 of
 // row/column r for a K-step of 16.
 #pragma once
+// Cache policy of the kernels' OUTPUT stores (the `aux` field of a raw buffer store): 0 = default (the line stays dirty in the XCD's L2 until it is
+// evicted or the kernel's end writes it back), 16 = sc1 (write-through).  Experiment knob (make wt).
+#ifndef MMGT_ST_AUX
+#define MMGT_ST_AUX 0
+#endif
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdint.h>
@@ -183,3 +188,13 @@ void mmgt_set_error(const char* fmt, ...);
       return 2;                                                          \
     }                                                                    \
   } while (0)
+
+// 16-byte output store through a pointer with the cache policy of MMGT_ST_AUX (the asm form is invisible to hipcc's vmcnt bookkeeping: the
+// hardware still counts it, so compiler waits can only wait for more than they need)
+__device__ __forceinline__ void st_out16(void* p, u32x4 v) {
+#if MMGT_ST_AUX == 16
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<u32x4*>(p) = v;
+#endif
+}

@@ -53,7 +53,7 @@ __device__ __forceinline__ acc4 mma16(s16x8 a, s16x8 b, acc4 c) {
 // 3/4 the length; 12 288 x 1280 is 192 tiles (a quarter of the chip idle throughout), but exactly 256 tiles of 192 x 320.
 template <int MODE, int BN, int BM = 256>
 __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __restrict__ W, long bsw, Epi ep, int M, int N,
-                                                        int K, int tiles_m, int tiles_n, int pb, unsigned long long* trace) {
+                                                        int K, int tiles_m, int tiles_n, int pb_stg, unsigned long long* trace) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   typedef bf16_t T;
   static_assert(BN == 128 || BN == 256 || BN == 320, "BN");
@@ -68,6 +68,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
   auto swz = [](int row) { return (row >> 1) & 7; };
 
   const int nwg = tiles_m * tiles_n;
+  const int pb = pb_stg & 255, stg = pb_stg >> 8;   // stg: start delay of every second CU's workgroup (tune key g16_stagger, units of 8128 clocks / 16)
   const int bz = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2;                      // wave group: waves 0-3 / 4-7 (SIMD partners w, w + 4 are in different groups)
@@ -270,6 +271,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
     constexpr int N_ = decltype(Nc)::value;
     [&]<int... I>(std::integer_sequence<int, I...>) { (f(integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N_>{});
   };
+  if (stg && ((blockIdx.x >> 3) & 1))
+    for (int i = 0; i < stg; ++i) __builtin_amdgcn_s_sleep(8);
   // prologue: chunk 0 whole, the A half of chunk 1 (the A stream runs two chunks ahead of the MFMAs, the W stream one)
   if (total > 0) {
     if (wr == 0 && has_bias) issue_bias(blockIdx.x, blockIdx.x);   // (the post-scale bias of the first tile is issued again in its first chunk: harmless)
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
             const auto s01 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[0], x[1]), pack_bf16x2(y[0], y[1]), false, false);
             const auto s23 = __builtin_amdgcn_permlane16_swap(pack_bf16x2(x[2], x[3]), pack_bf16x2(y[2], y[3]), false, false);
             if (m < M && 32 * jp < ncol)
-              *reinterpret_cast<u32x4*>(orow + (GEGLU ? 16 * jp : 32 * jp)) = (u32x4){s01[0], s23[0], s01[1], s23[1]};
+              st_out16(orow + (GEGLU ? 16 * jp : 32 * jp), (u32x4){s01[0], s23[0], s01[1], s23[1]});
             continue;
           }
           float o8[8];
@@ -494,8 +497,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
             for (int e = 0; e < 8; ++e) o8[e] += bf16_to_f32(r8.e[e]);
           }
           if (m < M && 32 * jp < ncol)
-            *reinterpret_cast<u32x4*>(orow + (GEGLU ? 16 * jp : 32 * jp)) =
-                (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])};
+            st_out16(orow + (GEGLU ? 16 * jp : 32 * jp),
+                     (u32x4){pack_bf16x2(o8[0], o8[1]), pack_bf16x2(o8[2], o8[3]), pack_bf16x2(o8[4], o8[5]), pack_bf16x2(o8[6], o8[7])});
         }
       }
     };
@@ -532,6 +535,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
 }
 
 unsigned long long* g_trace = nullptr;
+int g_stg = -1;   // mmgt_tune("g16_stagger", v): start delay of every second CU's workgroup in units of 512 clocks (-1 = by shape)
 int g_pb = -1;   // mmgt_tune("g16_pb", v): row panels per column-major group of the tile order (-1 = by shape, 1 = row-major)
 
 template <int MODE, int BN, int BM = 256>
@@ -560,7 +564,10 @@ int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int
   dim3 grid((unsigned)gx, 1, batch);
   // (measured, tools/ab_cfg.py G16_PB=1,4,8: see DESIGN.md; convs and narrow outputs keep the row-major order)
   const int pb = g_pb >= 0 ? g_pb : (MODE == 0 && tiles_n >= 8 && tiles_m >= 8) ? 8 : 1;
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, ad, reinterpret_cast<const char*>(W), bsw, ep, M, N, K, tiles_m, tiles_n, pb, g_trace);
+  // Short reductions with a residual epilogue spend as long in the tile end (residual in, tile out: HBM) as in the loop, and every workgroup of
+  // the chip gets there at the same time: half of them start ~2.5 us late (profiles/r6/bench_shortk_r6.txt: -7 ... -10 % on K = 320 / 640)
+  const int stg = g_stg >= 0 ? g_stg : (MODE == 0 && ep.residual && !ad.ksplit && K <= 1280) ? 10 : 0;
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, ad, reinterpret_cast<const char*>(W), bsw, ep, M, N, K, tiles_m, tiles_n, pb | (stg << 8), g_trace);
   MMGT_LAUNCH_CHECK();
   return 0;
 }
@@ -570,6 +577,7 @@ int launch16(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int
 // Debug (tools/trace_gemm16.py): a device buffer of [grid][32 tiles][2 groups][4 stamps] u64 receives 100-MHz time stamps.
 extern "C" void mmgt_gemm16_set_trace(void* p) { g_trace = reinterpret_cast<unsigned long long*>(p); }
 void mmgt_gemm16_set_pb(int v) { g_pb = v; }
+void mmgt_gemm16_set_stagger(int v) { g_stg = v; }
 
 namespace {
 

@@ -503,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
           rc_for<0, RT>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
             const u32x4 pk = out8(ic, jpc, rv[jp & 1][RES ? i : 0]);
-            __builtin_amdgcn_raw_buffer_store_b128(pk, rO, (int)eoff + i * erow + 64 * jp, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rO, (int)eoff + i * erow + 64 * jp, 0, MMGT_ST_AUX);
             float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[2 * e] = rc_lo(pk[e]); v[2 * e + 1] = rc_hi(pk[e]); }
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
         }
         const u32x4 pk = out8(std::integral_constant<int, i>{}, std::integral_constant<int, jp>{}, rv[i & 1][RES ? jp : 0]);
         // (the row offset rides in the VECTOR offset, not in soffset: see csrc/gnconv.hip -- the store-data hazard tools/check_mfma_overlap.py scans for)
-        if (!(abl & 16) || pk[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(pk, rO, (int)eoff + i * erow + 64 * jp, 0, 0);
+        if (!(abl & 16) || pk[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(pk, rO, (int)eoff + i * erow + 64 * jp, 0, MMGT_ST_AUX);
         __builtin_amdgcn_sched_barrier(0);
       });
       }
@@ -582,32 +582,35 @@ __global__ __launch_bounds__(512, 2) void rconv_kernel(const RcArgs a) {
 __global__ __launch_bounds__(256) void rconv_stats_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    float* __restrict__ scale, float* __restrict__ shift, int nb, int ppi, int C, int G, float cnt,
                                                                    float eps) {
-  __shared__ float pn[8][64], pm[8][64], pq[8][64];
-  const int n = blockIdx.x, g = threadIdx.x % G, run = threadIdx.x / G, nrun = 256 / G, cpg = C / G;
+  // a workgroup = one image x 8 groups, 32 runs per group (48 x 4 workgroups at the step's shapes: a fold is a chain of dependent updates, short chains)
+  constexpr int GPB = 8, NRUN = 256 / GPB;
+  __shared__ float pn[NRUN][GPB], pm[NRUN][GPB], pq[NRUN][GPB];
+  const int n = blockIdx.x, gl = threadIdx.x % GPB, g = blockIdx.y * GPB + gl, run = threadIdx.x / GPB, cpg = C / G;
   const long arr = (long)nb * ppi * C;
   float cn = 0.f, cm = 0.f, cq = 0.f;                      // count, mean, sum of squared deviations from the mean
   const float icnt = 1.f / cnt;
-  for (int p = run; p < ppi; p += nrun) {
-    const float* b = stats + ((long)n * ppi + p) * C + g * cpg;
-    for (int k = 0; k < cpg; ++k) {
-      const float s1 = b[arr + k], mb = b[k] + s1 * icnt, qb = fmaxf(b[2 * arr + k] - s1 * s1 * icnt, 0.f);
-      const float tot = cn + cnt, d = mb - cm, f = cnt / tot;
-      cm = fmaf(d, f, cm);
-      cq += qb + d * d * cn * f;
-      cn = tot;
-    }
-  }
-  pn[run][g] = cn;
-  pm[run][g] = cm;
-  pq[run][g] = cq;
-  __syncthreads();
-  if (run == 0) {
-    for (int r = 1; r < nrun; ++r) {
-      const float nb_ = pn[r][g];
-      if (nb_ > 0.f) {
-        const float tot = cn + nb_, d = pm[r][g] - cm, f = nb_ / tot;
+  if (g < G)
+    for (int p = run; p < ppi; p += NRUN) {
+      const float* b = stats + ((long)n * ppi + p) * C + g * cpg;
+      for (int k = 0; k < cpg; ++k) {
+        const float s1 = b[arr + k], mb = b[k] + s1 * icnt, qb = fmaxf(b[2 * arr + k] - s1 * s1 * icnt, 0.f);
+        const float tot = cn + cnt, d = mb - cm, f = cnt * __builtin_amdgcn_rcpf(tot);
         cm = fmaf(d, f, cm);
-        cq += pq[r][g] + d * d * cn * f;
+        cq += qb + d * d * cn * f;
+        cn = tot;
+      }
+    }
+  pn[run][gl] = cn;
+  pm[run][gl] = cm;
+  pq[run][gl] = cq;
+  __syncthreads();
+  if (run == 0 && g < G) {
+    for (int r = 1; r < NRUN; ++r) {
+      const float nb_ = pn[r][gl];
+      if (nb_ > 0.f) {
+        const float tot = cn + nb_, d = pm[r][gl] - cm, f = nb_ / tot;
+        cm = fmaf(d, f, cm);
+        cq += pq[r][gl] + d * d * cn * f;
         cn = tot;
       }
     }
@@ -758,8 +761,8 @@ extern "C" int mmgt_gn_silu_conv3x3_unet(const void* x0, int C0, const void* x1,
 extern "C" int mmgt_gn_stats_finalize_unet(const float* stats, const float* gamma, const float* beta, float* scale_shift, int nb, int parts_per_img, int count,
                                            int C, int G, float eps, void* stream) {
   MMGT_CHECK(stats && gamma && beta && scale_shift && nb > 0 && parts_per_img > 0 && count > 0, "gn_stats_finalize_unet: bad arguments");
-  MMGT_CHECK(G > 0 && G <= 64 && 256 % G == 0 && C % G == 0, "gn_stats_finalize_unet: unsupported C = %d, G = %d", C, G);
-  hipLaunchKernelGGL(rconv_stats_finalize_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta, scale_shift, scale_shift + (long)nb * C, nb,
+  MMGT_CHECK(G > 0 && G <= 64 && C % G == 0, "gn_stats_finalize_unet: unsupported C = %d, G = %d", C, G);
+  hipLaunchKernelGGL(rconv_stats_finalize_kernel, dim3(nb, (G + 7) / 8), dim3(256), 0, (hipStream_t)stream, stats, gamma, beta, scale_shift, scale_shift + (long)nb * C, nb,
                      parts_per_img, C, G, (float)count, eps);
   MMGT_LAUNCH_CHECK();
   return 0;

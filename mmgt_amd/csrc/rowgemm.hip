@@ -243,8 +243,8 @@ void rowgemm320_kernel(const RowGemmArgs a) {
             pkv[0][e] = sw[0];
             pkv[1][e] = sw[1];
           }
-          __builtin_amdgcn_raw_buffer_store_b128(pkv[0], ro, (int)(obase + 2u * (32 * t)), 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(pkv[1], ro, (int)(obase + ostep16 + 2u * (32 * t)), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(pkv[0], ro, (int)(obase + 2u * (32 * t)), 0, MMGT_ST_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(pkv[1], ro, (int)(obase + ostep16 + 2u * (32 * t)), 0, MMGT_ST_AUX);
         } else {
           *reinterpret_cast<u32x4*>(ot + (long)(32 * (t - nt1)) * a.npad) = pkv[0];
           *reinterpret_cast<u32x4*>(ot + (long)(32 * (t - nt1)) * a.npad + 16) = pkv[1];

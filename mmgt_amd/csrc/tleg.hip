@@ -490,7 +490,7 @@ void tleg320_kernel(const TlegArgs a) {
         // (the chunk's column offset rides in the VECTOR offset: with a register in soffset hipcc does not keep the wait states between a 16-byte
         //  store and the next write of its data registers, and MI355X then stores the overwritten values in lanes 12 .. 15 of every 16-lane
         //  row -- found in csrc/gnconv.hip, round 5; tools/check_mfma_overlap.py scans every object of the library for the pattern)
-        if (!(ABL & 8) || pk[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(pk, ro, (int)(rowoff[rt] + 2 * cofs + 64 * oc), 0, 0);
+        if (!(ABL & 8) || pk[0] == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b128(pk, ro, (int)(rowoff[rt] + 2 * cofs + 64 * oc), 0, MMGT_ST_AUX);
       }
     }
   }

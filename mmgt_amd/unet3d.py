@@ -121,6 +121,7 @@ class UNet3DConditionModel:
         self._fuse_oz = bool(hip.tune_get("oz3"))                 # 0: the three masked audio out-projections as separate launches
         self._fuse_ln = bool(hip.tune_get("rowgemm"))             # 0: LayerNorm and q / k / v GEMMs as separate launches
         self._fuse_tleg = bool(hip.tune_get("tleg"))              # 0: a level-0 temporal-attention leg as three launches
+        self._tables = None                                       # (reader key, data_ptr, images, (scale, shift)): GroupNorm tables handed from a conv's epilogue to the norm's reader
         self._rconv_stats = bool(hip.tune_get("rconv_stats"))     # a fused leg's output statistics from its epilogue instead of a pass over the tensor
         self._rconv = hip.tune_get("rconv")                        # resnets whose GroupNorm -> SiLU -> conv3x3 legs run as one launch (csrc/rconv.hip): a mask of
                                                                    # 1 the 320-wide level, 2 the 640-wide level, 4 the 1280-wide level (16 x 16 pixel tiles)
@@ -494,7 +495,11 @@ class UNet3DConditionModel:
         n = h * ww
         img = self.w.get(p + ".proj_in.img")
         if img is not None and n > 256 and n % 128 == 0:
-            sc, sh = hip.groupnorm_affine(x.view(nb, n, c), self.w[p + ".norm.g"], self.w[p + ".norm.b"], 32, 1e-6)
+            kept, self._tables = self._tables, None
+            if kept is not None and kept[0] == p + ".norm" and kept[1] == x.data_ptr() and kept[2] == nb:
+                sc, sh = kept[3]          # from the epilogue of the conv that wrote x (`_resnet`, reader=)
+            else:
+                sc, sh = hip.groupnorm_affine(x.view(nb, n, c), self.w[p + ".norm.g"], self.w[p + ".norm.b"], 32, 1e-6)
             return hip.rowgemm320(x.view(nb * n, c), img, self.w[p + ".proj_in.w"].shape[0], self.w.get(p + ".proj_in.bias"),
                                   pre_scale=sc, pre_shift=sh, pre_rows=n)[0]
         xn = self._gn(p + ".norm", x, 1e-6)
@@ -510,8 +515,10 @@ class UNet3DConditionModel:
         hid = self._norm_ff(p, norm, hid)
         return hip.gemm(hid, self.w[q + ".proj_out.w"], self.w.get(q + ".proj_out.bias"), residual=x_res)
 
-    def _resnet(self, p, x, temb, skip=None, out=None):
-        """ResnetBlock3D (resnet.py:217-247); `skip` = the UNet skip tensor that the reference concatenates first."""
+    def _resnet(self, p, x, temb, skip=None, out=None, reader=None):
+        """ResnetBlock3D (resnet.py:217-247); `skip` = the UNet skip tensor that the reference concatenates first.  reader: key of the
+        GroupNorm that reads the result next (a transformer block's `norm`): on the fused path its tables come out of conv2's epilogue
+        (`_norm_proj_in` picks them up from self._tables)."""
         nb, h, ww, c0 = x.shape
         hw = h * ww
         cout = self.spec[p + ".conv1.weight"][0]
@@ -549,6 +556,11 @@ class UNet3DConditionModel:
             assert skip is None
             res = x
         if fused:
+            if reader is not None and self._rconv_stats and hw > 256 and (reader.rsplit(".", 1)[0] + ".proj_in.img") in self.w:
+                y, tab = hip.gn_silu_conv3x3_unet(hdn, sc, sh, self.w[p + ".conv2.rimg"], cout, self.w[p + ".conv2.bias"], residual=res, out=out,
+                                                  next_norm=(self.w[reader + ".g"], self.w[reader + ".b"], 32, 1e-6))
+                self._tables = (reader, y.data_ptr(), nb, tab)
+                return y
             return hip.gn_silu_conv3x3_unet(hdn, sc, sh, self.w[p + ".conv2.rimg"], cout, self.w[p + ".conv2.bias"], residual=res, out=out)
         return hip.conv3x3(hdn, self.w[p + ".conv2.w"], self.w[p + ".conv2.bias"], residual=res, out=out)
 
@@ -914,11 +926,11 @@ class UNet3DConditionModel:
                 if shared and i == 0 and j == 0:
                     r = f"{p}.resnets.0"
                     x2 = torch.empty((2 * f,) + tuple(x.shape[1:3]) + (self.spec[r + ".conv1.weight"][0],), device=self._device, dtype=self._dtype)
-                    x = self._resnet(r, x, {r: temb[r][:1]}, out=x2[:f])
+                    x = self._resnet(r, x, {r: temb[r][:1]}, out=x2[:f], reader=f"{p}.attentions.0.norm" if self._twin else None)
                     x2[f:].copy_(x)
                     x = x2
                 else:
-                    x = self._resnet(f"{p}.resnets.{j}", x, temb)
+                    x = self._resnet(f"{p}.resnets.{j}", x, temb, reader=f"{p}.attentions.{j}.norm" if i < 3 else None)
                 if i < 3:
                     y = self._spatial_transformer_twin(f"{p}.attentions.{j}", x, ehs, f) if (shared and i == 0 and j == 0 and self._twin) else None
                     x = y if y is not None else self._spatial_transformer(f"{p}.attentions.{j}", x, ehs, f, cfg_row=cfg_row)
@@ -938,7 +950,7 @@ class UNet3DConditionModel:
         for i in range(4):
             p = f"up_blocks.{i}"
             for j in range(lpb + 1):
-                x = self._resnet(f"{p}.resnets.{j}", x, temb, skip=skips.pop())
+                x = self._resnet(f"{p}.resnets.{j}", x, temb, skip=skips.pop(), reader=f"{p}.attentions.{j}.norm" if i > 0 else None)
                 if i > 0:
                     x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs, f, cfg_row=cfg_row)
                 x = self._motion_module(f"{p}.motion_modules.{j}", x, f)

@@ -329,6 +329,26 @@ def test_gemm16_blocked_tile_order_is_a_permutation(M, N):
     torch.testing.assert_close(row_major.double(), ref_gemm(a, w) + b.double(), **tol(torch.bfloat16))
 
 
+def test_gemm16_start_stagger_changes_no_result():
+    """Every second CU's workgroup of a short reduction with a residual epilogue starts late (csrc/gemm16.hip `stg`: the chip is then not in
+    the tile-end phase all at once): timing only -- the result is bitwise that of the unstaggered launch, for the shape rule's default too."""
+    from mmgt_amd import hip
+    M, N, K = 192 * 17 + 5, 640, 640
+    a = rnd("stg.a", (M, K), 1.0, torch.bfloat16)
+    w = rnd("stg.w", (N, K), K ** -0.5, torch.bfloat16)
+    b = rnd("stg.b", (N,), 0.5)
+    r = rnd("stg.r", (M, N), 1.0, torch.bfloat16)
+    outs = []
+    try:
+        for v in (0, 10, 40, -1):
+            hip.tune("g16_stagger", v)
+            outs.append(hip.gemm(a, w, b, residual=r))
+    finally:
+        hip.tune("g16_stagger", -1)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    torch.testing.assert_close(outs[0].double(), ref_gemm(a, w) + b.double() + r.double(), **tol(torch.bfloat16))
+
+
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("c,hw,silu", [(128, 16384, True), (256, 4096, True), (512, 4096, False), (256, 1024, True), (128, 4100, True),
                                        (320, 4096, True), (320, 1024, False), (448, 2048, True)])

@@ -249,6 +249,35 @@ def test_unet_full_resolution_512x512_six_frames(full_sd, golden_dir):
     assert d16.max() <= FLOOR_SLACK * fmax and d16.mean() <= FLOOR_SLACK * fmean
 
 
+def test_groupnorm_tables_from_conv_epilogues_512x512_six_frames(full_sd, golden_dir):
+    """The GroupNorm tables that come out of a fused conv's epilogue (csrc/rconv.hip: conv1 -> the resnet's norm2, conv2 -> the `norm` of
+    the transformer block that reads the resnet's output) against the same forward with a statistics pass over every tensor
+    (`rconv_stats` = 0): both within the bf16 floor of the oracle, and the folds must have been the path taken (counted: 10 resnets on
+    the fused launch + the 5 level-0 transformer norms)."""
+    from mmgt_amd import hip
+    sd_gpu, sd_cpu = full_sd
+    case = SIX_FRAME_CASE
+    ref = cached("unet_512x512_six_frames", lambda: _run_oracle(sd_cpu, case))
+    fmax, fmean = _floor_cfg2(golden_dir)
+    n0 = hip.call_count("mmgt_gn_stats_finalize_unet")
+    out = _run_hip(sd_gpu, case, torch.bfloat16)
+    folds = hip.call_count("mmgt_gn_stats_finalize_unet") - n0
+    assert folds == 15, f"{folds} GroupNorm tables came from conv epilogues (15 expected)"
+    try:
+        hip.tune("rconv_stats", 0)
+        n0 = hip.call_count("mmgt_gn_stats_finalize_unet")
+        passes = _run_hip(sd_gpu, case, torch.bfloat16)
+        assert hip.call_count("mmgt_gn_stats_finalize_unet") == n0
+    finally:
+        hip.tune("rconv_stats", 1)
+    for o in (out, passes):
+        d = (o - ref).abs()
+        assert d.max() <= FLOOR_SLACK * fmax and d.mean() <= FLOOR_SLACK * fmean
+    d = (out - passes).abs()
+    print(f"epilogue statistics against passes: max|d| {d.max().item():.3e} mean|d| {d.mean().item():.3e}")
+    assert d.mean() <= fmean
+
+
 TWELVE_FRAME_CASE = dict(gc.UNET_CASES["full_cfg1"], frames=12, latent=64, timestep=499)
 
 

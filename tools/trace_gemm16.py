@@ -17,6 +17,10 @@ cases = [(16, gemm_case(196608, 1280, 320)), (16, gemm_case(196608, 2560, 320, a
 if os.environ.get("SET") == "l1":          # the level-1 / level-2 shapes of the step (K = 640 .. 5120)
     cases = [(16, gemm_case(49152, 5120, 640, act=1)), (16, gemm_case(12288, 10240, 1280, act=1)), (16, gemm_case(12288, 1280, 5120, res=True)),
              (17, gemm_case(49152, 640, 2560, res=True)), (16, gemm_case(49152, 1920, 640, bias=False))]
+if os.environ.get("SET") == "short":       # the short reductions with a residual epilogue (tile end = residual in + tile out); STG = start stagger
+    cases = [(0, gemm_case(49152, 640, 640, res=True)), (0, gemm_case(49152, 640, 640)), (0, gemm_case(12288, 1280, 1280, res=True)),
+             (0, gemm_case(196608, 320, 320, res=True)), (0, gemm_case(49152, 640, 2560, res=True))]
+    hip.tune("g16_stagger", int(os.environ.get("STG", "-1")))
 for cfg, (name, fn, flops, out) in cases:
     hip.tune("gemm_cfg", cfg)
     t_us = min(time_call(fn) for _ in range(3))
