@@ -930,6 +930,7 @@ void mmgt_gemm16_set_stagger(int v);
 void mmgt_gn_set_interleave(int v);
 void mmgt_gn_set_lpr0(int v);
 void mmgt_gn_set_narrow(int v);
+void mmgt_gn_set_slab(int v);
 void mmgt_ffn_set_dbg(int v);
 void mmgt_rowgemm_set_dbg(int v);
 void mmgt_tleg_set_abl(int v);
@@ -976,6 +977,7 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "gn_rows")) { mmgt_gn_set_rows(value); return 0; }
   if (key && !strcmp(key, "gn_interleave")) { mmgt_gn_set_interleave(value); return 0; }
   if (key && !strcmp(key, "gn_narrow")) { mmgt_gn_set_narrow(value); return 0; }
+  if (key && !strcmp(key, "gn_slab")) { mmgt_gn_set_slab(value); return 0; }
   if (key && !strcmp(key, "gn_lpr0")) { if (value != 4 && value != 8 && value != 16) return -1; mmgt_gn_set_lpr0(value); return 0; }
   if (key && !strcmp(key, "splitk")) { g_splitk = value; return 0; }
   if (key && !strcmp(key, "bm192")) { g_bm192 = value; return 0; }

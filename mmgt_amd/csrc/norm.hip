@@ -12,6 +12,7 @@ int g_gn_interleave = -1;   // mmgt_tune("gn_interleave", v): -1 = the default (
 int g_gn_lpr0 = 8;          // mmgt_tune("gn_lpr0", v): smallest lanes-per-row tried (benchmarking only)
 int g_gn_narrow = 2;        // mmgt_tune("gn_narrow", v): 0 = the general two-pass kernels for every shape, 1 = lane-per-vector kernels where the
                             // vectors of a row divide 64 (the VAE), 2 = also for 33..64 vectors, one row per wave (C = 320) (A/B)
+int g_gn_slab = 1;        // mmgt_tune("gn_slab", 0 / 1): the register-resident single-read kernel where a slab fits (A/B)
 int g_gn_rows = 0;   // mmgt_tune("gn_rows", v): force the rows per workgroup (0 = the measured choice below; benchmarking only)
 // Upper bound of the chunk count for an image of HW pixels: what callers size the workspace with (mmgt_groupnorm_chunks).
 inline int gn_chunks(int HW) {
@@ -468,6 +469,164 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x0,
   }
 }
 
+// ---- GroupNorm with the slab in REGISTERS: gn_small_kernel's workgroup (one image x `gpw` groups), thread mapping, arithmetic and reduction
+// orders -- bitwise its results -- but the slab is read from memory ONCE: thread (vector vc of a row, row r0 + i rp) keeps its <= NR vectors
+// (raw, 4 registers each) and makes the three passes over them.  gn_small_kernel pays three dependent memory round trips per launch, and
+// the two-kernel form (HW > 256) reads the tensor twice: 48 x 256 x 1280 took 31.6 us in the step and 48 x 1024 x 640 49.9 us, for 63 / 126 MB
+// moved (profiles/r6/opshapes_r6b.txt).  Slabs of up to 22 vectors per thread: every single-source level of the UNet below 64 x 64.
+template <typename T, int NR>
+__global__ __launch_bounds__(256) void gn_slab_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      T* __restrict__ out, int HW, int G, int gpw, float eps, int silu,
+                                                      float* __restrict__ tscale, float* __restrict__ tshift) {
+  constexpr int VEC = VecIO<T>::VEC;
+  __shared__ float part[256 * VEC];
+  __shared__ float chan[320];
+  __shared__ float gstat[2][4];
+  const int C = C0 + C1, cg = C / G, cw = gpw * cg, nvw = cw / VEC;
+  // The slabs of one image share their 128-byte lines (a slab's pixel is cw * sizeof(T) = 40 .. 320 bytes of a C * sizeof(T) row): workgroups are
+  // dealt to the XCDs round-robin, so the linear id is turned into a virtual one whose consecutive values sit on ONE XCD -- an image's slabs then
+  // fetch each line into one L2, at about the same time (as csrc/gemm16.hip's tile order).
+  int n = blockIdx.y, sl = blockIdx.x;
+  {
+    const int nsl = gridDim.x, tot = nsl * gridDim.y;
+    if ((tot & 7) == 0) {
+      const int lin = blockIdx.y * nsl + blockIdx.x, v = (lin & 7) * (tot >> 3) + (lin >> 3);
+      n = v / nsl;
+      sl = v - n * nsl;
+    }
+  }
+  const int c_lo = sl * cw;
+  const int tid = threadIdx.x;
+  const int rp = 256 / nvw;                 // rows per pass
+  const int vc = tid % nvw, r0 = tid / nvw;
+  const bool active = r0 < rp;
+  const int c = c_lo + vc * VEC;
+  const T* src = c < C0 ? x0 + (long)n * HW * C0 + c : x1 + (long)n * HW * C1 + (c - C0);
+  const long rstride = c < C0 ? C0 : C1;
+  int gid[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) gid[e] = (vc * VEC + e) / cg;
+
+  u32x4 raw[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int r = r0 + i * rp;
+    raw[i] = (active && r < HW) ? *reinterpret_cast<const u32x4*>(src + r * rstride) : (u32x4)(0u);
+  }
+  auto dec = [](const u32x4& u, float* f) {
+    union { u32x4 u; T e[VEC]; } v;
+    v.u = u;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) f[e] = Elem<T>::ld(&v.e[e]);
+  };
+  auto reduce = [&](const float (&acc)[VEC], int which) {   // (gn_small_kernel's, order for order)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) part[tid * VEC + e] = active ? acc[e] : 0.f;
+    __syncthreads();
+    for (int ch = tid; ch < cw; ch += 256) {
+      const int v = ch / VEC, e = ch % VEC;
+      float s = 0.f;
+      for (int r = 0; r < rp; ++r) s += part[(r * nvw + v) * VEC + e];
+      chan[ch] = s;
+    }
+    __syncthreads();
+    if (tid < gpw) {
+      float s = 0.f;
+      for (int k = 0; k < cg; ++k) s += chan[tid * cg + k];
+      gstat[which][tid] = s;
+    }
+    __syncthreads();
+  };
+
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+    if (active && r0 + i * rp < HW) {
+      float f[VEC];
+      dec(raw[i], f);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += f[e];
+    }
+  reduce(acc, 0);
+  const float cnt = (float)HW * (float)cg;
+  float mean[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { mean[e] = gstat[0][gid[e]] / cnt; acc[e] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < NR; ++i)
+    if (active && r0 + i * rp < HW) {
+      float f[VEC];
+      dec(raw[i], f);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { const float d = f[e] - mean[e]; acc[e] += d * d; }
+    }
+  reduce(acc, 1);
+  if (active) {
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float rstd = rsqrtf(gstat[1][gid[e]] / cnt + eps);
+      sc[e] = rstd * gamma[c + e];
+      sh[e] = beta[c + e] - mean[e] * sc[e];
+    }
+    if (tscale) {
+      if (r0 == 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { tscale[(long)n * C + c + e] = sc[e]; tshift[(long)n * C + c + e] = sh[e]; }
+      }
+      return;
+    }
+    T* dst = out + (long)n * HW * C + c;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int r = r0 + i * rp;
+      if (r < HW) {
+        float f[VEC];
+        dec(raw[i], f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float v = f[e] * sc[e] + sh[e];
+          f[e] = silu ? silu_f(v) : v;
+        }
+        VecIO<T>::store(dst + (long)r * C, f);
+      }
+    }
+  }
+}
+
+// the slab kernel's shape rule: whole vectors per slab, <= 22 vectors per thread; small slabs take as many groups as leave <= 6 vectors per thread
+// (a workgroup's fixed cost -- two reductions, six barriers -- is as long as a few of its loads: 48 x 64 x 1280 as 1536 one-group workgroups
+// 12.1 us, as 384 four-group ones see profiles/r6/bench_gn_slab_r6.txt), larger ones the fewest groups that fit; 0 = does not fit
+inline int gn_slab_gpw(int C, int G, int HW, int vec, int* nr) {
+  const int cg = C / G;
+  auto need = [&](int gpw) {
+    const int cw = gpw * cg;
+    if (G % gpw || cw % vec || cw > 320 || cw / vec > 256) return 1 << 30;
+    const int rp = 256 / (cw / vec);
+    return (HW + rp - 1) / rp;
+  };
+  int pick = 0;
+  for (int gpw = 4; gpw >= 1 && !pick; gpw >>= 1)
+    if (need(gpw) <= 6) pick = gpw;
+  for (int gpw = 1; gpw <= 4 && !pick; gpw <<= 1)
+    if (need(gpw) <= 22) pick = gpw;
+  if (!pick) return 0;
+  const int n = need(pick);
+  *nr = n <= 2 ? 2 : n <= 4 ? 4 : n <= 6 ? 6 : n <= 12 ? 12 : 22;
+  return pick;
+}
+template <typename T>
+void gn_slab_launch(int nr, dim3 grid, hipStream_t s, const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta, void* out, int HW,
+                    int G, int gpw, float eps, int silu, float* tscale, float* tshift) {
+#define GN_SLAB(NR_) hipLaunchKernelGGL((gn_slab_kernel<T, NR_>), grid, dim3(256), 0, s, (const T*)x0, C0, (const T*)x1, C1, gamma, beta, (T*)out, HW, G, gpw, eps, \
+                                        silu, tscale, tshift)
+  if (nr == 2) GN_SLAB(2); else if (nr == 4) GN_SLAB(4); else if (nr == 6) GN_SLAB(6); else if (nr == 12) GN_SLAB(12); else GN_SLAB(22);
+#undef GN_SLAB
+}
+
 // ---- LayerNorm: LPR lanes per row (8 .. 64, so all 64 lanes stream 16-byte vectors even at C = 320), the row slice in
 // registers, exact two-pass statistics, reductions by xor-shuffles inside the LPR-lane group ----
 template <typename T>
@@ -535,6 +694,7 @@ void mmgt_gn_set_rows(int v) { g_gn_rows = v; }
 void mmgt_gn_set_interleave(int v) { g_gn_interleave = v; }
 void mmgt_gn_set_lpr0(int v) { g_gn_lpr0 = v; }
 void mmgt_gn_set_narrow(int v) { g_gn_narrow = v; }
+void mmgt_gn_set_slab(int v) { g_gn_slab = v; }
 
 namespace {
 constexpr int GN_NARROW_U = 4;
@@ -567,6 +727,17 @@ extern "C" int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C
              "groupnorm: unsupported channels C0=%d C1=%d G=%d", C0, C1, G);
   MMGT_CHECK(NB > 0 && HW > 0 && NB <= 65535, "groupnorm: bad NB=%d HW=%d", NB, HW);
   hipStream_t s = (hipStream_t)stream;
+  {
+    int nr = 0;
+    const int gpw = g_gn_slab ? gn_slab_gpw(C, G, HW, vec, &nr) : 0;
+    if (gpw) {
+      dim3 grid(G / gpw, NB);
+      if (dtype == MMGT_BF16) gn_slab_launch<bf16_t>(nr, grid, s, x0, C0, x1, C1, gamma, beta, out, HW, G, gpw, eps, silu, nullptr, nullptr);
+      else gn_slab_launch<float>(nr, grid, s, x0, C0, x1, C1, gamma, beta, out, HW, G, gpw, eps, silu, nullptr, nullptr);
+      MMGT_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   {
     const int cg = C / G;
     // 4 groups per workgroup on the 8x8 level, 2 on the 16x16 level (more, shorter slabs: the passes are latency-bound)
@@ -638,6 +809,17 @@ extern "C" int mmgt_groupnorm_affine2(const void* x, int C0, const void* x1, int
   MMGT_CHECK(C <= GN_MAXC && C % G == 0 && G <= 64 && C0 % vec == 0 && C1 % vec == 0, "groupnorm_affine: unsupported channels C=%d + %d G=%d", C0, C1, G);
   MMGT_CHECK(NB > 0 && HW > 0 && NB <= 65535, "groupnorm_affine: bad NB=%d HW=%d", NB, HW);
   hipStream_t s = (hipStream_t)stream;
+  {
+    int nr = 0;
+    const int gpw = g_gn_slab ? gn_slab_gpw(C, G, HW, vec, &nr) : 0;      // the slab in registers: one read of the tensor, tables out
+    if (gpw) {
+      dim3 grid(G / gpw, NB);
+      if (dtype == MMGT_BF16) gn_slab_launch<bf16_t>(nr, grid, s, x, C0, x1, C1, gamma, beta, nullptr, HW, G, gpw, eps, 0, scale, shift);
+      else gn_slab_launch<float>(nr, grid, s, x, C0, x1, C1, gamma, beta, nullptr, HW, G, gpw, eps, 0, scale, shift);
+      MMGT_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   {
     // small images (the 16 x 16 and 8 x 8 levels): the single-launch kernel's two statistics passes, tables out (see mmgt_groupnorm_nhwc)
     const int cg = C / G;

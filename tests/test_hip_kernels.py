@@ -375,6 +375,44 @@ def test_groupnorm_narrow_rows(dt, c, hw, silu):
     torch.testing.assert_close(out.double(), general.double(), **tol(dt))
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("nb,c0,c1,hw,silu", [(8, 640, 0, 1024, False), (3, 640, 640, 1024, True), (8, 320, 0, 1024, True), (8, 1280, 0, 256, False),
+                                              (3, 1280, 1280, 256, True), (8, 1280, 0, 64, True), (3, 1280, 1280, 64, True), (5, 640, 0, 900, True),
+                                              (8, 640, 0, 64, False), (2, 2560, 0, 16, True)])
+def test_groupnorm_slab_in_registers(dt, nb, c0, c1, hw, silu):
+    """csrc/norm.hip gn_slab_kernel: a workgroup = one image x 1 / 2 / 4 groups keeps its slab in registers (2 .. 22 vectors per thread: every
+    instantiation is hit here, both element types, one and two sources, ragged row counts, grids that are and are not a multiple of the 8
+    XCDs) and reads the tensor once.  Against torch in fp64 (values whose mean is 10 x their spread), against the multi-pass kernels it
+    replaces on the same input, bitwise repeatable; the statistics-only entry (`groupnorm_affine`) against the tables of the full op."""
+    from mmgt_amd import hip
+    C = c0 + c1
+    x = rnd("slab.x", (nb, hw, C), 1.3, dt) + (10.0 * rnd("slab.mean", (C,), 1.0)).to(dt)
+    x0, x1 = (x[..., :c0].contiguous(), x[..., c0:].contiguous()) if c1 else (x, None)
+    g = rnd("g", (C,), 0.2) + 1.0
+    b = rnd("b", (C,), 0.2)
+    ref = F.group_norm(x.double().permute(0, 2, 1), 32, g.double(), b.double(), 1e-5).permute(0, 2, 1)
+    plain = ref
+    if silu:
+        ref = F.silu(ref)
+    n0 = hip.call_count("mmgt_groupnorm_nhwc")
+    out = hip.groupnorm(x0, g, b, 32, 1e-5, silu=silu, x1=x1)
+    assert hip.call_count("mmgt_groupnorm_nhwc") == n0 + 1
+    t = dict(rtol=1e-3, atol=2e-4) if dt == torch.float32 else tol(dt)
+    torch.testing.assert_close(out.double(), ref, **t)
+    assert torch.equal(out, hip.groupnorm(x0, g, b, 32, 1e-5, silu=silu, x1=x1))
+    sc, sh = hip.groupnorm_affine(x0, g, b, 32, 1e-5, x1=x1)
+    hip.tune("gn_slab", 0)
+    try:
+        passes = hip.groupnorm(x0, g, b, 32, 1e-5, silu=silu, x1=x1)
+        sc0, sh0 = hip.groupnorm_affine(x0, g, b, 32, 1e-5, x1=x1)
+    finally:
+        hip.tune("gn_slab", 1)
+    torch.testing.assert_close(out.double(), passes.double(), **t)
+    torch.testing.assert_close(sc, sc0, rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(sh, sh0, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close((x.double() * sc.double()[:, None] + sh.double()[:, None]), plain, rtol=1e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize("c0,c1,hw,eps", [(320, 0, 4096, 1e-5), (640, 320, 1024, 1e-5), (512, 0, 4096, 1e-6), (1280, 0, 64, 1e-6),
                                           (128, 0, 8192, 1e-6), (256, 0, 4096, 1e-6)])
 def test_groupnorm_mean_much_larger_than_std_fp32(c0, c1, hw, eps):
