@@ -482,6 +482,7 @@ int g_attn64 = 1;   // mmgt_tune("attn64", 0 / 1): the 64-queries-per-wave kerne
 
 }  // namespace
 int mmgt_attn64_launch(const void* params, int batch, int heads, void* stream);
+int mmgt_attn80_launch(const void* params, int batch, int heads, void* stream);   // attn80.hip (-1: switched off)
 void mmgt_attn_set64(int v) { g_attn64 = v; }
 void mmgt_attn_set_heads_inner(int v) { g_heads_inner = v; }
 namespace {
@@ -505,6 +506,10 @@ int launch_hd(AttnParams p, int batch, int heads, int vt, hipStream_t s) {
     const bool whole = p.nk % 64 == 0 && p.nk2 % 64 == 0;
     if (std::is_same<T, bf16_t>::value && HD == 40 && vt && whole && p.nq % 256 == 0 && g_attn64 && !p.out_scale)
       return mmgt_attn64_launch(&p, batch, heads, s);
+    if (std::is_same<T, bf16_t>::value && HD == 80 && vt && whole && p.nq % 256 == 0 && !p.out_scale && !p.o_twin) {
+      const int rc = mmgt_attn80_launch(&p, batch, heads, s);       // (-1: switched off)
+      if (rc >= 0) return rc;
+    }
     if (vt && whole) hipLaunchKernelGGL((attn_kernel<T, HD, 4, true, 64, false>), grid, dim3(256), 0, s, p);
     else if (vt) hipLaunchKernelGGL((attn_kernel<T, HD, 4, true, 64>), grid, dim3(256), 0, s, p);
     else if (short_keys) hipLaunchKernelGGL((attn_kernel<T, HD, 4, false, 32>), grid, dim3(256), 0, s, p);

@@ -403,6 +403,7 @@ int g_attn_nomax = 1;   // mmgt_tune("attn_nomax", 0 / 1): the kernel without th
 }  // namespace
 
 void mmgt_attn_set_nomax(int v) { g_attn_nomax = v; }
+int mmgt_attn_get_nomax() { return g_attn_nomax; }
 
 // attention.hip's dispatcher: bf16, head_dim 40, V transposed, nq % 256 == 0, nk % 64 == 0, nk2 % 64 == 0
 int mmgt_attn64_launch(const void* params, int batch, int heads, void* stream) {

@@ -924,6 +924,7 @@ int check_common(int dtype, int M, int N, int K, int act) {
 void mmgt_attn_set64(int v);
 void mmgt_gn_set_rows(int v);
 void mmgt_attn_set_heads_inner(int v);
+void mmgt_attn_set_attn80(int v);
 void mmgt_attn_set_nomax(int v);
 void mmgt_gemm16_set_pb(int v);
 void mmgt_gemm16_set_stagger(int v);
@@ -972,6 +973,7 @@ extern "C" int mmgt_tune(const char* key, int value) {
   if (key && !strcmp(key, "attn64")) { mmgt_attn_set64(value); return 0; }
   if (key && !strcmp(key, "attn_nomax") && (value == 0 || value == 1)) { mmgt_attn_set_nomax(value); return 0; }
   if (key && !strcmp(key, "attn_heads_inner")) { mmgt_attn_set_heads_inner(value); return 0; }
+  if (key && !strcmp(key, "attn80")) { mmgt_attn_set_attn80(value); return 0; }
   if (key && !strcmp(key, "g16_pb")) { mmgt_gemm16_set_pb(value); return 0; }
   if (key && !strcmp(key, "g16_stagger")) { mmgt_gemm16_set_stagger(value); return 0; }
   if (key && !strcmp(key, "gn_rows")) { mmgt_gn_set_rows(value); return 0; }

@@ -616,6 +616,58 @@ def test_attention_without_running_maximum_and_its_overflow_guard():
     assert torch.equal(run(1), fast)                        # repeatable
 
 
+@pytest.mark.parametrize("heads,B,nq,nk2", [(2, 4, 512, 256), (8, 2, 256, 0), (3, 4, 256, 64), (8, 8, 1024, 1024)])
+def test_attention_head_dim_80_dma_staged(heads, B, nq, nk2):
+    """csrc/attn80.hip (head_dim 80, the 32 x 32 level: LDS-DMA staged tiles, eight 32-query waves per workgroup, no running maximum in the fast
+    pass) against torch in fp64 and against attention.hip's register-staged kernel (mmgt_tune "attn80" = 0) on the same operands: with and
+    without the bank segment, pair counts that are and are not a multiple of the 8 XCDs, rows whose maximum jumps mid-sequence, and a key 2^170
+    above a row's reference (the guard re-runs that workgroup with the running maximum; no inf / NaN leaves the kernel); repeatable bitwise."""
+    from mmgt_amd import hip
+    dt = torch.bfloat16
+    hd = 80
+    inner = heads * hd
+    q = rnd("q80", (B, nq, inner), 1.0, dt)
+    k = rnd("k80", (B, nq, inner), 1.0, dt)
+    v = rnd("v80", (B, nq, inner), 1.0, dt)
+    kb = rnd("kb80", (2, max(nk2, 64), inner), 1.0, dt)
+    vb = rnd("vb80", (2, max(nk2, 64), inner), 1.0, dt)
+    for tile, qrow in ((1, 5), (2, 77), (3, 200)):
+        k[:, 64 * tile + 9] = (q[:, qrow].float() * 4).to(dt)
+    k[1, 64 * 3 + 17] = (q[1, 130].float() * 40).to(dt)     # batch 1, query 130: far beyond 2^100 above its reference
+    scale = hd ** -0.5
+    split = lambda t: t.double().reshape(t.shape[0], t.shape[1], heads, hd).permute(0, 2, 1, 3)
+    bdiv2 = max(3 * B // 4, 1)                              # the kernel reads bank row b // k2_bdiv: the third quarter of the batch row 0, the last row 1
+    refs = []
+    for b in range(B):
+        kk, vv = k[b:b + 1], v[b:b + 1]
+        if nk2 and b >= B // 2:
+            kk = torch.cat([kk, kb[b // bdiv2][None, :nk2]], 1)
+            vv = torch.cat([vv, vb[b // bdiv2][None, :nk2]], 1)
+        refs.append(_ref_attn(split(q[b:b + 1]), split(kk), split(vv), scale))
+    ref = torch.cat(refs).permute(0, 2, 1, 3).reshape(B, nq, inner)
+    vT, vbT = v.transpose(1, 2).contiguous(), vb.transpose(1, 2).contiguous()
+    kw = dict(k2=kb, v2=vbT, k2_str=(kb.stride(0), inner), v2_str=(vbT.stride(0), vbT.stride(1)), k2_bdiv=bdiv2, nk2=nk2,
+              seg2_first_batch=B // 2) if nk2 else {}
+
+    def run(a80):
+        out = torch.full_like(q, float("nan"))
+        hip.tune("attn80", a80)
+        hip.attention(q, k, vT, out, batch=B, heads=heads, hd=hd, nq=nq, nk=nq, scale=scale, q_str=(nq * inner, 0, inner),
+                      k_str=(nq * inner, 0, inner), v_str=(vT.stride(0), 0, vT.stride(1)), o_str=(nq * inner, 0, inner), v_transposed=True, **kw)
+        return out
+    try:
+        base, new = run(0), run(1)
+        again = run(1)
+    finally:
+        hip.tune("attn80", 1)
+    assert torch.isfinite(new.float()).all()
+    torch.testing.assert_close(base.double(), ref, rtol=2e-2, atol=3e-2)
+    torch.testing.assert_close(new.double(), ref, rtol=2e-2, atol=3e-2)
+    assert torch.equal(new, again)
+    err_new, err_base = (new.double() - ref).abs().mean().item(), (base.double() - ref).abs().mean().item()
+    assert err_new <= 1.5 * err_base + 1e-5, (err_new, err_base)
+
+
 @pytest.mark.parametrize("a64", [0, 1])
 def test_attention_run_to_run_deterministic(a64):
     """Identical launches give bitwise identical results (a data race between the staging writes and the fragment reads of the

@@ -64,3 +64,15 @@ if __name__ == "__main__":
                 print(f"{name:32s} attn_nomax={nm} | {min(ts):8.1f}/{statistics.median(ts):8.1f} us {fl / min(ts) / 1e6:5.0f} TF", flush=True)
         print(f"    max|nomax - running max| = {(outs[1] - outs[0]).abs().max().item():.3e}", flush=True)
     hip.tune("attn_nomax", 1)
+    # head_dim 80 (the 32 x 32 level): attention.hip's register-staged kernel (attn80 = 0) against csrc/attn80.hip (1, the default), alternating
+    for name, run, fl, o in [case(1024, 640, 1024), case(1024, 640, 0)]:
+        outs = {}
+        for rnd_ in range(3):
+            for a80 in (0, 1):
+                hip.tune("attn80", a80)
+                t_us(run)
+                ts = [t_us(run) for _ in range(3)]
+                outs[a80] = o.float().clone()
+                print(f"{name:32s} attn80={a80} | {min(ts):8.1f}/{statistics.median(ts):8.1f} us {fl / min(ts) / 1e6:5.0f} TF", flush=True)
+        print(f"    max|attn80 - base| = {(outs[1] - outs[0]).abs().max().item():.3e}", flush=True)
+    hip.tune("attn80", 1)

@@ -149,8 +149,8 @@ def scan(obj):
 
 # objects whose kernels are built on MFMAs and 16-byte stores: the scan must FIND both in them -- a disassembler whose text no longer matches the
 # patterns above (or an empty build directory) must fail the check, not pass it vacuously
-MFMA_OBJECTS = ("gemm.o", "gemm16.o", "ffn.o", "rowgemm.o", "attention.o", "attn64.o", "tleg.o", "gnconv.o", "rconv.o")
-NO_WIDE_STORES = ("attn64.o",)          # (its outputs leave as 8-byte stores)
+MFMA_OBJECTS = ("gemm.o", "gemm16.o", "ffn.o", "rowgemm.o", "attention.o", "attn64.o", "attn80.o", "tleg.o", "gnconv.o", "rconv.o")
+NO_WIDE_STORES = ("attn64.o", "attn80.o")         # (its outputs leave as 8-byte stores)
 
 
 def main():
