@@ -301,6 +301,29 @@ def kernel_rooflines(unet, dev):
     by = 3.0 * M * C * 2
     out.append({"kernel": "groupnorm+silu 48x4096x320", "bound": "hbm", "ms": ms, "achieved": by / ms / 1e6, "peak": 8000.0,
                 "unit": "GB/s", "frac": by / ms / 1e6 / 8000.0})
+    del x3, xi
+    # GroupNorm of a level-1 transformer block (48 x 1024 x 640): the slab of one image x two groups in registers, one read + one write (csrc/norm.hip gn_slab_kernel)
+    x1 = hash_uniform("k.x1", (48, 1024, 640), 1.0, dev).to(dt)
+    g1_, b1_ = torch.ones(640, device=dev), torch.zeros(640, device=dev)
+    o1 = torch.empty_like(x1)
+    ms = _time_ms(lambda: hip.groupnorm(x1, g1_, b1_, 32, 1e-6, out=o1))
+    by = 2.0 * x1.numel() * 2
+    out.append({"kernel": "groupnorm 48x1024x640 (slab in registers: one read, one write)", "bound": "hbm", "ms": ms, "achieved": by / ms / 1e6, "peak": 8000.0,
+                "unit": "GB/s", "frac": by / ms / 1e6 / 8000.0})
+    del x1, o1
+    # spatial attention with bank at the 32 x 32 level, hd 80 (csrc/attn80.hip)
+    n1, c1 = 1024, 640
+    qk1 = hash_uniform("k.qk1", (48 * n1, 2 * c1), 1.0, dev).to(dt)
+    vt1 = hash_uniform("k.vt1", (48, c1, n1), 1.0, dev).to(dt)
+    kb1 = hash_uniform("k.kb1", (2, n1, c1), 1.0, dev).to(dt)
+    vbt1 = hash_uniform("k.vbt1", (2, c1, n1), 1.0, dev).to(dt)
+    oa = torch.empty((48 * n1, c1), device=dev, dtype=dt)
+    ms = _time_ms(lambda: hip.attention(qk1, qk1[:, c1:], vt1, oa, batch=48, heads=8, hd=80, nq=n1, nk=n1, scale=80 ** -0.5, q_str=(n1 * 2 * c1, 0, 2 * c1),
+                                        k_str=(n1 * 2 * c1, 0, 2 * c1), v_str=(c1 * n1, 0, n1), o_str=(n1 * c1, 0, c1), v_transposed=True, k2=kb1, v2=vbt1,
+                                        k2_str=(kb1.stride(0), kb1.stride(1)), v2_str=(vbt1.stride(0), vbt1.stride(1)), k2_bdiv=24, nk2=n1, seg2_first_batch=24))
+    fl = 4.0 * 8 * 80 * n1 * (24 * n1 + 24 * 2 * n1)
+    out.append({"kernel": "attention hd=80 nq=1024 nk=1024 (+1024 bank keys for the cond half)", "bound": "mfma", "ms": ms, "achieved": fl / ms / 1e9,
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / PEAK_BF16_TFLOPS})
     return out
 
 
