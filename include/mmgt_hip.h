@@ -45,6 +45,11 @@ const char* mmgt_last_error(void);
  *   "attn64"   = 1 (default) / 0: the 64-queries-per-wave spatial attention kernel at head_dim 40;
  *   "attn_nomax" = 1 (default) / 0: that kernel without the running maximum (the softmax reference stays what a row's first 32 keys set it to; a
  *                workgroup in which a denominator ends beyond 2^100 runs its tile loop again with the running maximum: csrc/attn64.hip);
+ *   "attn80"   = 1 (default) / 0: head_dim 80 on the LDS-DMA-staged kernel of csrc/attn80.hip (0: attention.hip's register-staged kernel);
+ *   "gn_slab"  = 1 (default) / 0: GroupNorm below the 64 x 64 level with the image x group slab in registers, one read of the tensor
+ *                (0: the multi-pass kernels);
+ *   "g16_stagger" = -1 (default: by shape) / 0 / n: every second CU's gemm16 workgroup starts n x 512 clocks late (short reductions with a
+ *                residual epilogue: the chip is then not in the tile-end phase all at once); timing only, results are bitwise the same;
  *   "gn_rows"  = 0 (default: measured choice) or the GroupNorm rows per workgroup;
  *   "splitk"   = 1 (default) / 0: split-K of long reductions on grids of at most half a tile per CU (the 8x8-level convs);
  *   "ffn_dbg", "tleg_abl", "gnconv_abl", "rowgemm_dbg" 1 .. 4: timing ablations whose RESULTS ARE GARBAGE.  The product library does not
