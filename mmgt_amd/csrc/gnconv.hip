@@ -419,26 +419,45 @@ __global__ __launch_bounds__(512, 2) void gnconv_kernel(const GcArgs a) {
 }
 
 // Statistics of a GroupNorm from the per-tile partials of the launch that produced its input: stats [nb * tiles][C / 4][2] (sum, sum of squares per
-// 4-channel quad and 16 x 16 tile) -> the (scale, shift) tables, folded in a fixed order (8 interleaved runs of tiles per group, then the runs,
-// then the group's quads).  One workgroup per image, thread = (group, run).
+// 4-channel quad and 16 x 16 tile) -> the (scale, shift) tables.  One workgroup per image, thread = (group, run of tiles): every partial becomes
+// (count, mean, M2 = sum of squared deviations from ITS mean) and the partials are merged with Chan's update -- mean and M2 of a union from those of
+// its parts, every term of the order of the variance -- in a fixed order (8 interleaved runs of tiles per group, then the runs).  The cancellation
+// E[x^2] - mean^2 is then confined to the 1024 values of one partial instead of the image's 10^5 .. 10^6 (|mean| >> sigma).
 __global__ __launch_bounds__(256) void gn_stats_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float* __restrict__ scale, float* __restrict__ shift, int tiles, int C, int G, float eps,
                                                                 float inv_count) {
-  __shared__ float part[8][64][2];
+  __shared__ float part[8][64][3];
   const int n = blockIdx.x, g = threadIdx.x % G, run = threadIdx.x / G, nrun = 256 / G;     // G = 32: 8 runs
   const int qpg = C / G / 4, nq = C / 4;
-  float s1 = 0.f, s2 = 0.f;
+  const float cnt = 1024.f, icnt = 1.f / 1024.f;           // values per partial: 16 x 16 pixels x 4 channels
+  float cn = 0.f, cm = 0.f, cq = 0.f;
   for (int t = run; t < tiles; t += nrun) {
     const float* p = stats + ((long)(n * tiles + t) * nq + g * qpg) * 2;
-    for (int k = 0; k < qpg; ++k) { s1 += p[2 * k]; s2 += p[2 * k + 1]; }
+    for (int k = 0; k < qpg; ++k) {
+      const float s1 = p[2 * k], mb = s1 * icnt, qb = fmaxf(fmaf(-s1, mb, p[2 * k + 1]), 0.f);
+      const float tot = cn + cnt, d = mb - cm, f = cnt / tot;
+      cm = fmaf(d, f, cm);
+      cq += qb + d * d * cn * f;
+      cn = tot;
+    }
   }
-  part[run][g][0] = s1;
-  part[run][g][1] = s2;
+  part[run][g][0] = cn;
+  part[run][g][1] = cm;
+  part[run][g][2] = cq;
   __syncthreads();
   if (run == 0) {
-    for (int r = 1; r < nrun; ++r) { s1 += part[r][g][0]; s2 += part[r][g][1]; }
-    const float mean = s1 * inv_count;
-    const float var = fmaxf(fmaf(-mean, mean, s2 * inv_count), 0.f);
+    for (int r = 1; r < nrun; ++r) {
+      const float nb_ = part[r][g][0];
+      if (nb_ > 0.f) {
+        const float tot = cn + nb_, d = part[r][g][1] - cm, f = nb_ / tot;
+        cm = fmaf(d, f, cm);
+        cq += part[r][g][2] + d * d * cn * f;
+        cn = tot;
+      }
+    }
+    const float mean = cm;
+    const float var = cq / cn;
+    (void)inv_count;
     const float rstd = rsqrtf(var + eps);
     const int cpg = C / G;
     for (int c = g * cpg; c < (g + 1) * cpg; ++c) {

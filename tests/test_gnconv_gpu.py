@@ -129,9 +129,10 @@ def test_gnconv_statistics_of_the_output(cin, cout, res, nb, H, W):
 
 
 def test_gnconv_statistics_of_an_output_whose_mean_is_30_sigma():
-    """the epilogue's tallies are UNSHIFTED fp32 sums, so the finalize kernel's var = E[x^2] - mean^2 loses log2(mean^2 / var) bits (the
-    pass over the tensor in norm.hip shifts by a pivot).  At |mean| = 30 sigma (a conv bias of 30: ~10 bits of the 24) the tables from the producing
-    launch must still agree with the pass over the tensor and with fp64 at a level a bf16 consumer cannot see (its own rounding is 2^-8 = 4e-3)."""
+    """the epilogue's tallies are UNSHIFTED fp32 sums per 16 x 16 tile and 4-channel quad.  The finalize kernel turns every partial into
+    (count, mean, M2) and merges them with Chan's update, so the cancellation E[x^2] - mean^2 is confined to the 1024 values of one partial: at
+    |mean| = 30 sigma (a conv bias of 30) the tables from the producing launch agree with fp64 to 1e-4 relative (measured 1e-5; the plain
+    E[x^2] - mean^2 over the image was 1e-3), next to the pivot-shifted pass over the tensor (1e-6)."""
     from mmgt_amd import hip
     from mmgt_amd.packing import pack_gnconv
     nb, H, W, cout = 2, 64, 64, 128
@@ -156,7 +157,7 @@ def test_gnconv_statistics_of_an_output_whose_mean_is_30_sigma():
     ey = ((y1 - y0).abs() / gamma.double().view(1, 32, -1)).max().item()
     print(f"|mean| = {(mean.abs() / var.sqrt()).mean().item():.0f} sigma: relative scale error from the launch's tallies {e1:.2e}, from the shifted pass {e2:.2e}; "
           f"normalised-value error {ey:.2e} sigma")
-    assert e1 < 2e-3 and ey < 4e-3 and e2 < 1e-4
+    assert e1 < 1e-4 and ey < 1e-4 and e2 < 1e-4
 
 
 def test_gnconv_no_bias_and_zero_padding():
