@@ -61,7 +61,7 @@ const char* mmgt_last_error(void);
  * head_dim-40 attention kernels, the producer / consumer FeedForward) are records under tools/micro/. */
 int mmgt_tune(const char* key, int value);
 /* Host-side switches kept in the same table (what mmgt_amd/unet3d.py, pipeline.py and smga.py consult; all default 1, 0 = the
- * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "tleg", "rconv" (a mask: 1 the 320-wide resnets, 2 the 640-wide, 4 the 1280-wide), "gnconv" (mmgt_amd/vae.py),
+ * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "tleg", "up2" (the up-sampling convs in the four-phase form), "rconv" (a mask: 1 the 320-wide resnets, 2 the 640-wide, 4 the 1280-wide), "gnconv" (mmgt_amd/vae.py),
  * "zero_audio_skip", "window_state", "smga_graph".  mmgt_tune sets them, mmgt_tune_get reads them: one state describes a run. */
 int mmgt_tune_get(const char* key, int* value);
 /* Box calibration for bench.py's `box_calib` (csrc/calib.hip): a bare v_mfma_f32_16x16x32_bf16 loop on random operands, one wave per SIMD,
@@ -97,6 +97,10 @@ int mmgt_gemm_post(const void* A, long lda, const void* W, const float* bias, co
  * nearest-2x upsampled input (Upsample3D, resnet.py:70-88); stride 2 = Downsample3D (resnet.py:112-120).
  * stride -2 = stride 2 with the padding on the high side only (diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)),
  * the AutoencoderKL encoder's downsampler).
+ * upsample = 2: the same function as upsample = 1 from the FOUR-PHASE weight image [4][Cout][2][2][C0] (mmgt_amd/packing.py pack_conv3x3_up2): output
+ * pixel (2 y + a, 2 x + b) reads the stored pixels (y + a - 1 .. y + a, x + b - 1 .. x + b) through the 3 x 3 taps summed per stored pixel -- four
+ * 2 x 2 convs on the stored image (one per phase, grid.z), 16 instead of 36 multiply-adds per stored pixel and channel pair; bf16, one source,
+ * bias only, Cout a multiple of 256 or 320 (the up-sampling convs of the UNet, the ReferenceNet and the VAE decoder).
  * Wp: [Cout][3][3][C0+C1].  out (NB,OH,OW,Cout) = act(conv + bias + bias2[pixel / bias2_rows]) + residual.
  * Replaces: InflatedConv3d (src/models/resnet.py:9-17) in ResnetBlock3D.conv1/conv2 (resnet.py:223,240), conv_in /
  * conv_out (unet_3d.py:517,620), PoseGuider convs (pose_guider.py:47-57), AutoencoderKL decoder convs (diffusers). */

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
       const int cin = ad.C0 + ad.C1;
       if (p_c == 0 || p_c == ad.C0) {
         const int ky = p_tap / 3, kx = p_tap - ky * 3;
-        const int vh = ad.up ? ad.IH * 2 : ad.IH, vw = ad.up ? ad.IW * 2 : ad.IW;
+        const int vh = ad.up == 1 ? ad.IH * 2 : ad.IH, vw = ad.up == 1 ? ad.IW * 2 : ad.IW;
         const bool second = p_c >= ad.C0 && ad.C1 > 0;
         const long cpp = second ? ad.C1 : ad.C0;
         a_second = second;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && (BM / WM / 32) * (BN
         for (int i = 0; i < GA; ++i) {
           const int iy = coy[i] * ad.stride + ky - ad.pad, ix = cox[i] * ad.stride + kx - ad.pad;
           const bool ok = iy >= 0 && iy < vh && ix >= 0 && ix < vw;
-          const int sy = ad.up ? iy >> 1 : iy, sx = ad.up ? ix >> 1 : ix;
+          const int sy = ad.up == 1 ? iy >> 1 : iy, sx = ad.up == 1 ? ix >> 1 : ix;
           const unsigned off = (unsigned)((((long)cn[i] * ad.IH + sy) * ad.IW + sx) * cpp * ESZ) + achunk[i];
           aoff[i] = ok ? off : DMA_POISON;   // padding: an out-of-range offset reads as zero
         }
@@ -812,6 +812,7 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     else cfg = 1;
   }
   if (geglu && (cfg == 3 || cfg == 12)) cfg = 1;   // GEGLU pairs need 64-column wave tiles
+  if (MODE == 1 && ad.up == 2 && cfg != 16 && cfg != 17) cfg = N % 320 == 0 ? 17 : 16;   // the four-phase upsample conv exists in gemm16.hip only
   // cfg 19 = gemm16's 192 x 320 tile (round 5): taken where 256-row tiles leave the last round of the persistent grid half empty.  With T
   // tiles on 256 CUs a launch runs ceil(T / 256) rounds of one tile time; a 192-row tile takes ~0.88 of a 256-row tile's time (three MFMA row
   // tiles per four W fragment reads instead of four).  Measured (tools/ab_cfg.py SET=bm192, profiles/r5/ab_cfg_bm192_r5.txt): 49 152 x 640
@@ -862,6 +863,10 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
         }
       }
       return mmgt_gemm16_launch(MODE, bn, &ad, W, bsw, &ep, M, N, K, batch, s);
+    }
+    if (MODE == 1 && ad.up == 2) {
+      mmgt_set_error("conv3x3: the four-phase upsample form needs the gemm16 path (bf16, 16-byte aligned bias, Cout %% 4 == 0)");
+      return 1;
     }
     cfg = cfg == 16 ? 9 : geglu ? 1 : 12;   // (GEGLU pairs need 64-column wave tiles: not the 320-column tile)
   }
@@ -951,6 +956,7 @@ HostSwitch g_host[] = {
     {"rowgemm", 1},          // row-stationary LayerNorm / GroupNorm -> projection launches
     {"tleg", 1},             // a level-0 temporal-attention leg as one launch (csrc/tleg.hip)
     {"rconv", 5},            // the UNet resnets' GroupNorm + SiLU + conv3x3 legs as one launch (csrc/rconv.hip): a mask of 1 the 320-wide level, 2 the 640-wide, 4 the 1280-wide; 0 off
+    {"up2", 1},              // the convs behind a nearest 2x upsampling as four 2 x 2 convs on the stored image (packing.pack_conv3x3_up2; 0: 3 x 3 on the upsampled view)
     {"rconv_stats", 1},      // ... with the next GroupNorm's statistics from the launch's epilogue (0: a statistics pass over the tensor)
     {"gnconv", 2},           // the VAE's GroupNorm + SiLU + conv3x3 as one launch (csrc/gnconv.hip): 1 with a statistics pass, 2 statistics from the producing launch
     {"zero_audio_skip", 1},  // skip the audio cross-attention of an all-zero (unconditional) audio row
@@ -1057,21 +1063,27 @@ extern "C" int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1,
   if (stride == -2) { stride = 2; pad_lo = 0; }   // diffusers Downsample2D(padding=0): F.pad(x, (0, 1, 0, 1)) + stride-2 conv
   MMGT_CHECK(stride == 1 || stride == 2, "conv3x3: stride %d", stride);
   MMGT_CHECK(!(upsample && stride != 1), "conv3x3: upsample requires stride 1");
+  MMGT_CHECK(upsample >= 0 && upsample <= 2, "conv3x3: upsample = %d (0, 1, or 2 = the four-phase form with the packing.pack_conv3x3_up2 image)", upsample);
   MMGT_CHECK(C0 % 64 == 0 && C1 % 64 == 0 && (x1 != nullptr) == (C1 > 0),
              "conv3x3: channel counts must be multiples of 64 (C0=%d C1=%d)", C0, C1);
   MMGT_CHECK(act == 0 || act == 2 || act == 3, "conv3x3: act %d unsupported", act);
   MMGT_CHECK(((uintptr_t)x0 % 16) == 0 && ((uintptr_t)x1 % 16) == 0 && ((uintptr_t)Wp % 16) == 0,
              "conv3x3: pointers must be 16-byte aligned");
-  const int VH = upsample ? IH * 2 : IH, VW = upsample ? IW * 2 : IW;
-  const int OH = (VH + pad_lo + 1 - 3) / stride + 1, OW = (VW + pad_lo + 1 - 3) / stride + 1;
+  // upsample == 2: the conv behind a nearest 2x upsampling as four 2 x 2 convs on the stored image (one per output phase = grid.z), K = 4 Cin each:
+  // OH x OW is the PHASE grid (= the stored image), the kernel's epilogue scatters row (n, y, x) of phase (a, b) to pixel (2 y + a, 2 x + b)
+  const bool up2 = upsample == 2;
+  MMGT_CHECK(!up2 || (dtype == MMGT_BF16 && !residual && !bias2 && act == 0 && !x1 && (Cout % 256 == 0 || Cout % 320 == 0)),
+             "conv3x3: the four-phase upsample form is bf16, one source, bias only, Cout a multiple of 256 or 320");
+  const int VH = upsample == 1 ? IH * 2 : IH, VW = upsample == 1 ? IW * 2 : IW;
+  const int OH = up2 ? IH : (VH + pad_lo + 1 - 3) / stride + 1, OW = up2 ? IW : (VW + pad_lo + 1 - 3) / stride + 1;
   const long M = (long)NB * OH * OW;
-  MMGT_CHECK(M < (1l << 31), "conv3x3: too many output pixels");
+  MMGT_CHECK(M < (1l << 31) && (!up2 || 4 * M * Cout * 2 < (1l << 31) * 8), "conv3x3: too many output pixels");
   {
     const long esz_ = dtype == MMGT_BF16 ? 2 : 4, px = (long)NB * IH * IW;
     MMGT_CHECK(px * C0 * esz_ < (1l << 31) && px * C1 * esz_ < (1l << 31) && (long)Cout * 9 * (C0 + C1) * esz_ < (1l << 31),
                "conv3x3: a tensor exceeds the 2 GiB range of the 32-bit LDS-DMA offsets (split the batch)");
   }
-  const int K = 9 * (C0 + C1);
+  const int K = (up2 ? 4 : 9) * (C0 + C1);
   if (check_common(dtype, (int)M, Cout, K, act)) return 1;
   ADesc ad{};
   ad.src0 = (const char*)x0; ad.src1 = (const char*)x1; ad.C0 = C0; ad.C1 = C1; ad.IH = IH; ad.IW = IW; ad.OH = OH;
@@ -1083,6 +1095,7 @@ extern "C" int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1,
   ep.ldr = Cout; ep.out = (char*)out; ep.ldo = Cout; ep.act = act;
   ep.fast = epi_fast(ep, Cout, Cout, dtype == MMGT_BF16 ? 2 : 4);
   hipStream_t s = (hipStream_t)stream;
+  if (up2) return launch<bf16_t, 1>(ad, Wp, (long)Cout * K, ep, (int)M, Cout, K, 4, s);
   return dtype == MMGT_BF16 ? launch<bf16_t, 1>(ad, Wp, 0, ep, (int)M, Cout, K, 1, s)
                             : launch<float, 1>(ad, Wp, 0, ep, (int)M, Cout, K, 1, s);
 }

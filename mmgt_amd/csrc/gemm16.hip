@@ -149,8 +149,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
       const int cin = ad.C0 + ad.C1;
       if (p_c == 0 || p_c == ad.C0 || a_fresh) {
         a_fresh = false;
-        const int ky = p_tap / 3, kx = p_tap - ky * 3;
-        const int vh = ad.up ? ad.IH * 2 : ad.IH, vw = ad.up ? ad.IW * 2 : ad.IW;
+        // up == 2: the conv behind a nearest 2x upsampling as FOUR 2 x 2 convs on the stored image, one per output phase (a, b) = grid.z:
+        // output pixel (2 y + a, 2 x + b) sees input rows y + a - 1, y + a through the 3 x 3 weights summed per source pixel (the host's phase
+        // image, packing.pack_conv3x3_up2): 16 instead of 36 multiply-adds per input pixel, the same sums
+        const bool up2 = ad.up == 2;
+        const int ky = up2 ? p_tap >> 1 : p_tap / 3, kx = up2 ? p_tap & 1 : p_tap - ky * 3;
+        const int vh = ad.up == 1 ? ad.IH * 2 : ad.IH, vw = ad.up == 1 ? ad.IW * 2 : ad.IW;
         const bool second = p_c >= ad.C0 && ad.C1 > 0;
         const unsigned cpb = (unsigned)(second ? ad.C1 : ad.C0) * ESZ;   // bytes per pixel of the source tensor (< 2 GiB in all: host check)
         a_second = second;
@@ -160,9 +164,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
           const unsigned m = am0 + RPD * i;
           const unsigned cn = fastdiv(m, ad.fd_hw), rem = m - cn * (unsigned)(ad.OH * ad.OW);
           const unsigned oy = fastdiv(rem, ad.fd_ow), ox = rem - oy * (unsigned)ad.OW;
-          const int iy = (int)oy * ad.stride + ky - ad.pad, ix = (int)ox * ad.stride + kx - ad.pad;
+          const int iy = up2 ? (int)oy + ky + (bz >> 1) - 1 : (int)oy * ad.stride + ky - ad.pad;
+          const int ix = up2 ? (int)ox + kx + (bz & 1) - 1 : (int)ox * ad.stride + kx - ad.pad;
           const bool ok = (int)m < M && iy >= 0 && iy < vh && ix >= 0 && ix < vw;
-          const int sy = ad.up ? iy >> 1 : iy, sx = ad.up ? ix >> 1 : ix;
+          const int sy = ad.up == 1 ? iy >> 1 : iy, sx = ad.up == 1 ? ix >> 1 : ix;
           const unsigned off = (cn * (unsigned)(ad.IH * ad.IW) + (unsigned)(sy * ad.IW + sx)) * cpb + (unsigned)((c0sw ^ (4 * ((i + wid * GA) & 1))) << 4);
           aoff[i] = ok ? off : DMA_POISON;
         }
@@ -454,6 +459,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
       for (int i = 0; i < RT; ++i) {
         const int m = row0 + 16 * i + lme;
         T* orow = obase + (long)m * ep.ldo;
+        if (MODE == 1 && ad.up == 2) {          // phase (a, b) = grid.z of the upsampled output: row (n, y, x) -> pixel (2 y + a, 2 x + b)
+          const unsigned mm = (unsigned)(m < M ? m : M - 1);
+          const unsigned cn = fastdiv(mm, ad.fd_hw), rem = mm - cn * (unsigned)(ad.OH * ad.OW);
+          const unsigned oy = fastdiv(rem, ad.fd_ow), ox = rem - oy * (unsigned)ad.OW;
+          orow = obase + ((long)(cn * 2u * (unsigned)ad.OH + 2u * oy + (unsigned)(bz >> 1)) * (2 * ad.OW) + 2 * ox + (bz & 1)) * ep.ldo;
+        }
         if (RES) {
           if (NBUF == 2 ? i < RT - 1 : true) load_res(NBUF == 2 ? i + 1 : i, rv[NBUF == 2 ? (i + 1) & 1 : 0]);
         }

@@ -277,13 +277,22 @@ def gemm_batched(a, w, *, out):
 def conv3x3(x, wp, bias=None, *, stride=1, upsample=False, bias2=None, bias2_rows=0, residual=None, act=ACT_NONE,
             x1=None, out=None, pad_high_only=False):
     """x (NB, H, W, C0) channels-last [+ x1 (NB, H, W, C1)], wp [Cout][3][3][C0+C1] -> (NB, OH, OW, Cout).
-    pad_high_only (stride 2 only): zero padding after the last row / column only (the VAE encoder's downsampler)."""
+    pad_high_only (stride 2 only): zero padding after the last row / column only (the VAE encoder's downsampler).
+    upsample = True: the conv sees the nearest-2x upsampled input; upsample = 2: the same result from the four-phase image
+    packing.pack_conv3x3_up2(weight) ([4][Cout][2][2][C0]: four 2 x 2 convs on the stored image, 16 / 36 of the multiply-adds; bf16, bias only)."""
     _dev(x, wp, bias, bias2, residual, x1)
     assert x.dim() == 4 and x.is_contiguous() and wp.is_contiguous() and wp.dtype == x.dtype
     NB, IH, IW, C0 = x.shape
     C1 = 0 if x1 is None else x1.shape[3]
-    cout = wp.shape[0]
-    assert wp.numel() == cout * 9 * (C0 + C1)
+    if upsample is not True and upsample == 2:
+        assert wp.dim() == 5 and wp.shape[0] == 4 and wp.shape[2:] == (2, 2, C0) and x1 is None and residual is None and bias2 is None
+        assert x.dtype == torch.bfloat16 and act == ACT_NONE and stride == 1 and not pad_high_only
+        cout = wp.shape[1]
+        assert cout % 256 == 0 or cout % 320 == 0
+    else:
+        upsample = bool(upsample)
+        cout = wp.shape[0]
+        assert wp.numel() == cout * 9 * (C0 + C1)
     vh, vw = (IH * 2, IW * 2) if upsample else (IH, IW)
     if pad_high_only:
         assert stride == 2 and not upsample

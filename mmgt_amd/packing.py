@@ -23,6 +23,28 @@ def pack_conv3x3(w, cin_pad=None, cout_pad=None):
     return out.contiguous()
 
 
+def pack_conv3x3_up2(w):
+    """(Cout, Cin, 3, 3) -> [4][Cout][2][2][Cin]: the conv behind a nearest 2x upsampling as four 2 x 2 convs on the STORED image, one per output
+    phase (a, b) (image index 2 a + b; `hip.conv3x3(..., upsample=2)`).  Output pixel (2 y + a, 2 x + b) reads upsampled rows 2 y + a - 1 .. + 1, i.e.
+    stored rows y + a - 1 and y + a: for a = 0 the taps (ky = 0 | ky = 1, 2) fall on them, for a = 1 (ky = 0, 1 | ky = 2); columns alike.  The weights of
+    the taps that fall on one stored pixel are summed (in fp32, then rounded once): 16 instead of 36 multiply-adds per stored pixel and output channel,
+    the same sums as upsample -> conv3x3 (the zero padding too: a stored row / column outside the image is outside the upsampled one)."""
+    cout, cin = w.shape[:2]
+    wf = w if w.dtype == torch.float64 else w.float()
+    groups = (((0,), (1, 2)), ((0, 1), (2,)))               # [phase][stored row / column 0, 1] -> the 3 x 3 taps that fall on it
+    out = torch.zeros((4, cout, 2, 2, cin), device=w.device, dtype=wf.dtype)
+    for a in range(2):
+        for b in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    acc = 0
+                    for ky in groups[a][ty]:
+                        for kx in groups[b][tx]:
+                            acc = acc + wf[:, :, ky, kx]
+                    out[2 * a + b, :, ty, tx, :] = acc
+    return out.to(w.dtype).contiguous()
+
+
 def pad_rows(w, n_pad):
     """Zero-pad the output (row) dimension of a [N, K] weight / [N] bias."""
     if w is None or w.shape[0] == n_pad:

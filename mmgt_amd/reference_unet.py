@@ -61,7 +61,11 @@ class UNet2DConditionModel(UNet3DConditionModel):
                 if i > 0:
                     x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs, 1, write=bank)
             if i != 3:
-                x = hip.conv3x3(x, self.w[f"{p}.upsamplers.0.conv.w"], self.w[f"{p}.upsamplers.0.conv.bias"], upsample=True)
+                w2 = self.w.get(f"{p}.upsamplers.0.conv.w2")          # (the four-phase form: unet3d.py `_pack`)
+                if w2 is not None:
+                    x = hip.conv3x3(x, w2, self.w[f"{p}.upsamplers.0.conv.bias"], upsample=2)
+                else:
+                    x = hip.conv3x3(x, self.w[f"{p}.upsamplers.0.conv.w"], self.w[f"{p}.upsamplers.0.conv.bias"], upsample=True)
         bank.update(mid)                              # module order down -> up -> mid
         self.bank = bank
         out = hip.nhwc_to_ncfhw(x, b, self.boc[0])[:, :, 0].to(sample.dtype)

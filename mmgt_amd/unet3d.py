@@ -19,7 +19,7 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from . import hip
-from .packing import pack_conv3x3, pack_ff_fused, pack_ff_proj_out, pack_geglu, pack_rconv, pack_rowgemm, pack_tleg, pad_cols, pad_rows, round_up
+from .packing import pack_conv3x3, pack_conv3x3_up2, pack_ff_fused, pack_ff_proj_out, pack_geglu, pack_rconv, pack_rowgemm, pack_tleg, pad_cols, pad_rows, round_up
 from .unet3d_spec import unet3d_spec
 
 SD15_CONFIG = dict(  # SD-1.5 unet/config.json + unet_3d.py:649-662 + config/prompts/animation.yaml:47-75
@@ -120,6 +120,7 @@ class UNet3DConditionModel:
         self._share_rows = bool(hip.tune_get("shared_rows"))      # conv_in + first resnet once for both CFG rows
         self._fuse_oz = bool(hip.tune_get("oz3"))                 # 0: the three masked audio out-projections as separate launches
         self._fuse_ln = bool(hip.tune_get("rowgemm"))             # 0: LayerNorm and q / k / v GEMMs as separate launches
+        self._up2 = bool(hip.tune_get("up2"))                     # the up-sampling convs as four 2 x 2 convs on the stored image (0: the 3 x 3 conv on the upsampled view)
         self._fuse_tleg = bool(hip.tune_get("tleg"))              # 0: a level-0 temporal-attention leg as three launches
         self._tables = None                                       # (reader key, data_ptr, images, (scale, shift)): GroupNorm tables handed from a conv's epilogue to the norm's reader
         self._rconv_stats = bool(hip.tune_get("rconv_stats"))     # a fused leg's output statistics from its epilogue instead of a pass over the tensor
@@ -337,6 +338,9 @@ class UNet3DConditionModel:
         for k in self.spec:
             if k.endswith("samplers.0.conv.weight"):
                 conv(k[: -len(".weight")])
+                if ".upsamplers." in k and self._up2 and self._dtype == torch.bfloat16 and has(k) and (sd[k].shape[0] % 256 == 0 or sd[k].shape[0] % 320 == 0):
+                    # the conv behind the nearest 2x upsampling (resnet.py:31-77, Upsample3D: F.interpolate(nearest, x2) -> conv) as four 2 x 2 convs on the stored image: 16 / 36 of the work
+                    w[k[: -len(".weight")] + ".w2"] = self._t(pack_conv3x3_up2(sd[k]))
 
         self._spatial = [k[: -len(".transformer_blocks.0.attn2.to_q.weight")] for k in self.spec
                          if k.endswith(".transformer_blocks.0.attn2.to_q.weight")]
@@ -955,7 +959,11 @@ class UNet3DConditionModel:
                     x = self._spatial_transformer(f"{p}.attentions.{j}", x, ehs, f, cfg_row=cfg_row)
                 x = self._motion_module(f"{p}.motion_modules.{j}", x, f)
             if i != 3:
-                x = hip.conv3x3(x, self.w[f"{p}.upsamplers.0.conv.w"], self.w[f"{p}.upsamplers.0.conv.bias"], upsample=True)
+                w2 = self.w.get(f"{p}.upsamplers.0.conv.w2")
+                if w2 is not None:
+                    x = hip.conv3x3(x, w2, self.w[f"{p}.upsamplers.0.conv.bias"], upsample=2)
+                else:
+                    x = hip.conv3x3(x, self.w[f"{p}.upsamplers.0.conv.w"], self.w[f"{p}.upsamplers.0.conv.bias"], upsample=True)
 
         x = self._gn("conv_norm_out", x, self.config.norm_eps, silu=True)
         x = hip.conv3x3(x, self.w["conv_out.w"], self.w["conv_out.bias"])

@@ -13,7 +13,7 @@ from collections import OrderedDict
 import torch
 
 from . import hip
-from .packing import pack_conv3x3, pack_gnconv, pack_rconv, pad_cols, pad_rows, round_up
+from .packing import pack_conv3x3, pack_conv3x3_up2, pack_gnconv, pack_rconv, pad_cols, pad_rows, round_up
 
 _UP_CH = ((512, 512), (512, 512), (512, 256), (256, 128))     # (in, out) of decoder.up_blocks.0..3
 
@@ -165,6 +165,9 @@ class AutoencoderKL:
                 cin_pad, cout_pad = round_up(wt.shape[1], 64), round_up(wt.shape[0], 64)
                 w[p + ".w"] = self._t(pack_conv3x3(wt, cin_pad, cout_pad))
                 w[p + ".bias"] = self._f(pad_rows(b, cout_pad))
+                if ".upsamplers." in p and self._dtype == torch.bfloat16 and hip.tune_get("up2") and wt.shape[0] % 256 == 0 and wt.shape[1] % 64 == 0:
+                    # the conv behind the nearest 2x upsampling as four 2 x 2 convs on the stored image (packing.pack_conv3x3_up2): 16 / 36 of the work
+                    w[p + ".w2"] = self._t(pack_conv3x3_up2(wt.to(self._device, torch.float32)))
                 if self._dtype == torch.bfloat16 and (wt.shape[1], cout_pad) in ((128, 128), (256, 128), (256, 256), (128, 64)):
                     # the 512 x 512 and 256 x 256 levels: GroupNorm + SiLU + conv fused (csrc/gnconv.hip) wherever a GroupNorm feeds this conv
                     wpad = torch.zeros((cout_pad, wt.shape[1], 3, 3), device=self._device, dtype=torch.float32)
@@ -307,7 +310,11 @@ class AutoencoderKL:
                 x, st = self._resnet(f"decoder.up_blocks.{i}.resnets.{j}", x, st, next_pn=nxt)
             if i != 3:
                 p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
-                x, st = hip.conv3x3(x, self.w[p + ".w"], self.w[p + ".bias"], upsample=True), None
+                w2 = self.w.get(p + ".w2")
+                if w2 is not None:
+                    x, st = hip.conv3x3(x, w2, self.w[p + ".bias"], upsample=2), None
+                else:
+                    x, st = hip.conv3x3(x, self.w[p + ".w"], self.w[p + ".bias"], upsample=True), None
         return self._gn_silu_conv("decoder.conv_norm_out", "decoder.conv_out", x, stats=st)[0]
 
     def encode_nhwc(self, x):

@@ -275,6 +275,33 @@ def test_conv3x3(dt, cin, cout, hw, stride, up):
     torch.testing.assert_close(out.double(), _nhwc(ref2), **tol(dt))
 
 
+@pytest.mark.parametrize("nb,cin,cout,h,w_", [(3, 1280, 1280, 8, 8), (2, 640, 640, 16, 12), (5, 320, 640, 7, 9), (48, 1280, 1280, 8, 8), (2, 512, 512, 32, 32),
+                                              (1, 64, 256, 1, 1)])
+def test_conv3x3_upsample_as_four_phase_convs(nb, cin, cout, h, w_):
+    """The conv behind a nearest 2x upsampling (resnet.py:31-77) as four 2 x 2 convs on the stored image (`upsample=2`, packing.pack_conv3x3_up2:
+    the taps that fall on one stored pixel summed per output phase): the SAME function as upsample -> conv3x3 -- against torch in fp64 on the
+    bf16-rounded operands, and against the 3 x 3 kernel on the upsampled view (`upsample=True`), whose error it must not exceed by more than the
+    rounding of the summed weights; odd image sizes (every border pixel's padding), both gemm16 tile widths, the in-step 8 x 8 shape."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_conv3x3, pack_conv3x3_up2
+    dt = torch.bfloat16
+    x = rnd("up2.x", (nb, cin, h, w_), 1.0, dt)
+    w = rnd("up2.w", (cout, cin, 3, 3), 1.0 / math.sqrt(9 * cin), dt)
+    b = rnd("up2.b", (cout,), 0.5)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2.0, mode="nearest"), w.double(), b.double(), padding=1)
+    nine = hip.conv3x3(_nhwc(x), pack_conv3x3(w), b, upsample=True)
+    four = hip.conv3x3(_nhwc(x), pack_conv3x3_up2(w), b, upsample=2)
+    assert four.shape == nine.shape == (nb, 2 * h, 2 * w_, cout)
+    torch.testing.assert_close(four.double(), _nhwc(ref), **tol(dt))
+    e4, e9 = (four.double() - _nhwc(ref)).abs().mean().item(), (nine.double() - _nhwc(ref)).abs().mean().item()
+    assert e4 <= 1.6 * e9 + 1e-6, (e4, e9)       # (measured 1.4 x: a summed weight is rounded to bf16 once more, at up to four times a single weight's magnitude)
+    assert torch.equal(four, hip.conv3x3(_nhwc(x), pack_conv3x3_up2(w), b, upsample=2))
+    # exact-integer operands: every product and sum is exact in bf16 x bf16 -> fp32, so the two forms must agree bit for bit
+    xi = torch.randint(-2, 3, (nb, h, w_, cin), device=dev()).to(dt)
+    wi = torch.randint(-1, 2, (cout, cin, 3, 3), device=dev()).to(dt)
+    assert torch.equal(hip.conv3x3(xi, pack_conv3x3_up2(wi), None, upsample=2), hip.conv3x3(xi, pack_conv3x3(wi), None, upsample=True))
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_conv3x3_two_sources(dt):
     from mmgt_amd import hip

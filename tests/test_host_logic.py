@@ -149,6 +149,30 @@ def test_product_library_refuses_the_timing_ablations():
     assert r.returncode != 0 and "garbage" in r.stderr
 
 
+def test_pack_conv3x3_up2_is_upsample_then_conv():
+    """packing.pack_conv3x3_up2: four 2 x 2 convs on the stored image, one per output phase, equal conv3x3(nearest-upsample-2x(x)) exactly (fp64,
+    every border included): output pixel (2 y + a, 2 x + b) = sum over (ty, tx) of W2[2 a + b][:, ty, tx, :] . x[y + a - 1 + ty, x + b - 1 + tx]."""
+    import torch.nn.functional as F
+    from mmgt_amd.packing import pack_conv3x3_up2
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 6, 5, 7), generator=g, dtype=torch.float64)
+    w = torch.randn((4, 6, 3, 3), generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, None, padding=1)
+    w2 = pack_conv3x3_up2(w)                                  # (4, Cout, 2, 2, Cin)
+    assert w2.shape == (4, 4, 2, 2, 6) and w2.dtype == torch.float64
+    out = torch.zeros_like(ref)
+    xp = F.pad(x, (1, 1, 1, 1))                               # stored image with one zero row / column around it
+    for a in range(2):
+        for b in range(2):
+            acc = 0
+            for ty in range(2):
+                for tx in range(2):
+                    win = xp[:, :, a + ty:a + ty + 5, b + tx:b + tx + 7]          # stored pixel (y + a - 1 + ty, x + b - 1 + tx)
+                    acc = acc + torch.einsum("nchw,oc->nohw", win, w2[2 * a + b, :, ty, tx, :])
+            out[:, :, a::2, b::2] = acc
+    torch.testing.assert_close(out, ref, rtol=1e-12, atol=1e-12)
+
+
 def test_pack_rconv_fragment_image():
     """The weight image of csrc/rconv.hip: [64-channel phase][tap][k-step of 32][16-channel tile][lane][8] with lane (lm, lq) = row lm of the tile,
     reduction slots 8 lq .. 8 lq + 7 -- checked entry by entry against the definition; its size is what the library expects."""
