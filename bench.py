@@ -54,6 +54,11 @@ def executed_tflop(hip):
         if hip.tune_get("twin_attention"):
             # the first reference reader: GroupNorm / proj_in / q | k | v once, ONE attention pass over the own keys for both rows
             t -= 4 * (2.0 * f * n0 * 320 * 320) + 4.0 * 8 * 40 * n0 * n0 * f
+    if hip.tune_get("up2"):
+        # the three convs behind a nearest 2x upsampling as four 2 x 2 convs on the stored image: 16 instead of 36 multiply-adds per stored pixel
+        # and channel pair (weights of the taps that fall on one stored pixel summed on the host: the same function, packing.pack_conv3x3_up2)
+        for c, n in ((1280, n0 // 64), (1280, n0 // 16), (640, n0 // 4)):
+            t -= 2.0 * (2 * f) * n * c * c * (36 - 16)
     return t / 1e12
 
 

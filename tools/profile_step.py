@@ -35,11 +35,15 @@ def key_of(name, args, kw):
         return f"gemm_b B={a.shape[0]} M={a.shape[1]} N={w.shape[1]} K={a.shape[2]}", 2 * a.shape[0] * a.shape[1] * w.shape[1] * a.shape[2]
     if name == "conv3x3":
         x, wp = args[0], args[1]
-        cin = wp.numel() // (9 * wp.shape[0])
         st, up = kw.get("stride", 1), kw.get("upsample", False)
+        if up is not True and up == 2:      # the four-phase image [4][Cout][2][2][Cin]; TF/s stays algorithmic (36 multiply-adds per stored pixel)
+            cout, cin = wp.shape[1], wp.shape[4]
+        else:
+            cout = wp.shape[0]
+            cin = wp.numel() // (9 * cout)
         oh = x.shape[1] * (2 if up else 1) // st
-        return (f"conv nb={x.shape[0]} h={x.shape[1]} cin={cin} cout={wp.shape[0]} s={st} up={int(up)}",
-                2 * x.shape[0] * oh * oh * wp.shape[0] * 9 * cin)
+        return (f"conv nb={x.shape[0]} h={x.shape[1]} cin={cin} cout={cout} s={st} up={int(up)}" + (" (four 2x2 phase convs)" if int(up) == 2 else ""),
+                2 * x.shape[0] * oh * oh * cout * 9 * cin)
     if name == "attention":
         # the second key segment (reference bank) is read by batches >= seg2_first_batch only (the conditional CFG half)
         nb2 = kw["batch"] - kw.get("seg2_first_batch", 0) if kw.get("nk2", 0) else 0
