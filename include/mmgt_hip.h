@@ -61,7 +61,7 @@ const char* mmgt_last_error(void);
  * head_dim-40 attention kernels, the producer / consumer FeedForward) are records under tools/micro/. */
 int mmgt_tune(const char* key, int value);
 /* Host-side switches kept in the same table (what mmgt_amd/unet3d.py, pipeline.py and smga.py consult; all default 1, 0 = the
- * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "tleg", "up2" (the up-sampling convs in the four-phase form), "rconv" (a mask: 1 the 320-wide resnets, 2 the 640-wide, 4 the 1280-wide), "gnconv" (mmgt_amd/vae.py),
+ * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "tleg", "up2" (the up-sampling convs in the four-phase form), "conv_out_taps" (conv_norm_out + SiLU + conv_out as a 36-column GEMM + a gather), "rconv" (a mask: 1 the 320-wide resnets, 2 the 640-wide, 4 the 1280-wide), "gnconv" (mmgt_amd/vae.py),
  * "zero_audio_skip", "window_state", "smga_graph".  mmgt_tune sets them, mmgt_tune_get reads them: one state describes a run. */
 int mmgt_tune_get(const char* key, int* value);
 /* Box calibration for bench.py's `box_calib` (csrc/calib.hip): a bare v_mfma_f32_16x16x32_bf16 loop on random operands, one wave per SIMD,
@@ -107,6 +107,12 @@ int mmgt_gemm_post(const void* A, long lda, const void* W, const float* bias, co
 int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1, int NB, int IH, int IW, int stride, int upsample,
                       const void* Wp, const float* bias, const float* bias2, int bias2_rows, const void* residual,
                       void* out, int Cout, int act, int dtype, void* stream);
+
+/* A 3 x 3 / pad 1 conv with FOUR output channels (conv_out, unet_3d.py:620) as a GEMM + this gather: Y (NB, H, W, ldY) bf16 holds, per pixel, the 36
+ * products W[o][tap] . x[pixel] in column 4 tap + o (one GEMM over the pixel's channels for all nine taps: mmgt_rowgemm320 with norm = 3, the GroupNorm
+ * tables + SiLU of conv_norm_out applied while the rows are loaded); out (NB, H, W, 8) bf16 = bias[o] + the sum over the taps of the NEIGHBOUR pixel's
+ * product (out-of-image neighbours contribute nothing: the zero padding), channels 4 .. 7 zero. */
+int mmgt_conv_taps_gather(const void* Y, int ldY, const float* bias, void* out, int NB, int H, int W, int dtype, void* stream);
 
 /* GroupNorm over channels-last images, one statistic per (image, group), optional fused SiLU.
  * x,out (NB, HW, C) where C = C0 + C1 may be split over two sources (skip concat); workspace: NB*chunks*G*2 floats

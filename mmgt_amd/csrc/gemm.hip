@@ -956,6 +956,7 @@ HostSwitch g_host[] = {
     {"rowgemm", 1},          // row-stationary LayerNorm / GroupNorm -> projection launches
     {"tleg", 1},             // a level-0 temporal-attention leg as one launch (csrc/tleg.hip)
     {"rconv", 5},            // the UNet resnets' GroupNorm + SiLU + conv3x3 legs as one launch (csrc/rconv.hip): a mask of 1 the 320-wide level, 2 the 640-wide, 4 the 1280-wide; 0 off
+    {"conv_out_taps", 1},    // conv_norm_out + SiLU + conv_out (4 channels) as one 36-column GEMM over the pixels (GroupNorm + SiLU in its prologue) + a gather (0: GroupNorm pass + implicit-GEMM conv padded to 64 columns)
     {"up2", 1},              // the convs behind a nearest 2x upsampling as four 2 x 2 convs on the stored image (packing.pack_conv3x3_up2; 0: 3 x 3 on the upsampled view)
     {"rconv_stats", 1},      // ... with the next GroupNorm's statistics from the launch's epilogue (0: a statistics pass over the tensor)
     {"gnconv", 2},           // the VAE's GroupNorm + SiLU + conv3x3 as one launch (csrc/gnconv.hip): 1 with a statistics pass, 2 statistics from the producing launch

@@ -14,7 +14,8 @@ namespace {
 // workgroup's 99 000 cycles in rowgemm at N = 960 before, ~9 000 after).
 // STATS = false: y = x * gamma + beta only -- the second pass of a GroupNorm whose per-(image, channel) scale / shift tables the
 // caller put where gamma / beta are read (gn_apply_kernel's v = x * scale + shift, the same FMA: bit-identical).
-template <int KS, bool STATS = true>
+// SILU (with STATS = false): y = silu(x * gamma + beta) -- GroupNorm + SiLU in front of a conv that runs as a GEMM (conv_out: csrc/rowgemm.hip, norm 3).
+template <int KS, bool STATS = true, bool SILU = false>
 __device__ __forceinline__ void layernorm_fragments(s16x8 (&xf)[KS], const float* lgb, int hh, float eps) {
   constexpr int C = 16 * KS;
   typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
@@ -56,7 +57,8 @@ __device__ __forceinline__ void layernorm_fragments(s16x8 (&xf)[KS], const float
       const f32x2 z = STATS ? __builtin_elementwise_fma(x2, r2, nm2) : x2;
       const f32x2 g2 = j < 2 ? (f32x2){g0[2 * j], g0[2 * j + 1]} : (f32x2){g1[2 * j - 4], g1[2 * j - 3]};
       const f32x2 b2 = j < 2 ? (f32x2){b0[2 * j], b0[2 * j + 1]} : (f32x2){b1[2 * j - 4], b1[2 * j - 3]};
-      const f32x2 y = __builtin_elementwise_fma(z, g2, b2);
+      f32x2 y = __builtin_elementwise_fma(z, g2, b2);
+      if constexpr (SILU) y = (f32x2){silu_f(y[0]), silu_f(y[1])};
       o[j] = pack_bf16x2(y[0], y[1]);
     }
     union { u32x4 u; s16x8 s; } cv;

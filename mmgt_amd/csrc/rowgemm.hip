@@ -33,7 +33,7 @@ __device__ __forceinline__ f32x16 rmma(s16x8 a, s16x8 b, f32x16 c) { return __bu
 
 struct RowGemmArgs {
   const bf16_t* x; long ldx;
-  const float* gamma; const float* beta; int norm, pe_div, pe_mod; float eps;   // norm 1: LayerNorm, beta row (row / pe_div) % pe_mod; 2: x * gamma[g] + beta[g], both tables indexed so
+  const float* gamma; const float* beta; int norm, pe_div, pe_mod; float eps;   // norm 1: LayerNorm, beta row (row / pe_div) % pe_mod; 2: x * gamma[g] + beta[g], both tables indexed so (3: + SiLU)
   const char* wimg; const float* bias; const float* bias2; int bias2_rows;
   const bf16_t* res; long ldr;
   bf16_t* out; long ldo; int n1;                                           // normal tiles: columns [0, n1)
@@ -101,7 +101,7 @@ void rowgemm320_kernel(const RowGemmArgs a) {
     if (has_norm) {
       const long grp = a.pe_mod > 1 ? (long)(((unsigned)row0 / (unsigned)a.pe_div) % (unsigned)a.pe_mod) * RC : 0;
       const float* beta = a.beta + grp;
-      const float* gamma = a.gamma + (a.norm == 2 ? grp : 0);
+      const float* gamma = a.gamma + (a.norm >= 2 ? grp : 0);
       tn = *reinterpret_cast<const f32x4*>(tid < RC / 4 ? gamma + 4 * tid : beta + 4 * (tid - RC / 4));
     }
     const float* b2 = a.bias2 ? a.bias2 + (long)((unsigned)row0 / (unsigned)a.bias2_rows) * a.N : nullptr;
@@ -124,6 +124,7 @@ void rowgemm320_kernel(const RowGemmArgs a) {
     if (DBG == 5) stamp();
     if (a.norm == 1) layernorm_fragments<R_KS, true>(xf, lgb, hh, a.eps);
     else if (a.norm == 2) layernorm_fragments<R_KS, false>(xf, lgb, hh, a.eps);
+    else if (a.norm == 3) layernorm_fragments<R_KS, false, true>(xf, lgb, hh, a.eps);
   }
 
   // fragment ring: [group parity][k-step of the group]; 4 groups of 5 k-steps per tile (an EVEN number of groups: the first group of
@@ -281,8 +282,8 @@ extern "C" int mmgt_rowgemm320(const void* x, long ldx, int norm, const float* l
   MMGT_CHECK(mmgt_rowgemm320_image_bytes(N) > 0, "rowgemm320: N = 32 .. %d in steps of 32 (got %d)", R_MAXN, N);
   MMGT_CHECK(n1 >= 0 && n1 <= N && n1 % 32 == 0, "rowgemm320: n1 = %d must be a multiple of 32 within N = %d", n1, N);
   MMGT_CHECK(M > 0 && ldx >= RC && ldx % 8 == 0, "rowgemm320: bad M = %d or ldx = %ld", M, ldx);
-  MMGT_CHECK(norm >= 0 && norm <= 2 && (norm != 0) == (ln_gamma != nullptr) && (norm != 0) == (ln_beta != nullptr),
-             "rowgemm320: norm = %d (0 none, 1 LayerNorm, 2 scale / shift tables) and gamma / beta must come together", norm);
+  MMGT_CHECK(norm >= 0 && norm <= 3 && (norm != 0) == (ln_gamma != nullptr) && (norm != 0) == (ln_beta != nullptr),
+             "rowgemm320: norm = %d (0 none, 1 LayerNorm, 2 scale / shift tables, 3 the tables + SiLU) and gamma / beta must come together", norm);
   MMGT_CHECK(!norm || pe_mod <= 1 || (pe_div > 0 && pe_div % 128 == 0), "rowgemm320: pe_div = %d must be a multiple of 128", pe_div);
   MMGT_CHECK(!bias2 || (bias2_rows > 0 && bias2_rows % 128 == 0), "rowgemm320: bias2_rows = %d must be a multiple of 128", bias2_rows);
   MMGT_CHECK(n1 == 0 || (out && ldo >= n1 && ldo % 8 == 0 && (long)M * ldo * 2 < (1l << 31)),

@@ -56,6 +56,7 @@ _SIGS = {
     "mmgt_ncfhw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "mmgt_nhwc_to_ncfhw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                    c_int, c_void_p]),
+    "mmgt_conv_taps_gather": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_timestep_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mmgt_ff_fused_image_bytes": (c_int, [c_int, c_int]),
     "mmgt_ff_fused": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long,
@@ -575,18 +576,18 @@ def rowgemm320_supported(dtype, K, N):
 
 
 def rowgemm320(x, wimg, N, bias=None, *, ln_gamma=None, ln_beta=None, pe_div=0, pe_mod=0, eps=1e-5, residual=None, bias2=None,
-               bias2_rows=0, n1=None, out=None, out_t=None, n_tok=0, pre_scale=None, pre_shift=None, pre_rows=0):
+               bias2_rows=0, n1=None, out=None, out_t=None, n_tok=0, pre_scale=None, pre_shift=None, pre_rows=0, pre_silu=False):
     """[LayerNorm ->] Linear of the 320-channel level in one launch that reads x once (csrc/rowgemm.hip).  x (M, 320) bf16, wimg =
     packing.pack_rowgemm(W (N, 320)).  Columns [0, n1) -> out (M, n1) row-major (+ residual, n1 == N only), columns [n1, N) ->
     out_t (M / n_tok, N - n1, npad) transposed per batch of n_tok rows (the V^T operand of `attention(v_transposed=True)`).
     ln_beta (pe_mod, 320) fp32: row (m / pe_div) % pe_mod.  pre_scale / pre_shift (M / pre_rows, 320) fp32 instead of a LayerNorm:
-    x * scale[m / pre_rows] + shift[m / pre_rows] (`groupnorm_affine`).  Returns (out, out_t)."""
+    x * scale[m / pre_rows] + shift[m / pre_rows] (`groupnorm_affine`; pre_silu: SiLU behind it).  Returns (out, out_t)."""
     _dev(x, wimg, bias, ln_gamma, ln_beta, residual, bias2, out, out_t, pre_scale, pre_shift)
     norm = 1 if ln_gamma is not None else 0
     if pre_scale is not None:
         assert ln_gamma is None and pre_rows > 0 and x.shape[0] % pre_rows == 0
         assert pre_scale.shape == pre_shift.shape == (x.shape[0] // pre_rows, 320) and pre_scale.is_contiguous() and pre_shift.is_contiguous()
-        norm, ln_gamma, ln_beta, pe_div, pe_mod = 2, pre_scale, pre_shift, pre_rows, x.shape[0] // pre_rows
+        norm, ln_gamma, ln_beta, pe_div, pe_mod = (3 if pre_silu else 2), pre_scale, pre_shift, pre_rows, x.shape[0] // pre_rows
     assert x.dim() == 2 and x.shape[1] == 320 and x.stride(1) == 1 and x.dtype == torch.bfloat16
     M = x.shape[0]
     n1 = N if n1 is None else n1
@@ -746,6 +747,17 @@ def nhwc_to_ncfhw(x, B, C, scale=1.0, shift=0.0, clamp01=False):
     _check(lib().mmgt_nhwc_to_ncfhw(_ptr(x), _ptr(out), B, C, F, H, W, cpad, scale, shift, int(clamp01),
                                     dtype_code(x.dtype), _stream()),
            "mmgt_nhwc_to_ncfhw")
+    return out
+
+
+def conv_taps_gather(y, bias, NB, H, W):
+    """y (NB * H * W, ldY >= 36) bf16 = the per-pixel products of a 4-channel 3 x 3 conv (column 4 tap + o: packing.pack_conv_taps) -> (NB, H, W, 8) bf16:
+    channels 0 .. 3 = bias + the sum over the taps of the neighbour pixels' products, 4 .. 7 zero."""
+    _dev(y, bias)
+    assert y.dim() == 2 and y.shape[0] == NB * H * W and y.shape[1] >= 36 and y.stride(1) == 1 and y.dtype == torch.bfloat16
+    out = torch.empty((NB, H, W, 8), device=y.device, dtype=y.dtype)
+    _check(lib().mmgt_conv_taps_gather(_ptr(y), y.stride(0), _ptr(_f32(bias, "bias")), _ptr(out), NB, H, W, dtype_code(y.dtype), _stream()),
+           "mmgt_conv_taps_gather")
     return out
 
 

@@ -45,6 +45,16 @@ def pack_conv3x3_up2(w):
     return out.to(w.dtype).contiguous()
 
 
+def pack_conv_taps(w):
+    """(4, 320, 3, 3) -> the pack_rowgemm image of the (64, 320) matrix whose row 4 tap + o is w[o, :, ky, kx] (tap = 3 ky + kx; rows 36 .. 63 zero):
+    a 3 x 3 conv with four output channels as ONE GEMM over the pixels' channels for all nine taps + `hip.conv_taps_gather`."""
+    co, cin = w.shape[:2]
+    assert co == 4 and tuple(w.shape[2:]) == (3, 3)
+    m = torch.zeros((64, cin), device=w.device, dtype=w.dtype)
+    m[:36] = w.permute(2, 3, 0, 1).reshape(36, cin)
+    return pack_rowgemm(m)
+
+
 def pad_rows(w, n_pad):
     """Zero-pad the output (row) dimension of a [N, K] weight / [N] bias."""
     if w is None or w.shape[0] == n_pad:

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional, Union
 import torch
 
 from . import hip
-from .packing import pack_conv3x3, pack_conv3x3_up2, pack_ff_fused, pack_ff_proj_out, pack_geglu, pack_rconv, pack_rowgemm, pack_tleg, pad_cols, pad_rows, round_up
+from .packing import pack_conv3x3, pack_conv3x3_up2, pack_conv_taps, pack_ff_fused, pack_ff_proj_out, pack_geglu, pack_rconv, pack_rowgemm, pack_tleg, pad_cols, pad_rows, round_up
 from .unet3d_spec import unet3d_spec
 
 SD15_CONFIG = dict(  # SD-1.5 unet/config.json + unet_3d.py:649-662 + config/prompts/animation.yaml:47-75
@@ -302,6 +302,10 @@ class UNet3DConditionModel:
 
         conv("conv_in", cin_pad=64)
         conv("conv_out", cout_pad=64)
+        if self._dtype == torch.bfloat16 and hip.tune_get("conv_out_taps") and has("conv_out.weight") and tuple(sd["conv_out.weight"].shape) == (4, 320, 3, 3) \
+                and hip.rowgemm320_supported(self._dtype, 320, 64):
+            # conv_norm_out + SiLU + conv_out as ONE 36-column GEMM over the pixels (all nine taps) + a gather of the neighbours' products
+            w["conv_out.timg"] = pack_conv_taps(sd["conv_out.weight"].to(self._device))
         norm("conv_norm_out")
         lin("time_embedding.linear_1")
         lin("time_embedding.linear_2")
@@ -965,6 +969,12 @@ class UNet3DConditionModel:
                 else:
                     x = hip.conv3x3(x, self.w[f"{p}.upsamplers.0.conv.w"], self.w[f"{p}.upsamplers.0.conv.bias"], upsample=True)
 
+        timg = self.w.get("conv_out.timg")
+        nb, h, ww, c = x.shape
+        if timg is not None and c == 320 and (h * ww) % 128 == 0:
+            sc, sh = hip.groupnorm_affine(x.view(nb, h * ww, c), self.w["conv_norm_out.g"], self.w["conv_norm_out.b"], 32, self.config.norm_eps)
+            y, _ = hip.rowgemm320(x.view(nb * h * ww, c), timg, 64, pre_scale=sc, pre_shift=sh, pre_rows=h * ww, pre_silu=True)
+            return hip.conv_taps_gather(y, self.w["conv_out.bias"], nb, h, ww)
         x = self._gn("conv_norm_out", x, self.config.norm_eps, silu=True)
         x = hip.conv3x3(x, self.w["conv_out.w"], self.w["conv_out.bias"])
         return x

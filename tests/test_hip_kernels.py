@@ -302,6 +302,33 @@ def test_conv3x3_upsample_as_four_phase_convs(nb, cin, cout, h, w_):
     assert torch.equal(hip.conv3x3(xi, pack_conv3x3_up2(wi), None, upsample=2), hip.conv3x3(xi, pack_conv3x3(wi), None, upsample=True))
 
 
+@pytest.mark.parametrize("nb,h,w_", [(3, 16, 8), (2, 64, 64), (5, 8, 16), (1, 16, 24)])
+def test_conv_out_as_gemm_over_the_taps_and_gather(nb, h, w_):
+    """conv_norm_out -> SiLU -> conv_out (320 -> 4 channels, unet_3d.py:608-620) as ONE 36-column GEMM over every pixel's channels (all nine taps;
+    GroupNorm tables + SiLU applied in `rowgemm320`'s prologue) + `conv_taps_gather` (sum of the neighbours' products, zero padding, bias) against
+    torch in fp64 and against GroupNorm pass + implicit-GEMM conv (padded to 64 columns) on the same operands; channels 4 .. 7 are zero."""
+    from mmgt_amd import hip
+    from mmgt_amd.packing import pack_conv3x3, pack_conv_taps, pad_rows
+    dt = torch.bfloat16
+    x = rnd("co.x", (nb, h, w_, 320), 1.5, dt) + rnd("co.m", (320,), 1.0).to(dt)
+    g, b = rnd("co.g", (320,), 0.2) + 1.0, rnd("co.b", (320,), 0.2)
+    w = rnd("co.w", (4, 320, 3, 3), 1.0 / math.sqrt(9 * 320), dt)
+    bias = rnd("co.bias", (4,), 0.5)
+    xn = F.silu(F.group_norm(x.double().permute(0, 3, 1, 2), 32, g.double(), b.double(), 1e-5))
+    ref = F.conv2d(xn, w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    sc, sh = hip.groupnorm_affine(x.view(nb, h * w_, 320), g, b, 32, 1e-5)
+    y, _ = hip.rowgemm320(x.view(nb * h * w_, 320), pack_conv_taps(w), 64, pre_scale=sc, pre_shift=sh, pre_rows=h * w_, pre_silu=True)
+    out = hip.conv_taps_gather(y, bias, nb, h, w_)
+    assert out.shape == (nb, h, w_, 8) and (out[..., 4:] == 0).all()
+    torch.testing.assert_close(out[..., :4].double(), ref, **tol(dt))
+    old = hip.conv3x3(hip.groupnorm(x.view(nb, h * w_, 320), g, b, 32, 1e-5, silu=True).view(nb, h, w_, 320), pack_conv3x3(w, None, 64),
+                      pad_rows(bias, 64))[..., :4]
+    e_new, e_old = (out[..., :4].double() - ref).abs().mean().item(), (old.double() - ref).abs().mean().item()
+    assert e_new <= 2.0 * e_old + 1e-6, (e_new, e_old)       # (nine products rounded to bf16 before their sum; the implicit GEMM rounds once)
+    y2, _ = hip.rowgemm320(x.view(nb * h * w_, 320), pack_conv_taps(w), 64, pre_scale=sc, pre_shift=sh, pre_rows=h * w_, pre_silu=True)
+    assert torch.equal(out, hip.conv_taps_gather(y2, bias, nb, h, w_))
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_conv3x3_two_sources(dt):
     from mmgt_amd import hip
