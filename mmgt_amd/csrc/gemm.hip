@@ -1010,6 +1010,42 @@ extern "C" int mmgt_tune(const char* key, int value) {
   return 1;
 }
 
+// out[m][n] = act(bias[n] + W[n] . A[m]) for M <= 4 rows (the time-embedding MLP and the resnets' time_emb_proj of one timestep: unet_3d.py:
+// 480-500, resnet.py:225-226): a wave per output column streams its weight row once with 16-byte loads against the rows of A (re-read from L2), sums
+// across its lanes in a fixed order.  The tile kernels launch 128 x 128 tiles for these: 25 - 35 us per call against the few us the weights take to stream.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_kernel(const T* __restrict__ A, long lda, const T* __restrict__ W, const float* __restrict__ bias,
+                                                   T* __restrict__ out, long ldo, int M, int N, int K, int act) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const T* w = W + (long)n * K;
+  for (int k = lane * VEC; k < K; k += 64 * VEC) {
+    union { u32x4 u; T e[VEC]; } wv, av;
+    wv.u = *reinterpret_cast<const u32x4*>(w + k);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      if (m < M) {
+        av.u = *reinterpret_cast<const u32x4*>(A + m * lda + k);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[m] = fmaf(Elem<T>::ld(&wv.e[e]), Elem<T>::ld(&av.e[e]), acc[m]);
+      }
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    float v = acc[m];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0 && m < M) {
+      v += bias ? bias[n] : 0.f;
+      if (act == 2) v = silu_f(v);
+      Elem<T>::st(out + m * ldo + n, v);
+    }
+  }
+}
+}  // namespace
+
 static int gemm_entry(const void* A, long lda, const void* W, const float* bias, const float* bias2, int bias2_rows,
                       const float* row_scale, float alpha, const float* bias_post, const void* residual, long ldr, void* out,
                       long ldo, int M, int N, int K, int act, int batch, long bsA, long bsW, long bsR, long bsO, int dtype,
@@ -1025,6 +1061,16 @@ static int gemm_entry(const void* A, long lda, const void* W, const float* bias,
              "gemm: A/W must be 16-byte aligned with 16-byte aligned rows");
   MMGT_CHECK(((long)(M - 1) * lda + K) * esz < (1l << 31) && (long)N * K * esz < (1l << 31),
              "gemm: an operand (per batch entry) exceeds the 2 GiB range of the 32-bit LDS-DMA offsets");
+  if (M <= 4 && batch == 1 && !bias2 && !row_scale && alpha == 1.f && !bias_post && !residual && (act == 0 || act == 2) && K % (16 / esz) == 0) {
+    if (dtype == MMGT_BF16)
+      hipLaunchKernelGGL(gemv_kernel<bf16_t>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A, lda, (const bf16_t*)W, bias,
+                         (bf16_t*)out, ldo, M, N, K, act);
+    else
+      hipLaunchKernelGGL(gemv_kernel<float>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)A, lda, (const float*)W, bias,
+                         (float*)out, ldo, M, N, K, act);
+    MMGT_LAUNCH_CHECK();
+    return 0;
+  }
   ADesc ad{};
   ad.src0 = (const char*)A;
   ad.ld0 = lda;

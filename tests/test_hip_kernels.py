@@ -383,6 +383,26 @@ def test_gemm16_blocked_tile_order_is_a_permutation(M, N):
     torch.testing.assert_close(row_major.double(), ref_gemm(a, w) + b.double(), **tol(torch.bfloat16))
 
 
+@pytest.mark.parametrize("dt", DT)
+@pytest.mark.parametrize("M,N,K,act", [(1, 1280, 320, 2), (1, 1280, 1280, 0), (1, 20160, 1280, 0), (2, 1282, 320, 0), (4, 640, 64, 2), (3, 7, 1280, 0)])
+def test_gemm_of_a_few_rows(dt, M, N, K, act):
+    """M <= 4 rows (the time-embedding MLP, every resnet's time_emb_proj of one timestep) run on a wave-per-column kernel (csrc/gemm.hip
+    gemv_kernel) instead of 128 x 128 tiles: against fp64, bias and SiLU, column counts off the workgroup size, both element types."""
+    from mmgt_amd import hip
+    a = rnd("gv.a", (M, K), 1.0, dt)
+    w = rnd("gv.w", (N, K), K ** -0.5, dt)
+    b = rnd("gv.b", (N,), 0.5)
+    ref = ref_gemm(a, w) + b.double()
+    if act == 2:
+        ref = F.silu(ref)
+    out = hip.gemm(a, w, b, act=hip.ACT_SILU if act == 2 else hip.ACT_NONE)
+    assert out.shape == (M, N)
+    torch.testing.assert_close(out.double(), ref, **tol(dt))
+    assert torch.equal(out, hip.gemm(a, w, b, act=hip.ACT_SILU if act == 2 else hip.ACT_NONE))
+    nob = hip.gemm(a, w)
+    torch.testing.assert_close(nob.double(), ref_gemm(a, w), **tol(dt))
+
+
 def test_gemm16_start_stagger_changes_no_result():
     """Every second CU's workgroup of a short reduction with a residual epilogue starts late (csrc/gemm16.hip `stg`: the chip is then not in
     the tile-end phase all at once): timing only -- the result is bitwise that of the unstaggered launch, for the shape rule's default too."""
