@@ -1010,7 +1010,7 @@ extern "C" int mmgt_tune(const char* key, int value) {
   return 1;
 }
 
-// out[m][n] = act(bias[n] + W[n] . A[m]) for M <= 4 rows (the time-embedding MLP and the resnets' time_emb_proj of one timestep: unet_3d.py:
+// out[m][n] = act(bias[n] + W[n] . A[m]) for a single row (the kernel handles up to 4; the dispatcher sends M == 1: the time-embedding MLP and the resnets' time_emb_proj of one timestep: unet_3d.py:
 // 480-500, resnet.py:225-226): a wave per output column streams its weight row once with 16-byte loads against the rows of A (re-read from L2), sums
 // across its lanes in a fixed order.  The tile kernels launch 128 x 128 tiles for these: 25 - 35 us per call against the few us the weights take to stream.
 namespace {
@@ -1061,7 +1061,9 @@ static int gemm_entry(const void* A, long lda, const void* W, const float* bias,
              "gemm: A/W must be 16-byte aligned with 16-byte aligned rows");
   MMGT_CHECK(((long)(M - 1) * lda + K) * esz < (1l << 31) && (long)N * K * esz < (1l << 31),
              "gemm: an operand (per batch entry) exceeds the 2 GiB range of the 32-bit LDS-DMA offsets");
-  if (M <= 4 && batch == 1 && !bias2 && !row_scale && alpha == 1.f && !bias_post && !residual && (act == 0 || act == 2) && K % (16 / esz) == 0) {
+  if (M == 1 && batch == 1 && !bias2 && !row_scale && alpha == 1.f && !bias_post && !residual && (act == 0 || act == 2) && K % (16 / esz) == 0) {
+    // (M == 1 only: a CFG row run alone halves M, and where that crossed the kernels' boundary -- 6 rows batched, 3 alone -- the fp32 parity mode's
+    //  "one row alone == that row of the batch" gate saw two summation orders; one timestep is one row either way)
     if (dtype == MMGT_BF16)
       hipLaunchKernelGGL(gemv_kernel<bf16_t>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A, lda, (const bf16_t*)W, bias,
                          (bf16_t*)out, ldo, M, N, K, act);

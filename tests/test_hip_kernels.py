@@ -384,10 +384,11 @@ def test_gemm16_blocked_tile_order_is_a_permutation(M, N):
 
 
 @pytest.mark.parametrize("dt", DT)
-@pytest.mark.parametrize("M,N,K,act", [(1, 1280, 320, 2), (1, 1280, 1280, 0), (1, 20160, 1280, 0), (2, 1282, 320, 0), (4, 640, 64, 2), (3, 7, 1280, 0)])
+@pytest.mark.parametrize("M,N,K,act", [(1, 1280, 320, 2), (1, 1280, 1280, 0), (1, 20160, 1280, 0), (1, 1282, 320, 0), (1, 7, 1280, 2), (2, 1282, 320, 0), (4, 640, 64, 2)])
 def test_gemm_of_a_few_rows(dt, M, N, K, act):
-    """M <= 4 rows (the time-embedding MLP, every resnet's time_emb_proj of one timestep) run on a wave-per-column kernel (csrc/gemm.hip
-    gemv_kernel) instead of 128 x 128 tiles: against fp64, bias and SiLU, column counts off the workgroup size, both element types."""
+    """One row (the time-embedding MLP, every resnet's time_emb_proj of one timestep) runs on a wave-per-column kernel (csrc/gemm.hip
+    gemv_kernel) instead of 128 x 128 tiles; 2 .. 4 rows stay on the tiles (see the dispatcher): against fp64, bias and SiLU, column counts off
+    the workgroup size, both element types."""
     from mmgt_amd import hip
     a = rnd("gv.a", (M, K), 1.0, dt)
     w = rnd("gv.w", (N, K), K ** -0.5, dt)
