@@ -61,7 +61,7 @@ const char* mmgt_last_error(void);
  * head_dim-40 attention kernels, the producer / consumer FeedForward) are records under tools/micro/. */
 int mmgt_tune(const char* key, int value);
 /* Host-side switches kept in the same table (what mmgt_amd/unet3d.py, pipeline.py and smga.py consult; all default 1, 0 = the
- * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "tleg", "up2" (the up-sampling convs in the four-phase form), "conv_out_taps" (conv_norm_out + SiLU + conv_out as a 36-column GEMM + a gather), "rconv" (a mask: 1 the 320-wide resnets, 2 the 640-wide, 4 the 1280-wide), "gnconv" (mmgt_amd/vae.py),
+ * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "tleg", "up2" (the up-sampling convs in the four-phase form), "conv_out_taps" (conv_norm_out + SiLU + conv_out as a 36-column GEMM + a gather), "sc_cat" (conv_shortcut over [x | skip] as one two-source launch), "rconv" (a mask: 1 the 320-wide resnets, 2 the 640-wide, 4 the 1280-wide), "gnconv" (mmgt_amd/vae.py),
  * "zero_audio_skip", "window_state", "smga_graph".  mmgt_tune sets them, mmgt_tune_get reads them: one state describes a run. */
 int mmgt_tune_get(const char* key, int* value);
 /* Box calibration for bench.py's `box_calib` (csrc/calib.hip): a bare v_mfma_f32_16x16x32_bf16 loop on random operands, one wave per SIMD,
@@ -107,6 +107,13 @@ int mmgt_gemm_post(const void* A, long lda, const void* W, const float* bias, co
 int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1, int NB, int IH, int IW, int stride, int upsample,
                       const void* Wp, const float* bias, const float* bias2, int bias2_rows, const void* residual,
                       void* out, int Cout, int act, int dtype, void* stream);
+
+/* 1 x 1 conv over the channel concatenation of two channels-last tensors, out[p][o] = bias[o] + Wp[o] . [x0[p] | x1[p]] (+ residual[p][o]): the
+ * resnets' conv_shortcut over [hidden | skip] (resnet.py:243-245; unet_3d_blocks.py:941-969 concatenates first) as one launch -- the conv gather's
+ * two-source reduction with a single tap -- instead of two dense GEMMs chained through a residual.  bf16; `rows` pixels; C0, C1 multiples of 64, Cout a
+ * multiple of 256 or 320; Wp [Cout][C0 + C1]; residual / out (rows, Cout). */
+int mmgt_conv1x1_cat_nhwc(const void* x0, int C0, const void* x1, int C1, long rows, const void* Wp, const float* bias, const void* residual, void* out,
+                          int Cout, int dtype, void* stream);
 
 /* A 3 x 3 / pad 1 conv with FOUR output channels (conv_out, unet_3d.py:620) as a GEMM + this gather: Y (NB, H, W, ldY) bf16 holds, per pixel, the 36
  * products W[o][tap] . x[pixel] in column 4 tap + o (one GEMM over the pixel's channels for all nine taps: mmgt_rowgemm320 with norm = 3, the GroupNorm

@@ -812,7 +812,7 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
     else cfg = 1;
   }
   if (geglu && (cfg == 3 || cfg == 12)) cfg = 1;   // GEGLU pairs need 64-column wave tiles
-  if (MODE == 1 && ad.up == 2 && cfg != 16 && cfg != 17) cfg = N % 320 == 0 ? 17 : 16;   // the four-phase upsample conv exists in gemm16.hip only
+  if (MODE == 1 && ad.up >= 2 && cfg != 16 && cfg != 17) cfg = N % 320 == 0 ? 17 : 16;   // the four-phase upsample conv exists in gemm16.hip only
   // cfg 19 = gemm16's 192 x 320 tile (round 5): taken where 256-row tiles leave the last round of the persistent grid half empty.  With T
   // tiles on 256 CUs a launch runs ceil(T / 256) rounds of one tile time; a 192-row tile takes ~0.88 of a 256-row tile's time (three MFMA row
   // tiles per four W fragment reads instead of four).  Measured (tools/ab_cfg.py SET=bm192, profiles/r5/ab_cfg_bm192_r5.txt): 49 152 x 640
@@ -864,8 +864,8 @@ int launch(const ADesc& ad, const void* W, long bsw, const Epi& ep, int M, int N
       }
       return mmgt_gemm16_launch(MODE, bn, &ad, W, bsw, &ep, M, N, K, batch, s);
     }
-    if (MODE == 1 && ad.up == 2) {
-      mmgt_set_error("conv3x3: the four-phase upsample form needs the gemm16 path (bf16, 16-byte aligned bias, Cout %% 4 == 0)");
+    if (MODE == 1 && ad.up >= 2) {
+      mmgt_set_error("conv: the four-phase upsample form and the two-source 1 x 1 conv need the gemm16 path (bf16, 16-byte aligned bias, Cout %% 4 == 0)");
       return 1;
     }
     cfg = cfg == 16 ? 9 : geglu ? 1 : 12;   // (GEGLU pairs need 64-column wave tiles: not the 320-column tile)
@@ -957,6 +957,7 @@ HostSwitch g_host[] = {
     {"tleg", 1},             // a level-0 temporal-attention leg as one launch (csrc/tleg.hip)
     {"rconv", 5},            // the UNet resnets' GroupNorm + SiLU + conv3x3 legs as one launch (csrc/rconv.hip): a mask of 1 the 320-wide level, 2 the 640-wide, 4 the 1280-wide; 0 off
     {"conv_out_taps", 1},    // conv_norm_out + SiLU + conv_out (4 channels) as one 36-column GEMM over the pixels (GroupNorm + SiLU in its prologue) + a gather (0: GroupNorm pass + implicit-GEMM conv padded to 64 columns)
+    {"sc_cat", 1},           // the resnets' conv_shortcut over [x | skip] as one two-source 1 x 1 conv launch (0: two GEMMs chained through a residual)
     {"up2", 1},              // the convs behind a nearest 2x upsampling as four 2 x 2 convs on the stored image (packing.pack_conv3x3_up2; 0: 3 x 3 on the upsampled view)
     {"rconv_stats", 1},      // ... with the next GroupNorm's statistics from the launch's epilogue (0: a statistics pass over the tensor)
     {"gnconv", 2},           // the VAE's GroupNorm + SiLU + conv3x3 as one launch (csrc/gnconv.hip): 1 with a statistics pass, 2 statistics from the producing launch
@@ -1147,4 +1148,29 @@ extern "C" int mmgt_conv3x3_nhwc(const void* x0, int C0, const void* x1, int C1,
   if (up2) return launch<bf16_t, 1>(ad, Wp, (long)Cout * K, ep, (int)M, Cout, K, 4, s);
   return dtype == MMGT_BF16 ? launch<bf16_t, 1>(ad, Wp, 0, ep, (int)M, Cout, K, 1, s)
                             : launch<float, 1>(ad, Wp, 0, ep, (int)M, Cout, K, 1, s);
+}
+
+// 1 x 1 conv over the channel concatenation of two channels-last tensors: out[p][o] = bias[o] + W[o] . [x0[p] | x1[p]] (+ residual).  The resnets'
+// conv_shortcut over [hidden | skip] (resnet.py:243-245) as ONE launch through the conv gather of csrc/gemm16.hip (two sources, one tap) instead of
+// two dense GEMMs chained through a residual (the concatenation is never materialised either way).  bf16; C0, C1 multiples of 64; Wp [Cout][C0 + C1].
+extern "C" int mmgt_conv1x1_cat_nhwc(const void* x0, int C0, const void* x1, int C1, long rows, const void* Wp, const float* bias, const void* residual,
+                                     void* out, int Cout, int dtype, void* stream) {
+  MMGT_CHECK(x0 && x1 && Wp && out && rows > 0, "conv1x1_cat: null pointer");
+  MMGT_CHECK(dtype == MMGT_BF16, "conv1x1_cat: bf16 only");
+  MMGT_CHECK(C0 > 0 && C1 > 0 && C0 % 64 == 0 && C1 % 64 == 0 && (Cout % 256 == 0 || Cout % 320 == 0), "conv1x1_cat: C0 = %d, C1 = %d must be multiples of 64, Cout = %d of 256 or 320",
+             C0, C1, Cout);
+  MMGT_CHECK(rows < (1l << 31) && rows * C0 * 2 < (1l << 31) && rows * C1 * 2 < (1l << 31) && (long)Cout * (C0 + C1) * 2 < (1l << 31), "conv1x1_cat: an operand exceeds 2 GiB");
+  MMGT_CHECK((((uintptr_t)x0 | (uintptr_t)x1 | (uintptr_t)Wp | (uintptr_t)residual | (uintptr_t)out | (uintptr_t)bias) & 15) == 0, "conv1x1_cat: pointers must be 16-byte aligned");
+  const int K = C0 + C1;
+  if (check_common(dtype, (int)rows, Cout, K, 0)) return 1;
+  ADesc ad{};
+  // the rows as ONE image row of `rows` pixels: the centre tap of every pixel is the pixel itself, nothing reads a neighbour
+  ad.src0 = (const char*)x0; ad.src1 = (const char*)x1; ad.C0 = C0; ad.C1 = C1; ad.IH = 1; ad.IW = (int)rows; ad.OH = 1; ad.OW = (int)rows;
+  ad.stride = 1; ad.up = 3; ad.pad = 1;
+  make_fastdiv((unsigned)rows, ad.fd_hw);
+  make_fastdiv((unsigned)rows, ad.fd_ow);
+  Epi ep{};
+  ep.bias = bias; ep.alpha = 1.f; ep.residual = (const char*)residual; ep.ldr = Cout; ep.out = (char*)out; ep.ldo = Cout;
+  ep.fast = epi_fast(ep, Cout, Cout, 2);
+  return launch<bf16_t, 1>(ad, Wp, 0, ep, (int)rows, Cout, K, 1, (hipStream_t)stream);
 }

@@ -152,8 +152,10 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(ADesc ad, const char* __
         // up == 2: the conv behind a nearest 2x upsampling as FOUR 2 x 2 convs on the stored image, one per output phase (a, b) = grid.z:
         // output pixel (2 y + a, 2 x + b) sees input rows y + a - 1, y + a through the 3 x 3 weights summed per source pixel (the host's phase
         // image, packing.pack_conv3x3_up2): 16 instead of 36 multiply-adds per input pixel, the same sums
+        // up == 3: a 1 x 1 conv over the two sources (the resnets' conv_shortcut over [x | skip]): one tap, the centre -- the gather's two-source
+        // reduction without the nine taps (K = C0 + C1)
         const bool up2 = ad.up == 2;
-        const int ky = up2 ? p_tap >> 1 : p_tap / 3, kx = up2 ? p_tap & 1 : p_tap - ky * 3;
+        const int ky = up2 ? p_tap >> 1 : ad.up == 3 ? 1 : p_tap / 3, kx = up2 ? p_tap & 1 : ad.up == 3 ? 1 : p_tap - ky * 3;
         const int vh = ad.up == 1 ? ad.IH * 2 : ad.IH, vw = ad.up == 1 ? ad.IW * 2 : ad.IW;
         const bool second = p_c >= ad.C0 && ad.C1 > 0;
         const unsigned cpb = (unsigned)(second ? ad.C1 : ad.C0) * ESZ;   // bytes per pixel of the source tensor (< 2 GiB in all: host check)

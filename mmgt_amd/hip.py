@@ -56,6 +56,7 @@ _SIGS = {
     "mmgt_ncfhw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "mmgt_nhwc_to_ncfhw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int,
                                    c_int, c_void_p]),
+    "mmgt_conv1x1_cat_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mmgt_conv_taps_gather": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mmgt_timestep_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mmgt_ff_fused_image_bytes": (c_int, [c_int, c_int]),
@@ -747,6 +748,27 @@ def nhwc_to_ncfhw(x, B, C, scale=1.0, shift=0.0, clamp01=False):
     _check(lib().mmgt_nhwc_to_ncfhw(_ptr(x), _ptr(out), B, C, F, H, W, cpad, scale, shift, int(clamp01),
                                     dtype_code(x.dtype), _stream()),
            "mmgt_nhwc_to_ncfhw")
+    return out
+
+
+def conv1x1_cat_supported(dtype, c0, c1, cout):
+    return dtype == torch.bfloat16 and c0 % 64 == 0 and c1 % 64 == 0 and c0 > 0 and c1 > 0 and (cout % 256 == 0 or cout % 320 == 0)
+
+
+def conv1x1_cat(x0, x1, w, bias=None, residual=None, out=None):
+    """bias + [x0 | x1] . w^T (+ residual): x0 (rows, C0), x1 (rows, C1) bf16, w (Cout, C0 + C1) -> (rows, Cout), one launch (csrc/gemm16.hip's conv
+    gather over two sources with one tap): a resnet's conv_shortcut over the skip concatenation."""
+    _dev(x0, x1, w, bias, residual, out)
+    assert x0.dim() == 2 and x1.dim() == 2 and x0.shape[0] == x1.shape[0] and x0.is_contiguous() and x1.is_contiguous() and w.is_contiguous()
+    rows, c0, c1, cout = x0.shape[0], x0.shape[1], x1.shape[1], w.shape[0]
+    assert conv1x1_cat_supported(x0.dtype, c0, c1, cout) and w.shape == (cout, c0 + c1) and w.dtype == x0.dtype == x1.dtype
+    if out is None:
+        out = torch.empty((rows, cout), device=x0.device, dtype=x0.dtype)
+    assert out.shape == (rows, cout) and out.is_contiguous()
+    if residual is not None:
+        assert residual.shape == out.shape and residual.is_contiguous() and residual.dtype == x0.dtype
+    _check(lib().mmgt_conv1x1_cat_nhwc(_ptr(x0), c0, _ptr(x1), c1, rows, _ptr(w), _ptr(_f32(bias, "bias")), _ptr(residual), _ptr(out), cout,
+                                       dtype_code(x0.dtype), _stream()), "mmgt_conv1x1_cat_nhwc")
     return out
 
 

@@ -120,6 +120,7 @@ class UNet3DConditionModel:
         self._share_rows = bool(hip.tune_get("shared_rows"))      # conv_in + first resnet once for both CFG rows
         self._fuse_oz = bool(hip.tune_get("oz3"))                 # 0: the three masked audio out-projections as separate launches
         self._fuse_ln = bool(hip.tune_get("rowgemm"))             # 0: LayerNorm and q / k / v GEMMs as separate launches
+        self._sc_cat = bool(hip.tune_get("sc_cat"))               # a resnet's conv_shortcut over [x | skip] as one two-source launch (0: two GEMMs)
         self._up2 = bool(hip.tune_get("up2"))                     # the up-sampling convs as four 2 x 2 convs on the stored image (0: the 3 x 3 conv on the upsampled view)
         self._fuse_tleg = bool(hip.tune_get("tleg"))              # 0: a level-0 temporal-attention leg as three launches
         self._tables = None                                       # (reader key, data_ptr, images, (scale, shift)): GroupNorm tables handed from a conv's epilogue to the norm's reader
@@ -557,8 +558,12 @@ class UNet3DConditionModel:
                 res = hip.gemm(x.view(nb * hw, c0), wsc, self.w[p + ".sc.bias"])
             else:
                 c1 = skip.shape[3]
-                res = hip.gemm(x.view(nb * hw, c0), self._sc_split(p, c0, 0), self.w[p + ".sc.bias"])
-                res = hip.gemm(skip.view(nb * hw, c1), self._sc_split(p, c0, 1), None, residual=res)
+                if self._sc_cat and hip.conv1x1_cat_supported(self._dtype, c0, c1, cout) and nb * hw * max(c0, c1) * 2 < hip.DMA_LIMIT:
+                    # conv_shortcut over [x | skip] as one launch (two-source gather, one tap) instead of two GEMMs chained through a residual
+                    res = hip.conv1x1_cat(x.view(nb * hw, c0), skip.view(nb * hw, c1), wsc, self.w[p + ".sc.bias"])
+                else:
+                    res = hip.gemm(x.view(nb * hw, c0), self._sc_split(p, c0, 0), self.w[p + ".sc.bias"])
+                    res = hip.gemm(skip.view(nb * hw, c1), self._sc_split(p, c0, 1), None, residual=res)
             res = res.view(nb, h, ww, cout)
         else:
             assert skip is None

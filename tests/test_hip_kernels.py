@@ -329,6 +329,33 @@ def test_conv_out_as_gemm_over_the_taps_and_gather(nb, h, w_):
     assert torch.equal(out, hip.conv_taps_gather(y2, bias, nb, h, w_))
 
 
+@pytest.mark.parametrize("rows,c0,c1,cout,res", [(4096 * 3 + 37, 640, 320, 320, False), (5000, 320, 320, 320, True), (3072, 1280, 1280, 1280, False),
+                                                 (12288, 1280, 640, 1280, True), (777, 64, 128, 256, True), (49152, 640, 640, 640, False)])
+def test_conv1x1_over_two_sources(rows, c0, c1, cout, res):
+    """A resnet's conv_shortcut over the skip concatenation (resnet.py:243-245) as ONE launch -- gemm16's conv gather over two sources with a single
+    tap (`conv1x1_cat`) -- against fp64 and against the two dense GEMMs chained through a residual that it replaces; ragged row counts, split-K-sized
+    problems (3072 rows, K = 2560), with and without a residual; exact-integer operands must agree bit for bit."""
+    from mmgt_amd import hip
+    dt = torch.bfloat16
+    x0, x1 = rnd("sc.x0", (rows, c0), 1.0, dt), rnd("sc.x1", (rows, c1), 1.0, dt)
+    w = rnd("sc.w", (cout, c0 + c1), (c0 + c1) ** -0.5, dt)
+    b = rnd("sc.b", (cout,), 0.5)
+    r = rnd("sc.r", (rows, cout), 1.0, dt) if res else None
+    ref = torch.cat([x0, x1], 1).double() @ w.double().t() + b.double() + (r.double() if res else 0)
+    out = hip.conv1x1_cat(x0, x1, w, b, residual=r)
+    torch.testing.assert_close(out.double(), ref, **tol(dt))
+    two = hip.gemm(x1, w[:, c0:].contiguous(), None, residual=hip.gemm(x0, w[:, :c0].contiguous(), b))
+    if res:
+        two = (two.float() + r.float()).to(dt)
+    e1, e2 = (out.double() - ref).abs().mean().item(), (two.double() - ref).abs().mean().item()
+    assert e1 <= 1.05 * e2 + 1e-6, (e1, e2)          # (one rounding instead of two)
+    assert torch.equal(out, hip.conv1x1_cat(x0, x1, w, b, residual=r))
+    xi0, xi1 = torch.randint(-2, 3, (rows, c0), device=dev()).to(dt), torch.randint(-2, 3, (rows, c1), device=dev()).to(dt)
+    wi = torch.randint(-1, 2, (cout, c0 + c1), device=dev()).to(dt)
+    exact = (torch.cat([xi0, xi1], 1).float() @ wi.float().t()).to(dt)
+    assert torch.equal(hip.conv1x1_cat(xi0, xi1, wi), exact)
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_conv3x3_two_sources(dt):
     from mmgt_amd import hip
