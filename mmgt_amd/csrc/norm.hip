@@ -474,13 +474,13 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const T* __restrict__ x0,
 // (raw, 4 registers each) and makes the three passes over them.  gn_small_kernel pays three dependent memory round trips per launch, and
 // the two-kernel form (HW > 256) reads the tensor twice: 48 x 256 x 1280 took 31.6 us in the step and 48 x 1024 x 640 49.9 us, for 63 / 126 MB
 // moved (profiles/r6/opshapes_r6b.txt).  Slabs of up to 22 vectors per thread: every single-source level of the UNet below 64 x 64.
-template <typename T, int NR>
-__global__ __launch_bounds__(256) void gn_slab_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1,
+template <typename T, int NR, int NTHR = 256>
+__global__ __launch_bounds__(NTHR) void gn_slab_kernel(const T* __restrict__ x0, int C0, const T* __restrict__ x1, int C1,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       T* __restrict__ out, int HW, int G, int gpw, float eps, int silu,
                                                       float* __restrict__ tscale, float* __restrict__ tshift) {
   constexpr int VEC = VecIO<T>::VEC;
-  __shared__ float part[256 * VEC];
+  __shared__ float part[NTHR * VEC];
   __shared__ float chan[320];
   __shared__ float gstat[2][4];
   const int C = C0 + C1, cg = C / G, cw = gpw * cg, nvw = cw / VEC;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const T* __restrict__ x0, 
   }
   const int c_lo = sl * cw;
   const int tid = threadIdx.x;
-  const int rp = 256 / nvw;                 // rows per pass
+  const int rp = NTHR / nvw;                // rows per pass
   const int vc = tid % nvw, r0 = tid / nvw;
   const bool active = r0 < rp;
   const int c = c_lo + vc * VEC;
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const T* __restrict__ x0, 
 #pragma unroll
     for (int e = 0; e < VEC; ++e) part[tid * VEC + e] = active ? acc[e] : 0.f;
     __syncthreads();
-    for (int ch = tid; ch < cw; ch += 256) {
+    for (int ch = tid; ch < cw; ch += NTHR) {
       const int v = ch / VEC, e = ch % VEC;
       float s = 0.f;
       for (int r = 0; r < rp; ++r) s += part[(r * nvw + v) * VEC + e];
@@ -600,30 +600,41 @@ __global__ __launch_bounds__(256) void gn_slab_kernel(const T* __restrict__ x0, 
 // the slab kernel's shape rule: whole vectors per slab, <= 22 vectors per thread; small slabs take as many groups as leave <= 6 vectors per thread
 // (a workgroup's fixed cost -- two reductions, six barriers -- is as long as a few of its loads: 48 x 64 x 1280 as 1536 one-group workgroups
 // 12.1 us, as 384 four-group ones see profiles/r6/bench_gn_slab_r6.txt), larger ones the fewest groups that fit; 0 = does not fit
-inline int gn_slab_gpw(int C, int G, int HW, int vec, int* nr) {
+inline int gn_slab_gpw(int C, int G, int HW, int vec, int* nr, int* nthr) {
   const int cg = C / G;
-  auto need = [&](int gpw) {
+  auto need = [&](int gpw, int threads) {
     const int cw = gpw * cg;
     if (G % gpw || cw % vec || cw > 320 || cw / vec > 256) return 1 << 30;
-    const int rp = 256 / (cw / vec);
+    const int rp = threads / (cw / vec);
     return (HW + rp - 1) / rp;
   };
   int pick = 0;
+  *nthr = 256;
   for (int gpw = 4; gpw >= 1 && !pick; gpw >>= 1)
-    if (need(gpw) <= 6) pick = gpw;
+    if (need(gpw, 256) <= 6) pick = gpw;
   for (int gpw = 1; gpw <= 4 && !pick; gpw <<= 1)
-    if (need(gpw) <= 22) pick = gpw;
-  if (!pick) return 0;
-  const int n = need(pick);
+    if (need(gpw, 256) <= 22) pick = gpw;
+  if (!pick) {
+    // wide groups (the skip concatenations of the 32 x 32 level: 1920 / 960 channels = 60 / 30 per group, 15 vectors per slab row): 1024 threads hold
+    // the slab in <= 16 vectors each (128 registers per lane at 16 waves per workgroup)
+    for (int gpw = 1; gpw <= 4 && !pick; gpw <<= 1)
+      if (need(gpw, 1024) <= 16) pick = gpw;
+    if (!pick) return 0;
+    *nthr = 1024;
+    *nr = 16;
+    return pick;
+  }
+  const int n = need(pick, 256);
   *nr = n <= 2 ? 2 : n <= 4 ? 4 : n <= 6 ? 6 : n <= 12 ? 12 : 22;
   return pick;
 }
 template <typename T>
-void gn_slab_launch(int nr, dim3 grid, hipStream_t s, const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta, void* out, int HW,
-                    int G, int gpw, float eps, int silu, float* tscale, float* tshift) {
-#define GN_SLAB(NR_) hipLaunchKernelGGL((gn_slab_kernel<T, NR_>), grid, dim3(256), 0, s, (const T*)x0, C0, (const T*)x1, C1, gamma, beta, (T*)out, HW, G, gpw, eps, \
-                                        silu, tscale, tshift)
-  if (nr == 2) GN_SLAB(2); else if (nr == 4) GN_SLAB(4); else if (nr == 6) GN_SLAB(6); else if (nr == 12) GN_SLAB(12); else GN_SLAB(22);
+void gn_slab_launch(int nr, int nthr, dim3 grid, hipStream_t s, const void* x0, int C0, const void* x1, int C1, const float* gamma, const float* beta, void* out,
+                    int HW, int G, int gpw, float eps, int silu, float* tscale, float* tshift) {
+#define GN_SLAB(NR_, NT_) hipLaunchKernelGGL((gn_slab_kernel<T, NR_, NT_>), grid, dim3(NT_), 0, s, (const T*)x0, C0, (const T*)x1, C1, gamma, beta, (T*)out, HW, G, gpw, \
+                                             eps, silu, tscale, tshift)
+  if (nthr == 1024) GN_SLAB(16, 1024);
+  else if (nr == 2) GN_SLAB(2, 256); else if (nr == 4) GN_SLAB(4, 256); else if (nr == 6) GN_SLAB(6, 256); else if (nr == 12) GN_SLAB(12, 256); else GN_SLAB(22, 256);
 #undef GN_SLAB
 }
 
@@ -728,12 +739,12 @@ extern "C" int mmgt_groupnorm_nhwc(const void* x0, int C0, const void* x1, int C
   MMGT_CHECK(NB > 0 && HW > 0 && NB <= 65535, "groupnorm: bad NB=%d HW=%d", NB, HW);
   hipStream_t s = (hipStream_t)stream;
   {
-    int nr = 0;
-    const int gpw = g_gn_slab ? gn_slab_gpw(C, G, HW, vec, &nr) : 0;
+    int nr = 0, nthr = 256;
+    const int gpw = g_gn_slab ? gn_slab_gpw(C, G, HW, vec, &nr, &nthr) : 0;
     if (gpw) {
       dim3 grid(G / gpw, NB);
-      if (dtype == MMGT_BF16) gn_slab_launch<bf16_t>(nr, grid, s, x0, C0, x1, C1, gamma, beta, out, HW, G, gpw, eps, silu, nullptr, nullptr);
-      else gn_slab_launch<float>(nr, grid, s, x0, C0, x1, C1, gamma, beta, out, HW, G, gpw, eps, silu, nullptr, nullptr);
+      if (dtype == MMGT_BF16) gn_slab_launch<bf16_t>(nr, nthr, grid, s, x0, C0, x1, C1, gamma, beta, out, HW, G, gpw, eps, silu, nullptr, nullptr);
+      else gn_slab_launch<float>(nr, nthr, grid, s, x0, C0, x1, C1, gamma, beta, out, HW, G, gpw, eps, silu, nullptr, nullptr);
       MMGT_LAUNCH_CHECK();
       return 0;
     }
@@ -810,12 +821,12 @@ extern "C" int mmgt_groupnorm_affine2(const void* x, int C0, const void* x1, int
   MMGT_CHECK(NB > 0 && HW > 0 && NB <= 65535, "groupnorm_affine: bad NB=%d HW=%d", NB, HW);
   hipStream_t s = (hipStream_t)stream;
   {
-    int nr = 0;
-    const int gpw = g_gn_slab ? gn_slab_gpw(C, G, HW, vec, &nr) : 0;      // the slab in registers: one read of the tensor, tables out
+    int nr = 0, nthr = 256;
+    const int gpw = g_gn_slab ? gn_slab_gpw(C, G, HW, vec, &nr, &nthr) : 0;      // the slab in registers: one read of the tensor, tables out
     if (gpw) {
       dim3 grid(G / gpw, NB);
-      if (dtype == MMGT_BF16) gn_slab_launch<bf16_t>(nr, grid, s, x, C0, x1, C1, gamma, beta, nullptr, HW, G, gpw, eps, 0, scale, shift);
-      else gn_slab_launch<float>(nr, grid, s, x, C0, x1, C1, gamma, beta, nullptr, HW, G, gpw, eps, 0, scale, shift);
+      if (dtype == MMGT_BF16) gn_slab_launch<bf16_t>(nr, nthr, grid, s, x, C0, x1, C1, gamma, beta, nullptr, HW, G, gpw, eps, 0, scale, shift);
+      else gn_slab_launch<float>(nr, nthr, grid, s, x, C0, x1, C1, gamma, beta, nullptr, HW, G, gpw, eps, 0, scale, shift);
       MMGT_LAUNCH_CHECK();
       return 0;
     }

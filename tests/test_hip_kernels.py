@@ -480,11 +480,12 @@ def test_groupnorm_narrow_rows(dt, c, hw, silu):
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("nb,c0,c1,hw,silu", [(8, 640, 0, 1024, False), (3, 640, 640, 1024, True), (8, 320, 0, 1024, True), (8, 1280, 0, 256, False),
                                               (3, 1280, 1280, 256, True), (8, 1280, 0, 64, True), (3, 1280, 1280, 64, True), (5, 640, 0, 900, True),
-                                              (8, 640, 0, 64, False), (2, 2560, 0, 16, True)])
+                                              (8, 640, 0, 64, False), (2, 2560, 0, 16, True), (3, 1280, 640, 1024, True), (8, 640, 320, 1024, True),
+                                              (2, 1920, 0, 1000, False)])
 def test_groupnorm_slab_in_registers(dt, nb, c0, c1, hw, silu):
     """csrc/norm.hip gn_slab_kernel: a workgroup = one image x 1 / 2 / 4 groups keeps its slab in registers (2 .. 22 vectors per thread: every
-    instantiation is hit here, both element types, one and two sources, ragged row counts, grids that are and are not a multiple of the 8
-    XCDs) and reads the tensor once.  Against torch in fp64 (values whose mean is 10 x their spread), against the multi-pass kernels it
+    instantiation is hit here -- the 1024-thread one for the 60- / 30-channel groups of the 32 x 32 level's skip concatenations too --, both element
+    types, one and two sources, ragged row counts, grids that are and are not a multiple of the 8 XCDs) and reads the tensor once.  Against torch in fp64 (values whose mean is 10 x their spread), against the multi-pass kernels it
     replaces on the same input, bitwise repeatable; the statistics-only entry (`groupnorm_affine`) against the tables of the full op."""
     from mmgt_amd import hip
     C = c0 + c1

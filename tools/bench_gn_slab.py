@@ -27,7 +27,7 @@ def t_us(fn, reps=20):
     return best
 
 
-SHAPES = [(48, 1024, 640, 0), (48, 1024, 320, 0), (48, 1024, 1280, 0), (48, 1024, 640, 640), (48, 256, 1280, 0), (48, 256, 640, 0), (48, 256, 1280, 1280),
+SHAPES = [(48, 1024, 1280, 640), (48, 1024, 640, 320), (48, 1024, 640, 0), (48, 1024, 320, 0), (48, 1024, 1280, 0), (48, 1024, 640, 640), (48, 256, 1280, 0), (48, 256, 640, 0), (48, 256, 1280, 1280),
           (48, 64, 1280, 0), (48, 64, 1280, 1280), (24, 1024, 640, 0), (24, 256, 1280, 0)]
 print(f"{'nb x hw x (c0 + c1)':28s} {'passes':>8s} {'slab':>8s}   {'stats: passes':>14s} {'slab':>8s}   TB/s of the slab form (read + write)   max|d| between the forms")
 for nb, hw, c0, c1 in SHAPES:
