@@ -110,22 +110,44 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x0,
   // registers next to the 2 x MAXS x VEC accumulators cost the kernel half its occupancy (174 VGPRs, 2 waves per SIMD)
   for (int c = threadIdx.x; c < C; c += 256) ssq[c] = ssum[c];
   __syncthreads();
-  for (int r = rows.r0 + wid * rpw + sub; r < r1; r += rows.step) {
+  // two row steps per pass: ten 16-byte loads in flight per lane and ONE read of a vector's pivots for both rows (a pass per row kept five loads
+  // in flight and read 32 bytes of pivots from LDS per 16 bytes loaded: 2.3 TB/s on the two-source statistics of the 64 x 64 level against 5.8 for
+  // the lane-per-vector kernel of one source)
+  for (int r = rows.r0 + wid * rpw + sub; r < r1; r += 2 * rows.step) {
     const long pix = (long)n * HW + r;
+    const bool two = r + rows.step < r1;
+    const long pix2 = two ? pix + rows.step : pix;
     int keep = 0;
     asm volatile("" : "+v"(keep));                    // opaque zero: keeps the pivot reads inside the row loop
+    u32x4 raw[2][MAXS];
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
       const int vc = li + lpr * i;
       if (vc < nvec) {
         const int c = vc * VEC;
-        const T* src = c < C0 ? x0 + pix * C0 + c : x1 + pix * C1 + (c - C0);
-        float f[VEC], pv[VEC];
-        VecIO<T>::load(src, f);
+        const bool first = c < C0;
+        const T* b0 = first ? x0 + c : x1 + (c - C0);
+        const long cs = first ? C0 : C1;
+        raw[0][i] = *reinterpret_cast<const u32x4*>(b0 + pix * cs);
+        raw[1][i] = *reinterpret_cast<const u32x4*>(b0 + pix2 * cs);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+      const int vc = li + lpr * i;
+      if (vc < nvec) {
+        const int c = vc * VEC;
+        float pv[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; e += 4) *reinterpret_cast<f32x4*>(&pv[e]) = *reinterpret_cast<const f32x4*>(&ssq[c + e + keep]);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { const float d = f[e] - pv[e]; s[i][e] += d; q[i][e] += d * d; }
+        for (int h = 0; h < 2; ++h) {
+          if (h == 1 && !two) continue;
+          union { u32x4 u; T e[VEC]; } v;
+          v.u = raw[h][i];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { const float d = Elem<T>::ld(&v.e[e]) - pv[e]; s[i][e] += d; q[i][e] += d * d; }
+        }
       }
     }
   }
