@@ -61,7 +61,7 @@ const char* mmgt_last_error(void);
  * head_dim-40 attention kernels, the producer / consumer FeedForward) are records under tools/micro/. */
 int mmgt_tune(const char* key, int value);
 /* Host-side switches kept in the same table (what mmgt_amd/unet3d.py, pipeline.py and smga.py consult; all default 1, 0 = the
- * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "tleg", "up2" (the up-sampling convs in the four-phase form), "conv_out_taps" (conv_norm_out + SiLU + conv_out as a 36-column GEMM + a gather), "sc_cat" (conv_shortcut over [x | skip] as one two-source launch), "rconv" (a mask: 1 the 320-wide resnets, 2 the 640-wide, 4 the 1280-wide), "gnconv" (mmgt_amd/vae.py),
+ * unfused / stateless form, for same-box A/Bs): "fused_ff", "twin_attention", "shared_rows", "oz3", "rowgemm", "tleg", "up2" (the up-sampling convs in the four-phase form), "conv_out_taps" (conv_norm_out + SiLU + conv_out as a 36-column GEMM + a gather), "sc_cat" (conv_shortcut over [x | skip] as one two-source launch), "ffpo_cat" (ff2 + proj_out of a block as one two-source GEMM), "rconv" (a mask: 1 the 320-wide resnets, 2 the 640-wide, 4 the 1280-wide), "gnconv" (mmgt_amd/vae.py),
  * "zero_audio_skip", "window_state", "smga_graph".  mmgt_tune sets them, mmgt_tune_get reads them: one state describes a run. */
 int mmgt_tune_get(const char* key, int* value);
 /* Box calibration for bench.py's `box_calib` (csrc/calib.hip): a bare v_mfma_f32_16x16x32_bf16 loop on random operands, one wave per SIMD,

@@ -957,6 +957,7 @@ HostSwitch g_host[] = {
     {"tleg", 1},             // a level-0 temporal-attention leg as one launch (csrc/tleg.hip)
     {"rconv", 5},            // the UNet resnets' GroupNorm + SiLU + conv3x3 legs as one launch (csrc/rconv.hip): a mask of 1 the 320-wide level, 2 the 640-wide, 4 the 1280-wide; 0 off
     {"conv_out_taps", 1},    // conv_norm_out + SiLU + conv_out (4 channels) as one 36-column GEMM over the pixels (GroupNorm + SiLU in its prologue) + a gather (0: GroupNorm pass + implicit-GEMM conv padded to 64 columns)
+    {"ffpo_cat", 1},         // a transformer block's ff2 (+ residual) and proj_out (+ residual) as ONE two-source GEMM with the host-multiplied weight [W_po W2 | W_po] (0: two GEMMs)
     {"sc_cat", 1},           // the resnets' conv_shortcut over [x | skip] as one two-source 1 x 1 conv launch (0: two GEMMs chained through a residual)
     {"up2", 1},              // the convs behind a nearest 2x upsampling as four 2 x 2 convs on the stored image (packing.pack_conv3x3_up2; 0: 3 x 3 on the upsampled view)
     {"rconv_stats", 1},      // ... with the next GroupNorm's statistics from the launch's epilogue (0: a statistics pass over the tensor)

@@ -120,6 +120,8 @@ class UNet3DConditionModel:
         self._share_rows = bool(hip.tune_get("shared_rows"))      # conv_in + first resnet once for both CFG rows
         self._fuse_oz = bool(hip.tune_get("oz3"))                 # 0: the three masked audio out-projections as separate launches
         self._fuse_ln = bool(hip.tune_get("rowgemm"))             # 0: LayerNorm and q / k / v GEMMs as separate launches
+        self._ffpo_cat = bool(hip.tune_get("ffpo_cat"))           # ff2 + residual + proj_out + residual of a block as one two-source GEMM (0: two GEMMs)
+        self._ffpo = {}
         self._sc_cat = bool(hip.tune_get("sc_cat"))               # a resnet's conv_shortcut over [x | skip] as one two-source launch (0: two GEMMs)
         self._up2 = bool(hip.tune_get("up2"))                     # the up-sampling convs as four 2 x 2 convs on the stored image (0: the 3 x 3 conv on the upsampled view)
         self._fuse_tleg = bool(hip.tune_get("tleg"))              # 0: a level-0 temporal-attention leg as three launches
@@ -235,6 +237,7 @@ class UNet3DConditionModel:
         self._loaded = True
         self._ehs_cache = None
         self._zbias = {}
+        self._ffpo = {}
         self._banks = {}
         return missing, unexpected
 
@@ -521,8 +524,31 @@ class UNet3DConditionModel:
         if img is not None and po is not None and (q + ".proj_out.bias") in self.w:
             return hip.ff_fused_po(hid, self.w[norm + ".g"], self.w[norm + ".b"], img, self.w[p + ".ff2.bias"], hid,
                                    self.w[p + ".ff2.w"].shape[1], po, self.w[q + ".proj_out.bias"], x_res)
+        wcat = self._ffpo_weights(p, q) if img is None else None
+        if wcat is not None and hid.shape[0] * max(wcat[0].shape[1] - hid.shape[1], hid.shape[1]) * 2 < hip.DMA_LIMIT:
+            # proj_out(hid + b2 + W2 g) + x_res = [W_po W2 | W_po] . [g | hid] + (b_po + W_po b2) + x_res: the block's last two GEMMs as ONE over the
+            # two sources g (GEGLU output) and hid -- the FeedForward's result is read by nothing else (transformer_3d.py:262-268, motion_module.py:178-182)
+            g = hip.gemm(self._ln(norm, hid), self.w[p + ".ff1.w"], self.w[p + ".ff1.bias"], act=hip.ACT_GEGLU)
+            return hip.conv1x1_cat(g, hid, wcat[0], wcat[1], residual=x_res)
         hid = self._norm_ff(p, norm, hid)
         return hip.gemm(hid, self.w[q + ".proj_out.w"], self.w.get(q + ".proj_out.bias"), residual=x_res)
+
+    def _ffpo_weights(self, p, q):
+        """([W_po W2 | W_po] (C, inner + C) in the model dtype, b_po + W_po b2 (fp32)) of a transformer block whose FeedForward output feeds proj_out
+        alone; products in fp32 from the stored weights, rounded once.  None where the one-launch form does not apply."""
+        key = p + ".ffpo"
+        if key not in self._ffpo:
+            w2, wpo = self.w.get(p + ".ff2.w"), self.w.get(q + ".proj_out.w")
+            ok = self._ffpo_cat and w2 is not None and wpo is not None and (p + ".ff2.bias") in self.w and (q + ".proj_out.bias") in self.w and \
+                wpo.shape[0] == wpo.shape[1] == w2.shape[0] and hip.conv1x1_cat_supported(self._dtype, w2.shape[1], w2.shape[0], wpo.shape[0])
+            if ok:
+                wpf = wpo.float()
+                wc = torch.cat([wpf @ w2.float(), wpf], 1).to(self._dtype).contiguous()
+                bc = (self.w[q + ".proj_out.bias"].float() + wpf @ self.w[p + ".ff2.bias"].float()).contiguous()
+                self._ffpo[key] = (wc, bc)
+            else:
+                self._ffpo[key] = None
+        return self._ffpo[key]
 
     def _resnet(self, p, x, temb, skip=None, out=None, reader=None):
         """ResnetBlock3D (resnet.py:217-247); `skip` = the UNet skip tensor that the reference concatenates first.  reader: key of the

@@ -356,6 +356,29 @@ def test_conv1x1_over_two_sources(rows, c0, c1, cout, res):
     assert torch.equal(hip.conv1x1_cat(xi0, xi1, wi), exact)
 
 
+@pytest.mark.parametrize("rows,C,inner", [(4096 + 64, 640, 2560), (3072, 1280, 5120)])
+def test_ff2_and_proj_out_as_one_two_source_gemm(rows, C, inner):
+    """A transformer block's tail, proj_out(hid + b2 + W2 g) + x_res (transformer_3d.py:262-268), as ONE GEMM over the two sources g and hid with the
+    host-multiplied weight [W_po W2 | W_po] and bias b_po + W_po b2 (unet3d.py `_ffpo_weights`) against fp64 and against the two chained GEMMs
+    (whose intermediate is rounded to bf16 once more)."""
+    from mmgt_amd import hip
+    dt = torch.bfloat16
+    g = rnd("fp.g", (rows, inner), 1.0, dt)
+    hid = rnd("fp.h", (rows, C), 1.0, dt)
+    xres = rnd("fp.x", (rows, C), 1.0, dt)
+    w2, b2 = rnd("fp.w2", (C, inner), inner ** -0.5, dt), rnd("fp.b2", (C,), 0.3)
+    wpo, bpo = rnd("fp.wpo", (C, C), C ** -0.5, dt), rnd("fp.bpo", (C,), 0.3)
+    ref = (hid.double() + b2.double() + g.double() @ w2.double().t()) @ wpo.double().t() + bpo.double() + xres.double()
+    wpf = wpo.float()
+    wcat = torch.cat([wpf @ w2.float(), wpf], 1).to(dt).contiguous()
+    bcat = (bpo + wpf @ b2).contiguous()
+    one = hip.conv1x1_cat(g, hid, wcat, bcat, residual=xres)
+    two = hip.gemm(hip.gemm(g, w2, b2, residual=hid), wpo, bpo, residual=xres)
+    torch.testing.assert_close(one.double(), ref, **tol(dt))
+    e1, e2 = (one.double() - ref).abs().mean().item(), (two.double() - ref).abs().mean().item()
+    assert e1 <= 1.25 * e2 + 1e-6, (e1, e2)
+
+
 @pytest.mark.parametrize("dt", DT)
 def test_conv3x3_two_sources(dt):
     from mmgt_amd import hip
