@@ -21,6 +21,13 @@ def key_of(name, args, kw):
         epi = ("geglu" if kw.get("act") == hip.ACT_GEGLU else "") + ("+res" if kw.get("residual") is not None else "") + \
               ("+b2" if kw.get("bias2") is not None else "") + ("+rs" if kw.get("row_scale") is not None else "")
         return f"gemm M={a.shape[0]} N={w.shape[0]} K={a.shape[1]} {epi}", 2 * a.shape[0] * w.shape[0] * a.shape[1]
+    if name == "conv1x1_cat":
+        x0, x1, w = args[0], args[1], args[2]
+        res = kw.get("residual") is not None or (len(args) > 4 and args[4] is not None)
+        return (f"conv1x1_cat M={x0.shape[0]} N={w.shape[0]} K={x0.shape[1]}+{x1.shape[1]} (two sources, one launch){' +res' if res else ''}",
+                2 * x0.shape[0] * w.shape[0] * (x0.shape[1] + x1.shape[1]))
+    if name == "conv_taps_gather":
+        return f"conv_taps_gather nb={args[2]} h={args[3]} (conv_out: sum of the neighbours' products)", 0
     if name == "gemm_bf16_f32":
         a, w = args[0], args[1]
         return f"gemm_bf16_f32 M={a.shape[0]} N={w.shape[0]} K={a.shape[1]} (bf16 pieces -> fp32)", 2 * a.shape[0] * w.shape[0] * a.shape[1]
@@ -113,7 +120,7 @@ def main():
     if len(sys.argv) > 2:                                       # window length (the reference ships context_frames = 12)
         bench.FRAMES = int(sys.argv[2])
         bench.build_inputs.__defaults__ = (bench.FRAMES,) + bench.build_inputs.__defaults__[1:]
-    for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "ff_fused", "ff_fused_po", "temporal_leg320", "rowgemm320", "groupnorm_affine", "gn_silu_conv3x3_unet", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
+    for n in ["gemm", "gemm_post", "gemm_batched_wx", "gemm_batched", "ff_fused", "ff_fused_po", "temporal_leg320", "rowgemm320", "groupnorm_affine", "gn_silu_conv3x3_unet", "conv1x1_cat", "conv_taps_gather", "conv3x3", "groupnorm", "layernorm", "attention", "softmax_rows",
               "ncfhw_to_nhwc", "nhwc_to_ncfhw", "timestep_features", "silu", "cfg_ddim_step", "accumulate_window"]:
         wrap(n)
     sys.argv = ["bench.py", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-calib"]
